@@ -1,0 +1,155 @@
+/*
+ * warpsense_hip.h — C ABI of libwarpsense_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for warpsense's data-parallel hot path: every entry point below replaces one
+ * member of the reference's CUDA device API (file:line under the reference tree given per function).
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.  The header-only C++
+ * classes with the reference's names (cuda::TSDFCuda, cuda::RegistrationCuda, cuda::DeviceMap,
+ * cuda::DeviceMapMemWrapper, cuda::pause/cleanup) live in include/warpsense_hip/compat.hpp and forward
+ * to these functions; INTEGRATION.md shows the reference-side wiring.
+ *
+ * Conventions
+ *   - all geometry is integer millimetres / voxel indices exactly as in the reference
+ *     (include/warpsense/consts.h: MATRIX_RESOLUTION 32768, WEIGHT_RESOLUTION 64);
+ *   - a voxel is a packed TSDFEntry: low 16 bits value, high 16 bits weight (include/map/tsdf.h:16-23);
+ *   - matrices are column-major like rmagine::Matrix4x4f / Matrix6x6l and Eigen
+ *     (include/warpsense/math/matrix4x4.h:175-185, matrix6x6.h:112-115);
+ *   - every function returns WS_OK (0) or a negative ws_status; ws_last_error() gives the message of
+ *     the calling thread's last failure.  Nothing throws across the ABI.
+ *   - work is stream-ordered on the context's HIP stream; functions that return host data synchronise.
+ *
+ * Result semantics: the TSDF scatter is resolved in the canonical serial order of the reference kernel
+ * (ascending point index, ray step, fan step — SURVEY.md §7 H1), so results are deterministic and
+ * bit-identical to oracle/ws_oracle.c.
+ */
+#ifndef WARPSENSE_HIP_H
+#define WARPSENSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ws_context ws_context; /* one per (process, GPU): device id + stream                          */
+typedef struct ws_map ws_map;         /* cuda::TSDFCuda: avg_map_ + new_map_ + scan buffer (update_tsdf.h:9-34) */
+typedef struct ws_reg ws_reg;         /* cuda::RegistrationCuda (registration.h:10-45)                          */
+
+typedef enum
+{
+  WS_OK = 0,
+  WS_ERR_INVALID = -1,     /* bad argument                                             */
+  WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
+  WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
+  WS_ERR_CAPACITY = -4,    /* contested-voxel arena exhausted (see ws_tsdf_stats)       */
+  WS_ERR_RANGE = -5        /* ray too long for the order key            */
+} ws_status;
+
+#define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
+#define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
+
+/* integrate pass selection, ws_tsdf_set_integrate() */
+#define WS_INTEGRATE_SPARSE 0 /* stream only 64-voxel tiles the scan touched (default)                 */
+#define WS_INTEGRATE_DENSE 1  /* stream every voxel like cu_avg_tsdf_krnl (update_tsdf.cu:13-43)       */
+
+/* registration flags */
+#define WS_REG_ALL_POINTS 0u
+#define WS_REG_COMPAT_REFERENCE_LAUNCH 1u /* reproduce the <<<128,512>>> / N%32 coverage of registration.cu:353-356 */
+
+const char *ws_last_error(void);
+int ws_version(void);
+
+/* ------------------------------------------------------------------ context ---- */
+/* cuda runtime implicit context of the reference; device_id < 0 -> current device */
+int ws_ctx_create(int device_id, ws_context **out);
+int ws_ctx_destroy(ws_context *ctx);
+/* Run all work of this context on a caller-owned hipStream_t (e.g. torch's current stream). NULL restores the own stream. */
+int ws_ctx_set_stream(ws_context *ctx, void *hip_stream);
+/* cuda::pause()  — src/warpsense/cuda/cleanup.cu:3-6 */
+int ws_sync(ws_context *ctx);
+/* cuda::cleanup() — src/warpsense/cuda/cleanup.cu:8-11 (hipDeviceReset; invalidates every handle) */
+int ws_device_reset(void);
+
+/* ------------------------------------------------------------------ maps ---- */
+/* TSDFCuda::TSDFCuda(existing_map, tau, max_weight, map_resolution) — update_tsdf.cu:130-141.
+ * Like the reference, BOTH device maps start as copies of host_data (DeviceMapMemWrapper ctor,
+ * device_map_wrapper.cu:20-24). host_data may be NULL: both maps are then filled with (tau, 0). */
+int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], const int32_t offset[3],
+                  const uint32_t *host_data, int32_t tau, int32_t max_weight, int32_t map_resolution, ws_map **out);
+int ws_map_destroy(ws_map *map); /* TSDFCuda::~TSDFCuda + ~DeviceMapMemWrapper */
+/* DeviceMapMemWrapper::to_device — device_map_wrapper.cu:35-45 (params + all voxels, host -> HBM) */
+int ws_map_upload(ws_map *map, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3],
+                  const uint32_t *host_data);
+/* DeviceMapMemWrapper::update_params — device_map_wrapper.cu:47-56 (params only) */
+int ws_map_set_params(ws_map *map, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3]);
+/* DeviceMapMemWrapper::to_host — device_map_wrapper.cu:85-92 (synchronises) */
+int ws_map_download(ws_map *map, int which, int32_t size[3], int32_t pos[3], int32_t offset[3], uint32_t *host_data);
+/* device pointer of the voxel array (uint32 per voxel, z fastest) — what DeviceMap::data_ is on the device */
+void *ws_map_device_data(ws_map *map, int which);
+int64_t ws_map_n_voxels(const ws_map *map);
+
+/* ------------------------------------------------------------------ TSDF update ---- */
+/* TSDFCuda::update_tsdf(scan_points, scanner_pos, up) — update_tsdf.cu:143-166.
+ * xyz_host: n x 3 int32 (rmagine::Pointi AoS); scanner_pos in voxel units, up scaled by 32768.
+ * Returns after enqueueing, like the reference (no device sync). */
+int ws_tsdf_update(ws_map *map, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
+/* same with the scan already resident in HBM (no H2D copy) */
+int ws_tsdf_update_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
+/* only the scatter (cu_min_tsdf_krnl, update_tsdf.cu:45-128): fills new_map, no integrate. For parity tests. */
+int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
+/* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
+int ws_tsdf_integrate(ws_map *map);
+int ws_tsdf_set_integrate(ws_map *map, int mode);
+
+typedef struct
+{
+  int64_t contested_voxels;  /* voxels resolved by the exact ordered fallback in the last update */
+  int64_t contested_records; /* candidate records collected for them                              */
+  int64_t dirty_tiles;       /* 64-voxel tiles streamed by the last sparse integrate              */
+  int32_t error_flags;       /* bit0 arena overflow, bit1 order-key range                         */
+} ws_tsdf_stats_t;
+int ws_tsdf_stats(ws_map *map, ws_tsdf_stats_t *out); /* synchronises */
+
+/* ------------------------------------------------------------------ registration ---- */
+/* RegistrationCuda::RegistrationCuda — registration.cu:259-281 (buffers grow on demand beyond max_points) */
+int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out);
+int ws_reg_destroy(ws_reg *reg);
+/* RegistrationCuda::prepare_registration — registration.cu:303-308 */
+int ws_reg_prepare(ws_reg *reg, const int32_t *xyz_host, size_t n);
+int ws_reg_prepare_dev(ws_reg *reg, const int32_t *xyz_dev, size_t n); /* device-to-device copy */
+/* RegistrationCuda::perform_registration — registration.cu:347-368. T, h column-major. Synchronises. */
+int ws_reg_iterate(ws_reg *reg, const ws_map *map, const float T[16], int32_t map_resolution, uint32_t flags,
+                   int64_t h[36], int64_t g[6], int32_t *e, int32_t *c);
+/* cuda::TSDFRegistration::register_cloud — src/warpsense/tsdf_registration.cpp:28-96 with the whole
+ * Gauss-Newton loop on the device (points must have been given to ws_reg_prepare*). Synchronises. */
+int ws_register_cloud(ws_reg *reg, const ws_map *map, const float T_in[16], int32_t max_iterations,
+                      float it_weight_gradient, float epsilon, int32_t map_resolution, uint32_t flags,
+                      float T_out[16], int32_t *iterations);
+
+/* Building blocks of the same loop for point-sharded multi-GPU runs: every rank owns the
+ * points [first, first+count) of the prepared cloud, accumulates its 44 int64 partial sums
+ * (h[36] column-major, g[6], e, c) into sums_dev, the caller all-reduces sums_dev (RCCL), then every
+ * rank runs the identical solve. All stream-ordered, no host synchronisation. */
+int ws_reg_begin(ws_reg *reg, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon);
+int ws_reg_accumulate_dev(ws_reg *reg, const ws_map *map, int32_t map_resolution, uint32_t flags, size_t first,
+                          size_t count, int64_t *sums_dev /* 44 */);
+int ws_reg_solve_dev(ws_reg *reg, const int64_t *sums_dev /* 44 */);
+int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out[16]); /* synchronises */
+
+/* ------------------------------------------------------------------ measurement ---- */
+/* Kernel classes for hipEvent timing (bench.py's roofline leg). */
+#define WS_K_MARCH 0     /* ray-march scatter passes                       */
+#define WS_K_RESOLVE 1   /* key -> entry resolution passes                 */
+#define WS_K_INTEGRATE 2 /* dense or sparse weighted-average pass          */
+#define WS_K_REG 3       /* one Gauss-Newton iteration (Jacobian+reduce+solve) */
+#define WS_K_COUNT 4
+int ws_prof_enable(ws_context *ctx, uint32_t class_mask); /* 0 disables */
+/* sum of event-measured durations and number of launches per class since the last reset (synchronises) */
+int ws_prof_read(ws_context *ctx, int kernel_class, double *total_ms, int64_t *launches);
+int ws_prof_reset(ws_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WARPSENSE_HIP_H */

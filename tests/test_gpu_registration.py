@@ -1,0 +1,93 @@
+"""GPU parity of the Point-to-TSDF registration against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def build_scene(size=(128, 128, 64), tau=1000, res=50, mw=640, rings=64, az=512, he=(2600.0, 2300.0, 1000.0), scans=1):
+    import torch
+    import warpsense_amd as W
+    params = W.Params(W.MapParams(resolution=res, max_distance=tau / 1000.0, max_weight=mw // 64,
+                                  size=tuple(s * res / 1000.0 for s in size)))
+    lm = W.LocalMap(size[0], size[1], size[2], tau, 0)
+    reg = W.TSDFRegistration(params, lm)
+    oa = O.OracleMap(size, tau, 0)
+    on = oa.copy()
+    pts = None
+    for k in range(scans):
+        pts = S.os1_128_scan(rings=rings, azimuths=az, half_extents_mm=he, seed=21 + k)
+        O.update_tsdf(oa, on, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+        reg.update_tsdf(torch.from_numpy(pts).cuda(), pose=np.eye(4, dtype=np.float32))
+    return reg, oa, pts, res
+
+
+def pose_error(A, B):
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    dt = np.linalg.norm(A[:3, 3] - B[:3, 3]) / 1000.0  # mm -> m
+    R = A[:3, :3] @ B[:3, :3].T
+    # atan2 form: well conditioned near 0 (arccos of a float32-rounded trace is not)
+    k = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    ang = np.arctan2(np.linalg.norm(k), (np.trace(R) - 1) / 2)
+    return dt, ang
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_hgec_bit_exact(flags):
+    """h, g, e, c of one perform_registration call == oracle, for identity and a perturbed transform."""
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene()
+    reg.reg_.flags = flags
+    q = S.transform_points_mm(pts, S.perturbation(40, -30, 10, 2.0))
+    reg.reg_.prepare_registration(q)
+    for T in (np.eye(4, dtype=np.float32), S.perturbation(-35, 28, -9, -1.7), S.perturbation(500.5, 100.25, 3.75, 11.0)):
+        h, g, e, c = reg.reg_.perform_registration(reg.tsdf().device_map(), T, res)
+        ho, go, eo, co = O.reg_iterate(oa, T, q, res, flags)
+        assert c == co and e == eo and c > 1000
+        assert np.array_equal(g, go)
+        assert np.array_equal(h, ho)
+        assert np.array_equal(h, h.T)
+
+
+@pytest.mark.parametrize("n", [1, 31, 127, 128, 1000, 65536 + 77])
+def test_hgec_ragged_sizes(n):
+    """point counts around the reference's launch-shape edges (N<128, N%32 != 0, N>65536), both modes."""
+    reg, oa, pts, res = build_scene(rings=16, az=128)
+    rng = np.random.default_rng(n)
+    q = pts[rng.integers(0, pts.shape[0], n)]
+    reg.reg_.prepare_registration(q)
+    T = S.perturbation(12, -7, 3, 0.8)
+    for flags in (0, 1):
+        reg.reg_.flags = flags
+        h, g, e, c = reg.reg_.perform_registration(reg.tsdf().device_map(), T, res)
+        ho, go, eo, co = O.reg_iterate(oa, T, q, res, flags)
+        assert (e, c) == (eo, co)
+        assert np.array_equal(g, go) and np.array_equal(h, ho)
+
+
+def test_register_cloud_matches_oracle_pose():
+    """register_cloud: same iteration count, per-iteration sums and final pose (1e-4 m / 1e-4 rad)."""
+    reg, oa, pts, res = build_scene(scans=2)
+    Tp = S.perturbation(60, 40, 0, 3.0)
+    q = S.transform_points_mm(pts, Tp)
+    T_gpu = reg.register_cloud(q, np.eye(4, dtype=np.float32))
+    T_cpu, it_cpu, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+    dt, ang = pose_error(T_gpu, T_cpu)
+    assert reg.last_iterations == it_cpu, (reg.last_iterations, it_cpu)
+    assert dt < 1e-4 and ang < 1e-4, (dt, ang)
+    # and it actually registers: closer to the inverse perturbation than the start
+    inv = np.linalg.inv(Tp.astype(np.float64))
+    assert pose_error(T_gpu, inv)[0] < pose_error(np.eye(4), inv)[0]
+
+
+def test_register_cloud_empty_overlap():
+    """c == 0 (cloud far outside the map): the loop stops instead of producing NaN."""
+    reg, oa, pts, res = build_scene(rings=8, az=64)
+    q = pts + np.array([10_000_000, 0, 0], dtype=np.int32)
+    T = reg.register_cloud(q[:100], np.eye(4, dtype=np.float32))
+    assert np.all(np.isfinite(T))
+    assert np.allclose(T, np.eye(4))

@@ -1,0 +1,138 @@
+"""GPU parity of the TSDF update against the CPU oracle (bit-exact), through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def make_pair(size, tau, res, max_weight, default_weight=0):
+    import warpsense_amd as W
+    lm = W.LocalMap(size[0], size[1], size[2], tau, default_weight)
+    om_avg = O.OracleMap(size, tau, default_weight)
+    om_new = om_avg.copy()
+    t = W.TSDFCuda(lm.device_map(), tau, max_weight, res)
+    return lm, t, om_avg, om_new
+
+
+def download(t, lm, which):
+    import warpsense_amd as W
+    host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+    (t.avg_map() if which == 0 else t.new_map()).to_host(host)
+    return host.data_
+
+
+def test_kat_tsdf_write():
+    """test/map.cpp:9-90 / test/cuda.cpp:268-414: one point, res 1000, tau 3000, 21^3 map."""
+    tau, res, mw = 3000, 1000, 640
+    lm, t, oa, on = make_pair((20, 20, 20), tau, res, mw)
+    pts = np.array([[5500, 500, 500]], dtype=np.int32)
+    t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
+    avg = download(t, lm, 0)
+    lm.data[:] = avg
+    got = [lm.value(x, 0, 0) for x in range(1, 9)]
+    assert got == [(3000, 64), (3000, 64), (2000, 64), (1000, 64), (0, 64), (-1000, 47), (-2000, 23), (3000, 0)]
+    assert int((avg != O.pack(tau, 0)).sum()) == 7
+    new = download(t, lm, 1)
+    assert np.all(new == O.pack(tau, 0))
+
+
+@pytest.mark.parametrize("tau,res,size,rings,az", [(1000, 50, (128, 128, 64), 32, 256), (600, 64, (100, 100, 60), 16, 512),
+                                                   (1000, 20, (160, 160, 80), 24, 128)])
+def test_scatter_matches_oracle(tau, res, size, rings, az):
+    """new_map after the scatter == serial reference kernel (oracle wso_update_min), bit for bit."""
+    torch = _torch()
+    mw = 640
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    he = (size[0] * res * 0.4, size[1] * res * 0.35, size[2] * res * 0.3)
+    pts = S.os1_128_scan(rings=rings, azimuths=az, half_extents_mm=he, seed=7)
+    st = O.update_min(on, pts, (0, 0, 0), (0, 0, 32768), tau, res)
+    assert st.write_calls > 0
+    d = torch.from_numpy(pts).cuda()
+    t.scatter(d, (0, 0, 0), (0, 0, 32768))
+    new = download(t, lm, 1)
+    stats = t.stats()
+    assert stats["error_flags"] == 0
+    mism = np.nonzero(new != on.data)[0]
+    assert mism.size == 0, f"{mism.size} voxels differ, first {mism[:5]}, contested={stats}"
+
+
+def test_three_scans_avg_matches_oracle():
+    """avg_map after 3 successive updates (moving sensor) is bit-exact; new_map is back to (tau,0)."""
+    torch = _torch()
+    tau, res, mw = 1000, 50, 640
+    size = (128, 128, 64)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    he = (2500.0, 2200.0, 900.0)
+    for k, sensor in enumerate([(0, 0, 0), (120, -40, 10), (260, 30, -20)]):
+        pts = S.os1_128_scan(sensor_mm=sensor, rings=32, azimuths=256, half_extents_mm=he, seed=11 + k)
+        pos = [int(np.floor(np.float32(s) / np.float32(res))) for s in sensor]
+        O.update_tsdf(oa, on, pts, pos, (0, 0, 32768), tau, mw, res)
+        t.update_tsdf(torch.from_numpy(pts).cuda(), pos, (0, 0, 32768))
+        avg = download(t, lm, 0)
+        assert np.array_equal(avg, oa.data), f"scan {k}: {(avg != oa.data).sum()} voxels differ"
+    assert np.all(download(t, lm, 1) == O.pack(tau, 0))
+
+
+def test_dense_equals_sparse():
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw = 1000, 50, 640
+    size = (96, 96, 48)
+    he = (1800.0, 1500.0, 700.0)
+    outs = []
+    for mode in (W.WS_INTEGRATE_SPARSE, W.WS_INTEGRATE_DENSE):
+        lm, t, _, _ = make_pair(size, tau, res, mw)
+        t.set_integrate(mode)
+        for k in range(2):
+            pts = S.os1_128_scan(rings=16, azimuths=128, half_extents_mm=he, seed=3 + k)
+            t.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
+        outs.append(download(t, lm, 0))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_nondefault_new_map_first_update():
+    """TSDFCuda copies the host map into BOTH device maps (update_tsdf.cu:135-136): with a non-default
+    map the first update sees those entries in new_map.  Must match the oracle run the same way."""
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw = 1000, 50, 640
+    size = (64, 64, 32)
+    rng = np.random.default_rng(5)
+    lm = W.LocalMap(*size, tau, 0)
+    n = lm.data.size
+    vals = rng.integers(-tau, tau + 1, n).astype(np.int16)
+    wts = rng.choice(np.array([0, 0, 0, -64, 64, 23], dtype=np.int16), n)
+    lm.data[:] = O.pack(vals, wts)
+    oa = O.OracleMap(size, tau, 0, data=lm.data.copy())
+    on = oa.copy()
+    t = W.TSDFCuda(lm.device_map(), tau, mw, res)
+    pts = S.os1_128_scan(rings=16, azimuths=128, half_extents_mm=(1200.0, 1000.0, 500.0), seed=9)
+    O.update_tsdf(oa, on, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+    t.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
+    assert np.array_equal(download(t, lm, 0), oa.data)
+    assert np.all(download(t, lm, 1) == O.pack(tau, 0))
+
+
+def test_too_many_points_is_a_noop(capsys):
+    """update_tsdf.cu:146-150: stderr message and no work."""
+    tau, res, mw = 1000, 50, 640
+    lm, t, _, _ = make_pair((32, 32, 32), tau, res, mw)
+    pts = np.zeros((1_000_001, 3), dtype=np.int32)
+    t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
+    assert "larger than" in capsys.readouterr().err
+    assert np.all(download(t, lm, 0) == O.pack(tau, 0))
+
+
+def test_empty_scan():
+    tau, res, mw = 1000, 50, 640
+    lm, t, _, _ = make_pair((32, 32, 32), tau, res, mw)
+    t.update_tsdf(np.zeros((0, 3), dtype=np.int32), (0, 0, 0), (0, 0, 32768))
+    assert np.all(download(t, lm, 0) == O.pack(tau, 0))

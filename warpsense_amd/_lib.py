@@ -1,0 +1,93 @@
+"""ctypes binding of libwarpsense_hip.so — the C ABI declared in include/warpsense_hip.h.
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
+
+WS_MAP_AVG, WS_MAP_NEW = 0, 1
+WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE = 0, 1
+WS_REG_ALL_POINTS, WS_REG_COMPAT_REFERENCE_LAUNCH = 0, 1
+WS_K_MARCH, WS_K_RESOLVE, WS_K_INTEGRATE, WS_K_REG = 0, 1, 2, 3
+
+# every symbol include/warpsense_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ws_last_error", "ws_version", "ws_ctx_create", "ws_ctx_destroy", "ws_ctx_set_stream", "ws_sync",
+    "ws_device_reset", "ws_map_create", "ws_map_destroy", "ws_map_upload", "ws_map_set_params", "ws_map_download",
+    "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
+    "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
+    "ws_reg_prepare_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
+    "ws_reg_solve_dev", "ws_reg_poll", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
+]
+
+
+class WsError(RuntimeError):
+    pass
+
+
+class TsdfStats(C.Structure):
+    _fields_ = [("contested_voxels", C.c_int64), ("contested_records", C.c_int64), ("dirty_tiles", C.c_int64),
+                ("error_flags", C.c_int32)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built (python -m warpsense_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WsError(f"{LIB_PATH} is missing: build it with `python -m warpsense_amd.build` "
+                      "(there is no CPU fallback for the hot path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, sz, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t, C.c_int64
+    P = C.POINTER
+    L.ws_last_error.restype = C.c_char_p
+    L.ws_version.restype = C.c_int
+    L.ws_ctx_create.argtypes = [C.c_int, P(vp)]
+    L.ws_ctx_destroy.argtypes = [vp]
+    L.ws_ctx_set_stream.argtypes = [vp, vp]
+    L.ws_sync.argtypes = [vp]
+    L.ws_map_create.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, P(vp)]
+    L.ws_map_destroy.argtypes = [vp]
+    L.ws_map_upload.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.ws_map_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ws_map_download.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.ws_map_device_data.argtypes = [vp, C.c_int]
+    L.ws_map_device_data.restype = vp
+    L.ws_map_n_voxels.argtypes = [vp]
+    L.ws_map_n_voxels.restype = i64
+    L.ws_tsdf_update.argtypes = [vp, vp, sz, vp, vp]
+    L.ws_tsdf_update_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.ws_tsdf_scatter_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.ws_tsdf_integrate.argtypes = [vp]
+    L.ws_tsdf_set_integrate.argtypes = [vp, C.c_int]
+    L.ws_tsdf_stats.argtypes = [vp, P(TsdfStats)]
+    L.ws_reg_create.argtypes = [vp, sz, P(vp)]
+    L.ws_reg_destroy.argtypes = [vp]
+    L.ws_reg_prepare.argtypes = [vp, vp, sz]
+    L.ws_reg_prepare_dev.argtypes = [vp, vp, sz]
+    L.ws_reg_iterate.argtypes = [vp, vp, vp, i32, u32, vp, vp, P(i32), P(i32)]
+    L.ws_register_cloud.argtypes = [vp, vp, vp, i32, C.c_float, C.c_float, i32, u32, vp, P(i32)]
+    L.ws_reg_begin.argtypes = [vp, vp, i32, C.c_float, C.c_float]
+    L.ws_reg_accumulate_dev.argtypes = [vp, vp, i32, u32, sz, sz, vp]
+    L.ws_reg_solve_dev.argtypes = [vp, vp]
+    L.ws_reg_poll.argtypes = [vp, P(i32), P(i32), vp]
+    L.ws_prof_enable.argtypes = [vp, u32]
+    L.ws_prof_read.argtypes = [vp, C.c_int, P(C.c_double), P(i64)]
+    L.ws_prof_reset.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().ws_last_error()
+        raise WsError(f"{what} failed with status {rc}: {msg.decode(errors='replace') if msg else ''}")

@@ -1,0 +1,413 @@
+"""Host-side mirror of the reference's device API over the C ABI (include/warpsense_hip.h).
+
+Same names, argument meaning and error behaviour as the reference classes, so tests read like the
+reference's own (test/cuda.cpp, test/pcd_registration.cpp):
+
+    DeviceMap            include/warpsense/cuda/device_map.h:32-164     (non-owning host view)
+    DeviceMapMemWrapper  include/warpsense/cuda/device_map_wrapper.h:10-36
+    TSDFCuda             include/warpsense/cuda/update_tsdf.h:9-34
+    RegistrationCuda     include/warpsense/cuda/registration.h:10-45
+    TSDFMapping          src/warpsense/tsdf_mapping.cpp:30-95            (ROS-free constructor path)
+    TSDFRegistration     src/warpsense/tsdf_registration.cpp:22-96
+    pause / cleanup      src/warpsense/cuda/cleanup.cu
+
+Matrices handed to these classes are ordinary numpy 4x4 arrays (math layout, M[i, j]); the column-major
+flattening the C ABI wants (rmagine::Matrix4x4f / Eigen) happens here.  All compute runs in the HIP
+library; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import (WS_INTEGRATE_DENSE, WS_INTEGRATE_SPARSE, WS_MAP_AVG, WS_MAP_NEW, WS_REG_ALL_POINTS,
+                   WS_REG_COMPAT_REFERENCE_LAUNCH, WsError, check)
+
+MATRIX_RESOLUTION = 32768  # include/warpsense/consts.h:12-13
+WEIGHT_RESOLUTION = 64     # include/warpsense/consts.h:9-10
+
+
+def _ptr(a):
+    """void* of a numpy array or of a torch tensor (host or device)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _is_device(a) -> bool:
+    return hasattr(a, "is_cuda") and bool(a.is_cuda)
+
+
+def _i3(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.int32).reshape(3))
+
+
+def _colmajor(T) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T).reshape(16)
+
+
+def pack_entry(value, weight):
+    """TSDFEntry raw word: low 16 bits value, high 16 bits weight (include/map/tsdf.h:16-23)."""
+    v = np.asarray(value).astype(np.int16).astype(np.uint16).astype(np.uint32)
+    w = np.asarray(weight).astype(np.int16).astype(np.uint16).astype(np.uint32)
+    return v | (w << np.uint32(16))
+
+
+def unpack_entry(raw):
+    raw = np.asarray(raw, dtype=np.uint32)
+    return (raw & 0xFFFF).astype(np.uint16).astype(np.int16), (raw >> 16).astype(np.uint16).astype(np.int16)
+
+
+class Context:
+    """One per process and GPU: device + HIP stream (the reference uses the implicit CUDA context)."""
+
+    _default = None
+    _lock = threading.Lock()
+
+    def __init__(self, device_id: int = -1):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.ws_ctx_create(int(device_id), C.byref(h)), "ws_ctx_create")
+        self.handle = h
+
+    @classmethod
+    def default(cls) -> "Context":
+        with cls._lock:
+            if cls._default is None:
+                cls._default = cls()
+            return cls._default
+
+    def set_stream(self, hip_stream_ptr):
+        check(self._L.ws_ctx_set_stream(self.handle, C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None),
+              "ws_ctx_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def sync(self):
+        check(self._L.ws_sync(self.handle), "ws_sync")
+
+    # hipEvent timing of kernel classes (bench.py)
+    def prof_enable(self, mask: int):
+        check(self._L.ws_prof_enable(self.handle, int(mask)), "ws_prof_enable")
+
+    def prof_reset(self):
+        check(self._L.ws_prof_reset(self.handle), "ws_prof_reset")
+
+    def prof_read(self, cls: int):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._L.ws_prof_read(self.handle, int(cls), C.byref(ms), C.byref(n)), "ws_prof_read")
+        return ms.value, n.value
+
+    def close(self):
+        if self.handle:
+            self._L.ws_ctx_destroy(self.handle)
+            self.handle = None
+
+
+def pause(ctx: Context | None = None):
+    """cuda::pause() — cleanup.cu:3-6."""
+    (ctx or Context.default()).sync()
+
+
+def cleanup():
+    """cuda::cleanup() — cleanup.cu:8-11.  Resets the device: every handle becomes invalid."""
+    check(_lib.load().ws_device_reset(), "ws_device_reset")
+    Context._default = None
+
+
+class DeviceMap:
+    """Non-owning view of a ring-buffer local map in HOST memory: size, offset, data, pos
+    (include/warpsense/cuda/device_map.h:32-48).  The arrays are shared with whoever owns the map."""
+
+    def __init__(self, size, offset, data, pos):
+        self.size_ = np.asarray(size, dtype=np.int32).reshape(3)
+        self.offset_ = np.asarray(offset, dtype=np.int32).reshape(3)
+        self.pos_ = np.asarray(pos, dtype=np.int32).reshape(3)
+        self.data_ = data
+        if data is not None:
+            assert data.dtype == np.uint32 and data.flags["C_CONTIGUOUS"]
+            assert data.size == int(np.prod(self.size_.astype(np.int64)))
+
+    def n_voxels(self) -> int:
+        return int(np.prod(self.size_.astype(np.int64)))
+
+
+class LocalMap:
+    """In-memory part of HDF5LocalMap (src/map/hdf5_local_map.cpp:5-20): sizes forced odd, offset = size/2,
+    every voxel the default entry.  Owns the host arrays a DeviceMap views."""
+
+    def __init__(self, sx, sy, sz, default_value, default_weight=0):
+        self.size = np.array([s if s % 2 == 1 else s + 1 for s in (int(sx), int(sy), int(sz))], dtype=np.int32)
+        self.pos = np.zeros(3, dtype=np.int32)
+        self.offset = (self.size // 2).astype(np.int32)
+        self.data = np.full(int(np.prod(self.size.astype(np.int64))), pack_entry(default_value, default_weight),
+                            dtype=np.uint32)
+
+    def device_map(self) -> DeviceMap:
+        return DeviceMap(self.size, self.offset, self.data, self.pos)
+
+    def get_index(self, x, y, z) -> int:
+        s, p, o = self.size.astype(np.int64), self.pos.astype(np.int64), self.offset.astype(np.int64)
+        xi = (x - p[0] + o[0] + s[0]) % s[0]
+        yi = (y - p[1] + o[1] + s[1]) % s[1]
+        zi = (z - p[2] + o[2] + s[2]) % s[2]
+        return int((xi * s[1] + yi) * s[2] + zi)
+
+    def in_bounds(self, x, y, z) -> bool:
+        d = np.abs(np.array([x, y, z], dtype=np.int64) - self.pos)
+        return bool(np.all(d <= self.size // 2))
+
+    def value(self, x, y, z):
+        if not self.in_bounds(x, y, z):
+            raise IndexError(f"Index out of bounds: {x}; {y}; {z}")  # std::out_of_range, hdf5_local_map.h:172-181
+        v, w = unpack_entry(self.data[self.get_index(x, y, z)])
+        return int(v), int(w)
+
+
+class DeviceMapMemWrapper:
+    """Device copy of one map (device_map_wrapper.h:10-36); owned by a TSDFCuda."""
+
+    def __init__(self, tsdf: "TSDFCuda", which: int):
+        self._t = tsdf
+        self._which = which
+
+    def to_device(self, existing_map: DeviceMap):
+        t = self._t
+        check(t._L.ws_map_upload(t.handle, self._which, _ptr(_i3(existing_map.size_)), _ptr(_i3(existing_map.pos_)),
+                                 _ptr(_i3(existing_map.offset_)), _ptr(existing_map.data_)), "ws_map_upload")
+
+    def update_params(self, existing_map: DeviceMap):
+        t = self._t
+        check(t._L.ws_map_set_params(t.handle, self._which, _ptr(_i3(existing_map.size_)),
+                                     _ptr(_i3(existing_map.pos_)), _ptr(_i3(existing_map.offset_))), "ws_map_set_params")
+
+    def to_host(self, existing_map: DeviceMap):
+        t = self._t
+        size, pos, off = np.zeros(3, np.int32), np.zeros(3, np.int32), np.zeros(3, np.int32)
+        check(t._L.ws_map_download(t.handle, self._which, _ptr(size), _ptr(pos), _ptr(off), _ptr(existing_map.data_)),
+              "ws_map_download")
+        existing_map.size_[:] = size
+        existing_map.pos_[:] = pos
+        existing_map.offset_[:] = off
+
+    def dev(self):
+        return self._t.handle
+
+    def device_ptr(self) -> int:
+        return int(self._t._L.ws_map_device_data(self._t.handle, self._which) or 0)
+
+
+class TSDFCuda:
+    """cuda::TSDFCuda (update_tsdf.h:9-34, update_tsdf.cu:130-221)."""
+
+    n_max_points_ = 1_000_000
+
+    def __init__(self, existing_map: DeviceMap, tau: int, max_weight: int, map_resolution: int, ctx: Context | None = None):
+        self.ctx = ctx or Context.default()
+        self._L = self.ctx._L
+        self.tau_, self.max_weight_, self.map_resolution_ = int(tau), int(max_weight), int(map_resolution)
+        self.n_voxels_ = existing_map.n_voxels()
+        h = C.c_void_p()
+        check(self._L.ws_map_create(self.ctx.handle, _ptr(_i3(existing_map.size_)), _ptr(_i3(existing_map.pos_)),
+                                    _ptr(_i3(existing_map.offset_)), _ptr(existing_map.data_), self.tau_, self.max_weight_,
+                                    self.map_resolution_, C.byref(h)), "ws_map_create")
+        self.handle = h
+        self._avg = DeviceMapMemWrapper(self, WS_MAP_AVG)
+        self._new = DeviceMapMemWrapper(self, WS_MAP_NEW)
+
+    # -- the three update_tsdf overloads of the reference (update_tsdf.cu:143-191)
+    def update_tsdf(self, scan_points, scanner_pos, up, result: DeviceMap | None = None, latest_map: DeviceMap | None = None):
+        n = int(scan_points.shape[0])
+        sp, u = _i3(scanner_pos), _i3(up)
+        if _is_device(scan_points):
+            rc = self._L.ws_tsdf_update_dev(self.handle, _ptr(scan_points), n, _ptr(sp), _ptr(u))
+        else:
+            pts = np.ascontiguousarray(scan_points, dtype=np.int32)
+            rc = self._L.ws_tsdf_update(self.handle, _ptr(pts), n, _ptr(sp), _ptr(u))
+        if rc == -3:
+            # update_tsdf.cu:146-150: message on stderr, no work, no exception
+            import sys
+            print("HIP Error: " + self._L.ws_last_error().decode(), file=sys.stderr)
+            return
+        check(rc, "ws_tsdf_update")
+        if result is not None:
+            self._avg.to_host(result)
+        if latest_map is not None:
+            self._new.to_host(latest_map)
+
+    def scatter(self, scan_points_dev, scanner_pos, up):
+        """cu_min_tsdf_krnl alone (parity tests): leaves the resolved scan in new_map."""
+        check(self._L.ws_tsdf_scatter_dev(self.handle, _ptr(scan_points_dev), int(scan_points_dev.shape[0]),
+                                          _ptr(_i3(scanner_pos)), _ptr(_i3(up))), "ws_tsdf_scatter_dev")
+
+    def integrate(self):
+        check(self._L.ws_tsdf_integrate(self.handle), "ws_tsdf_integrate")
+
+    def set_integrate(self, mode: int):
+        check(self._L.ws_tsdf_set_integrate(self.handle, int(mode)), "ws_tsdf_set_integrate")
+
+    def stats(self) -> dict:
+        st = _lib.TsdfStats()
+        check(self._L.ws_tsdf_stats(self.handle, C.byref(st)), "ws_tsdf_stats")
+        return {"contested_voxels": st.contested_voxels, "contested_records": st.contested_records,
+                "dirty_tiles": st.dirty_tiles, "error_flags": st.error_flags}
+
+    def device_map(self):
+        return self.handle
+
+    def avg_map(self) -> DeviceMapMemWrapper:
+        return self._avg
+
+    def new_map(self) -> DeviceMapMemWrapper:
+        return self._new
+
+    def close(self):
+        if self.handle:
+            self._L.ws_map_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RegistrationCuda:
+    """cuda::RegistrationCuda (registration.h:10-45, registration.cu:259-368)."""
+
+    def __init__(self, map_: DeviceMap | None = None, ctx: Context | None = None, flags: int = WS_REG_ALL_POINTS):
+        self.ctx = ctx or Context.default()
+        self._L = self.ctx._L
+        self.flags = int(flags)
+        h = C.c_void_p()
+        check(self._L.ws_reg_create(self.ctx.handle, 128 * 1024, C.byref(h)), "ws_reg_create")
+        self.handle = h
+        self.curr_n_points = 0
+
+    def prepare_registration(self, points):
+        n = int(points.shape[0])
+        self.curr_n_points = n
+        if _is_device(points):
+            check(self._L.ws_reg_prepare_dev(self.handle, _ptr(points), n), "ws_reg_prepare_dev")
+        else:
+            pts = np.ascontiguousarray(points, dtype=np.int32)
+            check(self._L.ws_reg_prepare(self.handle, _ptr(pts), n), "ws_reg_prepare")
+
+    def perform_registration(self, map_dev, pretransform, map_resolution: int):
+        """Returns (h 6x6 int64 math layout, g[6] int64, e, c) — the out-parameters of the reference."""
+        T = _colmajor(pretransform)
+        h = np.zeros(36, dtype=np.int64)
+        g = np.zeros(6, dtype=np.int64)
+        e, c = C.c_int32(0), C.c_int32(0)
+        check(self._L.ws_reg_iterate(self.handle, map_dev, _ptr(T), int(map_resolution), self.flags, _ptr(h), _ptr(g),
+                                     C.byref(e), C.byref(c)), "ws_reg_iterate")
+        return h.reshape(6, 6).T.copy(), g, e.value, c.value
+
+    def register_cloud(self, map_dev, pretransform, max_iterations, it_weight_gradient, epsilon, map_resolution):
+        T = _colmajor(pretransform)
+        out = np.zeros(16, dtype=np.float32)
+        it = C.c_int32(0)
+        check(self._L.ws_register_cloud(self.handle, map_dev, _ptr(T), int(max_iterations), C.c_float(it_weight_gradient),
+                                        C.c_float(epsilon), int(map_resolution), self.flags, _ptr(out), C.byref(it)),
+              "ws_register_cloud")
+        return out.reshape(4, 4).T.copy(), it.value
+
+    def close(self):
+        if self.handle:
+            self._L.ws_reg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def to_int_mat(mat):
+    """(mat * MATRIX_RESOLUTION).cast<int>() — include/util/util.h:8-11."""
+    return (np.asarray(mat, dtype=np.float32) * np.float32(MATRIX_RESOLUTION)).astype(np.int32)
+
+
+def to_map(pose, map_resolution: int):
+    """floor(translation / resolution) in float — include/util/util.h:52-56."""
+    t = np.asarray(pose, dtype=np.float32)[:3, 3]
+    return np.floor(t / np.float32(map_resolution)).astype(np.int32)
+
+
+class MapParams:
+    """The hot-path knobs of params/params.yaml with the scaling rules of include/params/map_params.h:100-114."""
+
+    def __init__(self, resolution=64, max_distance=1.0, max_weight=10, size=(40.0, 40.0, 25.0), shift=10.0, initial_weight=0):
+        self.resolution = int(resolution)
+        self.tau = int(max_distance * 1000)
+        self.max_weight = int(max_weight * WEIGHT_RESOLUTION)
+        self.size = tuple(int(s * 1000 / self.resolution) for s in size)
+        self.shift = float(shift)
+        self.initial_weight = int(initial_weight)
+
+
+class RegistrationParams:
+    def __init__(self, max_iterations=200, it_weight_gradient=0.1, epsilon=0.03):
+        self.max_iterations = int(max_iterations)
+        self.it_weight_gradient = float(it_weight_gradient)
+        self.epsilon = float(epsilon)
+
+
+class Params:
+    def __init__(self, map_params: MapParams | None = None, registration: RegistrationParams | None = None):
+        self.map = map_params or MapParams()
+        self.registration = registration or RegistrationParams()
+
+
+class TSDFMapping:
+    """cuda::TSDFMapping without ROS (the protected constructor path, tsdf_mapping.cpp:30-41)."""
+
+    def __init__(self, params: Params, local_map: LocalMap, ctx: Context | None = None):
+        self.params_ = params
+        self.local_map_ = local_map
+        self.cuda_map_ = local_map.device_map()
+        self.tsdf_ = TSDFCuda(self.cuda_map_, params.map.tau, params.map.max_weight, params.map.resolution, ctx)
+        self.mutex_ = threading.RLock()  # the reference's shared_mutex: one writer or many readers
+
+    def convert_pose_to_gpu(self, pose):
+        """tsdf_mapping.cpp:77-85: pos = floor(t/res) voxels, up = (R_int * (0,0,MR)) / MR."""
+        # (R_int * (0, 0, MR) + 0) / MR == third column of R_int exactly (|R_int| <= 32768, no int overflow)
+        up = to_int_mat(pose)[:3, 2].astype(np.int32)
+        return to_map(pose, self.params_.map.resolution), up
+
+    def update_tsdf(self, scan_points, pose=None, pos_rm=None, up_rm=None, result: DeviceMap | None = None):
+        if pose is not None:
+            pos_rm, up_rm = self.convert_pose_to_gpu(pose)
+        with self.mutex_:
+            self.tsdf_.update_tsdf(scan_points, pos_rm, up_rm, result=result)
+
+    def tsdf(self) -> TSDFCuda:
+        return self.tsdf_
+
+
+class TSDFRegistration(TSDFMapping):
+    """cuda::TSDFRegistration (tsdf_registration.cpp:22-96)."""
+
+    def __init__(self, params: Params, local_map: LocalMap, ctx: Context | None = None, flags: int = WS_REG_ALL_POINTS):
+        super().__init__(params, local_map, ctx)
+        self.reg_ = RegistrationCuda(self.cuda_map_, ctx, flags)
+        self.last_iterations = 0
+
+    def register_cloud(self, cloud, pretransform):
+        """Returns total_transform (4x4 float32); Gauss-Newton loop on the device."""
+        self.reg_.prepare_registration(cloud)
+        r, m = self.params_.registration, self.params_.map
+        with self.mutex_:
+            T, it = self.reg_.register_cloud(self.tsdf_.device_map(), pretransform, r.max_iterations, r.it_weight_gradient,
+                                             r.epsilon, m.resolution)
+        self.last_iterations = it
+        return T

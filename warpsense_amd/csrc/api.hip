@@ -1,0 +1,584 @@
+// api.hip — the extern "C" surface of libwarpsense_hip.so (include/warpsense_hip.h): handle
+// management, host<->HBM transfers, stream ordering and hipEvent profiling.  No kernels here.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ws_internal.h"
+
+namespace ws
+{
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  set_error(buf);
+  return WS_ERR_HIP;
+}
+
+static int invalid(const char *msg)
+{
+  set_error(msg);
+  return WS_ERR_INVALID;
+}
+
+static hipEvent_t take_event(ws_context *ctx)
+{
+  if (!ctx->pool.empty())
+  {
+    hipEvent_t e = ctx->pool.back();
+    ctx->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(ws_context *ctx, int cls)
+{
+  if (!(ctx->prof_mask & (1u << cls))) return;
+  ws_context::Span sp;
+  sp.a = take_event(ctx);
+  sp.b = take_event(ctx);
+  sp.cls = cls;
+  (void)hipEventRecord(sp.a, ctx->stream);
+  ctx->spans.push_back(sp);
+}
+
+void prof_end(ws_context *ctx, int cls)
+{
+  if (!(ctx->prof_mask & (1u << cls))) return;
+  for (size_t i = ctx->spans.size(); i-- > 0;)
+  {
+    if (ctx->spans[i].cls == cls)
+    {
+      (void)hipEventRecord(ctx->spans[i].b, ctx->stream);
+      return;
+    }
+  }
+}
+
+static void prof_resolve(ws_context *ctx)
+{
+  for (auto &sp : ctx->spans)
+  {
+    float ms = 0.f;
+    if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess)
+    {
+      ctx->prof_ms[sp.cls] += ms;
+      ctx->prof_n[sp.cls] += 1;
+    }
+    ctx->pool.push_back(sp.a);
+    ctx->pool.push_back(sp.b);
+  }
+  ctx->spans.clear();
+}
+
+int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value)
+{
+  for (int64_t i = 0; i < n; ++i)
+    if (data[i] != value) return 0;
+  return 1;
+}
+
+static void copy3(int32_t dst[3], const int32_t src[3])
+{
+  dst[0] = src[0];
+  dst[1] = src[1];
+  dst[2] = src[2];
+}
+
+size_t reg_partials_bytes();
+} // namespace ws
+
+using namespace ws;
+
+extern "C" {
+
+const char *ws_last_error(void) { return g_last_error.c_str(); }
+int ws_version(void) { return 1; }
+
+int ws_ctx_create(int device_id, ws_context **out)
+{
+  if (!out) return invalid("ws_ctx_create: out is NULL");
+  // the constant the kernels use for dz_per_distance must be what the reference computes (update_tsdf.cu:49-50)
+  {
+    float angle = 45.f / 128.f;
+    int dz = (int)(std::tan(angle / 180 * M_PI) / 2.0 * MATRIX_RESOLUTION);
+    if (dz != DZ_PER_DISTANCE) return invalid("ws_ctx_create: dz_per_distance constant mismatch");
+  }
+  if (device_id >= 0) WS_HIP(hipSetDevice(device_id));
+  int dev = 0;
+  WS_HIP(hipGetDevice(&dev));
+  ws_context *ctx = new (std::nothrow) ws_context();
+  if (!ctx) return invalid("ws_ctx_create: out of host memory");
+  ctx->device = dev;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess)
+  {
+    delete ctx;
+    return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__);
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return WS_OK;
+}
+
+int ws_ctx_destroy(ws_context *ctx)
+{
+  if (!ctx) return WS_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_resolve(ctx);
+  for (auto e : ctx->pool) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return WS_OK;
+}
+
+int ws_ctx_set_stream(ws_context *ctx, void *hip_stream)
+{
+  if (!ctx) return invalid("ws_ctx_set_stream: ctx is NULL");
+  WS_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return WS_OK;
+}
+
+int ws_sync(ws_context *ctx)
+{
+  if (!ctx) return invalid("ws_sync: ctx is NULL");
+  WS_HIP(hipStreamSynchronize(ctx->stream));
+  return WS_OK;
+}
+
+int ws_device_reset(void)
+{
+  WS_HIP(hipDeviceReset());
+  return WS_OK;
+}
+
+// ------------------------------------------------------------------ maps
+static int map_free(ws_map *m)
+{
+  if (!m) return WS_OK;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->scan_dev,
+                  m->counters, m->contested_vox_lo, m->contested_vox_hi, m->heads, m->arena};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (m->counters_host) (void)hipHostFree(m->counters_host);
+  delete m;
+  return WS_OK;
+}
+
+int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], const int32_t offset[3],
+                  const uint32_t *host_data, int32_t tau, int32_t max_weight, int32_t res, ws_map **out)
+{
+  if (!ctx || !size || !pos || !offset || !out) return invalid("ws_map_create: NULL argument");
+  if (size[0] < 3 || size[1] < 3 || size[2] < 3) return invalid("ws_map_create: map sizes must be >= 3");
+  if (res < 2) return invalid("ws_map_create: map_resolution must be >= 2 mm (the ray step is resolution/2)");
+  if (tau <= 0 || tau > 32767) return invalid("ws_map_create: tau must fit the int16 TSDF value");
+  ws_map *m = new (std::nothrow) ws_map();
+  if (!m) return invalid("ws_map_create: out of host memory");
+  m->ctx = ctx;
+  for (int w = 0; w < 2; ++w)
+  {
+    copy3(m->par[w].size, size);
+    copy3(m->par[w].pos, pos);
+    copy3(m->par[w].offset, offset);
+  }
+  m->n_vox = (int64_t)size[0] * size[1] * size[2];
+  m->n_tiles = (m->n_vox + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
+  m->tau = tau;
+  m->max_weight = max_weight;
+  m->res = res;
+  // contested-voxel capacity: generous fixed pools (usage is reported by ws_tsdf_stats)
+  m->contested_cap = 1u << 22; // 4 Mi voxels
+  m->arena_cap = 1u << 24;     // 16 Mi records (256 MiB)
+
+  hipStream_t s = ctx->stream;
+  int rc = WS_OK;
+#define TRY(call)                                                   \
+  do                                                                \
+  {                                                                 \
+    hipError_t e__ = (call);                                        \
+    if (e__ != hipSuccess)                                          \
+    {                                                               \
+      rc = hip_fail(e__, #call, __FILE__, __LINE__);                \
+      map_free(m);                                                  \
+      return rc;                                                    \
+    }                                                               \
+  } while (0)
+  const size_t map_bytes = (size_t)m->n_vox * sizeof(uint32_t);
+  TRY(hipMalloc((void **)&m->data[0], map_bytes));
+  TRY(hipMalloc((void **)&m->data[1], map_bytes));
+  TRY(hipMalloc((void **)&m->kpos, (size_t)m->n_vox * sizeof(uint64_t)));
+  TRY(hipMalloc((void **)&m->kneg, (size_t)m->n_vox * sizeof(uint64_t)));
+  TRY(hipMalloc((void **)&m->dirty, (size_t)m->n_tiles));
+  TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
+  TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
+  TRY(hipMalloc((void **)&m->contested_vox_lo, (size_t)m->contested_cap * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->contested_vox_hi, (size_t)m->contested_cap * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->heads, (size_t)m->contested_cap * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));
+  TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
+  TRY(hipMemsetAsync(m->kpos, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
+  TRY(hipMemsetAsync(m->kneg, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
+  TRY(hipMemsetAsync(m->dirty, 0, (size_t)m->n_tiles, s));
+  TRY(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
+  const uint32_t def = ((uint32_t)tau & 0xffffu);
+  if (host_data)
+  {
+    // DeviceMapMemWrapper(existing_map) x2: avg_map_ and new_map_ both start as the host map (update_tsdf.cu:135-136)
+    TRY(hipMemcpyAsync(m->data[0], host_data, map_bytes, hipMemcpyHostToDevice, s));
+    TRY(hipMemcpyAsync(m->data[1], m->data[0], map_bytes, hipMemcpyDeviceToDevice, s));
+    TRY(hipStreamSynchronize(s));
+    m->new_is_default = check_all_equal_host(host_data, m->n_vox, def) != 0;
+  }
+  else
+  {
+    rc = fill_u32(ctx, m->data[0], def, m->n_vox);
+    if (rc == WS_OK) rc = fill_u32(ctx, m->data[1], def, m->n_vox);
+    if (rc != WS_OK)
+    {
+      map_free(m);
+      return rc;
+    }
+    m->new_is_default = true;
+  }
+#undef TRY
+  *out = m;
+  return WS_OK;
+}
+
+int ws_map_destroy(ws_map *map) { return map_free(map); }
+
+int ws_map_set_params(ws_map *m, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3])
+{
+  if (!m || !size || !pos || !offset || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("ws_map_set_params: bad argument");
+  if ((int64_t)size[0] * size[1] * size[2] != m->n_vox) return invalid("ws_map_set_params: voxel count differs from the allocation");
+  // parameters are kernel arguments: order against work already enqueued is automatic
+  copy3(m->par[which].size, size);
+  copy3(m->par[which].pos, pos);
+  copy3(m->par[which].offset, offset);
+  return WS_OK;
+}
+
+int ws_map_upload(ws_map *m, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3],
+                  const uint32_t *host_data)
+{
+  if (!host_data) return invalid("ws_map_upload: host_data is NULL");
+  int rc = ws_map_set_params(m, which, size, pos, offset);
+  if (rc != WS_OK) return rc;
+  WS_HIP(hipMemcpyAsync(m->data[which], host_data, (size_t)m->n_vox * sizeof(uint32_t), hipMemcpyHostToDevice, m->ctx->stream));
+  WS_HIP(hipStreamSynchronize(m->ctx->stream)); // cudaMemcpy of the reference is synchronous; the host buffer may be reused
+  if (which == WS_MAP_NEW) m->new_is_default = check_all_equal_host(host_data, m->n_vox, ((uint32_t)m->tau & 0xffffu)) != 0;
+  return WS_OK;
+}
+
+int ws_map_download(ws_map *m, int which, int32_t size[3], int32_t pos[3], int32_t offset[3], uint32_t *host_data)
+{
+  if (!m || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("ws_map_download: bad argument");
+  if (size) copy3(size, m->par[which].size);
+  if (pos) copy3(pos, m->par[which].pos);
+  if (offset) copy3(offset, m->par[which].offset);
+  if (host_data)
+  {
+    WS_HIP(hipMemcpyAsync(host_data, m->data[which], (size_t)m->n_vox * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
+  }
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return WS_OK;
+}
+
+void *ws_map_device_data(ws_map *m, int which)
+{
+  if (!m || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return nullptr;
+  return m->data[which];
+}
+
+int64_t ws_map_n_voxels(const ws_map *m) { return m ? m->n_vox : 0; }
+
+// ------------------------------------------------------------------ TSDF update
+int ws_tsdf_set_integrate(ws_map *m, int mode)
+{
+  if (!m || (mode != WS_INTEGRATE_SPARSE && mode != WS_INTEGRATE_DENSE)) return invalid("ws_tsdf_set_integrate: bad argument");
+  m->integrate_mode = mode;
+  return WS_OK;
+}
+
+int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
+{
+  if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
+  if (n > MAX_SCAN_POINTS)
+  {
+    // update_tsdf.cu:146-150: message, no work
+    char buf[160];
+    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
+    set_error(buf);
+    return WS_ERR_TOO_MANY_POINTS;
+  }
+  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up);
+  if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
+  return rc;
+}
+
+int ws_tsdf_integrate(ws_map *m)
+{
+  if (!m) return invalid("ws_tsdf_integrate: map is NULL");
+  return launch_tsdf_integrate(m);
+}
+
+int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
+{
+  if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_update_dev: NULL argument");
+  if (n > MAX_SCAN_POINTS)
+  {
+    char buf[160];
+    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
+    set_error(buf);
+    return WS_ERR_TOO_MANY_POINTS;
+  }
+  // scatter with the map's current state flag, integrate with the same flag (dense if new_map was not default)
+  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up);
+  if (rc != WS_OK) return rc;
+  return launch_tsdf_integrate(m);
+}
+
+int ws_tsdf_update(ws_map *m, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
+{
+  if (!m || (!xyz_host && n) || !scanner_pos || !up) return invalid("ws_tsdf_update: NULL argument");
+  if (n > MAX_SCAN_POINTS)
+  {
+    char buf[160];
+    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
+    set_error(buf);
+    return WS_ERR_TOO_MANY_POINTS;
+  }
+  if (n)
+  {
+    // pageable source: hipMemcpyAsync stages the data before it returns, like the reference's cudaMemcpy (update_tsdf.cu:152)
+    WS_HIP(hipMemcpyAsync(m->scan_dev, xyz_host, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, m->ctx->stream));
+  }
+  return ws_tsdf_update_dev(m, m->scan_dev, n, scanner_pos, up);
+}
+
+int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
+{
+  if (!m || !out) return invalid("ws_tsdf_stats: NULL argument");
+  WS_HIP(hipMemcpyAsync(m->counters_host, m->counters, sizeof(TsdfCounters), hipMemcpyDeviceToHost, m->ctx->stream));
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  out->contested_voxels = m->counters_host->contested;
+  out->contested_records = m->counters_host->records;
+  out->dirty_tiles = m->counters_host->dirty_tiles;
+  out->error_flags = (int32_t)m->counters_host->error;
+  if (out->error_flags & 1)
+  {
+    set_error("contested-voxel arena exhausted: the last TSDF update is not exact");
+    return WS_ERR_CAPACITY;
+  }
+  if (out->error_flags & 2)
+  {
+    set_error("a ray needs more than 65536 steps or 256 fan steps: outside the supported range");
+    return WS_ERR_RANGE;
+  }
+  return WS_OK;
+}
+
+// ------------------------------------------------------------------ registration
+int ws_reg_destroy(ws_reg *r)
+{
+  if (!r) return WS_OK;
+  (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->points) (void)hipFree(r->points);
+  if (r->partials) (void)hipFree(r->partials);
+  if (r->state) (void)hipFree(r->state);
+  if (r->T_dev) (void)hipFree(r->T_dev);
+  if (r->sums_dev) (void)hipFree(r->sums_dev);
+  if (r->state_host) (void)hipHostFree(r->state_host);
+  delete r;
+  return WS_OK;
+}
+
+static int reg_reserve(ws_reg *r, size_t n)
+{
+  if (n <= r->cap) return WS_OK;
+  WS_HIP(hipStreamSynchronize(r->ctx->stream));
+  if (r->points) WS_HIP(hipFree(r->points));
+  r->points = nullptr;
+  r->cap = 0;
+  WS_HIP(hipMalloc((void **)&r->points, n * 3 * sizeof(int32_t)));
+  r->cap = n;
+  return WS_OK;
+}
+
+int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
+{
+  if (!ctx || !out) return invalid("ws_reg_create: NULL argument");
+  ws_reg *r = new (std::nothrow) ws_reg();
+  if (!r) return invalid("ws_reg_create: out of host memory");
+  r->ctx = ctx;
+  if (max_points == 0) max_points = 128 * 1024; // registration.cu:261
+  int rc = reg_reserve(r, max_points);
+  hipError_t e = hipSuccess;
+  if (rc == WS_OK) e = hipMalloc((void **)&r->partials, reg_partials_bytes());
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->state, sizeof(GnState));
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->T_dev, 16 * sizeof(float));
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->sums_dev, 44 * sizeof(int64_t));
+  if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->state_host, sizeof(GnState), hipHostMallocDefault);
+  if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, sizeof(GnState), ctx->stream);
+  if (rc != WS_OK || e != hipSuccess)
+  {
+    if (e != hipSuccess) rc = hip_fail(e, "ws_reg_create allocation", __FILE__, __LINE__);
+    ws_reg_destroy(r);
+    return rc;
+  }
+  *out = r;
+  return WS_OK;
+}
+
+int ws_reg_prepare(ws_reg *r, const int32_t *xyz_host, size_t n)
+{
+  if (!r || (!xyz_host && n)) return invalid("ws_reg_prepare: NULL argument");
+  int rc = reg_reserve(r, n);
+  if (rc != WS_OK) return rc;
+  r->n = n;
+  if (n) WS_HIP(hipMemcpyAsync(r->points, xyz_host, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, r->ctx->stream));
+  return WS_OK;
+}
+
+int ws_reg_prepare_dev(ws_reg *r, const int32_t *xyz_dev, size_t n)
+{
+  if (!r || (!xyz_dev && n)) return invalid("ws_reg_prepare_dev: NULL argument");
+  int rc = reg_reserve(r, n);
+  if (rc != WS_OK) return rc;
+  r->n = n;
+  if (n) WS_HIP(hipMemcpyAsync(r->points, xyz_dev, n * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, r->ctx->stream));
+  return WS_OK;
+}
+
+int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, int64_t h[36], int64_t g[6],
+                   int32_t *e, int32_t *c)
+{
+  if (!r || !m || !T || !h || !g || !e || !c) return invalid("ws_reg_iterate: NULL argument");
+  if (res < 1) return invalid("ws_reg_iterate: map_resolution must be positive");
+  hipStream_t s = r->ctx->stream;
+  WS_HIP(hipMemcpyAsync(r->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, s)); // registration.cu:351
+  int rc = launch_reg_accumulate(r, m, r->T_dev, res, flags, 0, r->n, r->sums_dev, false);
+  if (rc != WS_OK) return rc;
+  int64_t sums[44];
+  WS_HIP(hipMemcpyAsync(sums, r->sums_dev, sizeof sums, hipMemcpyDeviceToHost, s));
+  WS_HIP(hipStreamSynchronize(s));
+  std::memcpy(h, sums, 36 * sizeof(int64_t));
+  std::memcpy(g, sums + 36, 6 * sizeof(int64_t));
+  *e = (int32_t)sums[42];
+  *c = (int32_t)sums[43];
+  return WS_OK;
+}
+
+int ws_reg_begin(ws_reg *r, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon)
+{
+  if (!r || !T_in) return invalid("ws_reg_begin: NULL argument");
+  GnState *h = r->state_host;
+  // the pinned staging block may still be read by an earlier async copy
+  WS_HIP(hipStreamSynchronize(r->ctx->stream));
+  std::memset(h, 0, sizeof(GnState));
+  std::memcpy(h->T, T_in, 16 * sizeof(float));
+  // Point center = total_transform.block<3,1>(0,3).cast<int>() — tsdf_registration.cpp:33
+  for (int k = 0; k < 3; ++k) h->center[k] = (int32_t)T_in[12 + k];
+  h->alpha = 0.f;
+  h->it_weight_gradient = it_weight_gradient;
+  h->epsilon = epsilon;
+  h->max_iterations = max_iterations;
+  WS_HIP(hipMemcpyAsync(r->state, h, sizeof(GnState), hipMemcpyHostToDevice, r->ctx->stream));
+  return WS_OK;
+}
+
+int ws_reg_accumulate_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev)
+{
+  if (!r || !m || !sums_dev) return invalid("ws_reg_accumulate_dev: NULL argument");
+  return launch_reg_accumulate(r, m, nullptr, res, flags, first, count, sums_dev, false);
+}
+
+int ws_reg_solve_dev(ws_reg *r, const int64_t *sums_dev)
+{
+  if (!r || !sums_dev) return invalid("ws_reg_solve_dev: NULL argument");
+  return launch_reg_solve(r, sums_dev);
+}
+
+int ws_reg_poll(ws_reg *r, int32_t *finished, int32_t *iterations, float T_out[16])
+{
+  if (!r) return invalid("ws_reg_poll: reg is NULL");
+  WS_HIP(hipMemcpyAsync(r->state_host, r->state, sizeof(GnState), hipMemcpyDeviceToHost, r->ctx->stream));
+  WS_HIP(hipStreamSynchronize(r->ctx->stream));
+  const GnState *h = r->state_host;
+  if (finished) *finished = (h->finished || h->iterations >= h->max_iterations) ? 1 : 0;
+  if (iterations) *iterations = h->iterations;
+  if (T_out) std::memcpy(T_out, h->T, 16 * sizeof(float));
+  return WS_OK;
+}
+
+int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t max_iterations, float it_weight_gradient,
+                      float epsilon, int32_t res, uint32_t flags, float T_out[16], int32_t *iterations)
+{
+  if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud: NULL argument");
+  if (res < 1) return invalid("ws_register_cloud: map_resolution must be positive");
+  int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
+  if (rc != WS_OK) return rc;
+  // The loop runs on the device; the host only enqueues batches and looks at the `finished` flag in
+  // between (iterations past convergence exit at once on the device).
+  const int batch = 16;
+  int done = 0, fin = 0, iters = 0;
+  while (!fin && done < max_iterations)
+  {
+    int todo = max_iterations - done < batch ? max_iterations - done : batch;
+    for (int i = 0; i < todo; ++i)
+    {
+      rc = launch_reg_accumulate(r, m, nullptr, res, flags, 0, r->n, nullptr, true);
+      if (rc != WS_OK) return rc;
+    }
+    done += todo;
+    rc = ws_reg_poll(r, &fin, &iters, T_out);
+    if (rc != WS_OK) return rc;
+  }
+  if (iterations) *iterations = iters;
+  return WS_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int ws_prof_enable(ws_context *ctx, uint32_t class_mask)
+{
+  if (!ctx) return invalid("ws_prof_enable: ctx is NULL");
+  WS_HIP(hipStreamSynchronize(ctx->stream));
+  prof_resolve(ctx);
+  ctx->prof_mask = class_mask;
+  return WS_OK;
+}
+
+int ws_prof_read(ws_context *ctx, int cls, double *total_ms, int64_t *launches)
+{
+  if (!ctx || cls < 0 || cls >= WS_K_COUNT) return invalid("ws_prof_read: bad argument");
+  WS_HIP(hipStreamSynchronize(ctx->stream));
+  prof_resolve(ctx);
+  if (total_ms) *total_ms = ctx->prof_ms[cls];
+  if (launches) *launches = ctx->prof_n[cls];
+  return WS_OK;
+}
+
+int ws_prof_reset(ws_context *ctx)
+{
+  if (!ctx) return invalid("ws_prof_reset: ctx is NULL");
+  WS_HIP(hipStreamSynchronize(ctx->stream));
+  prof_resolve(ctx);
+  for (int k = 0; k < WS_K_COUNT; ++k)
+  {
+    ctx->prof_ms[k] = 0;
+    ctx->prof_n[k] = 0;
+  }
+  return WS_OK;
+}
+
+} // extern "C"

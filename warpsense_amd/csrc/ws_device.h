@@ -1,0 +1,96 @@
+// ws_device.h — device-side fixed-point helpers shared by the kernels (gfx950).
+//
+// Integer semantics follow the reference exactly: `int` expressions wrap (written through unsigned so
+// the compiler cannot assume "no overflow"), divisions truncate toward zero, `long` is int64.
+#pragma once
+
+#include "ws_internal.h"
+
+namespace ws
+{
+__device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int64_t wmul64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+__device__ __forceinline__ int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+__device__ __forceinline__ int64_t wsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int32_t iabs32(int32_t a) { return a < 0 ? wsub(0, a) : a; }
+
+// Vector3<int>::l2norm — include/warpsense/math/vector3.h:318-330: int(sqrtf(float(int sum)))
+__device__ __forceinline__ int32_t l2norm_i(int32_t x, int32_t y, int32_t z)
+{
+  int32_t sq = wadd(wadd(wmul(x, x), wmul(y, y)), wmul(z, z));
+  return (int32_t)__fsqrt_rn((float)sq);
+}
+// Vector3<long>::l2norm — same header, T = long
+__device__ __forceinline__ int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
+{
+  int64_t sq = wadd64(wadd64(wmul64(x, x), wmul64(y, y)), wmul64(z, z));
+  return (int64_t)__fsqrt_rn((float)sq);
+}
+
+// TSDFEntry — include/map/tsdf.h:16-23
+__device__ __forceinline__ uint32_t pack_entry(int32_t value, int32_t weight)
+{
+  return ((uint32_t)value & 0xffffu) | ((uint32_t)weight << 16);
+}
+__device__ __forceinline__ int32_t entry_value(uint32_t raw) { return (int32_t)(int16_t)(raw & 0xffffu); }
+__device__ __forceinline__ int32_t entry_weight(uint32_t raw) { return (int32_t)(int16_t)(raw >> 16); }
+
+// overflow() — include/warpsense/cuda/device_map.h:14-30
+__device__ __forceinline__ int32_t ring(int32_t val, int32_t max)
+{
+  if (val >= 2 * max) return val - 2 * max;
+  if (val >= max) return val - max;
+  return val;
+}
+
+// DeviceMap::get_index — device_map.h:93-101, z fastest; 64-bit product so 2049^3 does not wrap
+__device__ __forceinline__ int64_t get_index(const MapParams &m, int32_t x, int32_t y, int32_t z)
+{
+  int32_t xi = ring(x - m.pos[0] + m.offset[0] + m.size[0], m.size[0]);
+  int32_t yi = ring(y - m.pos[1] + m.offset[1] + m.size[1], m.size[1]);
+  int32_t zi = ring(z - m.pos[2] + m.offset[2] + m.size[2], m.size[2]);
+  return ((int64_t)xi * m.size[1] + yi) * (int64_t)m.size[2] + zi;
+}
+
+// DeviceMap::in_bounds — device_map.h:109-114
+__device__ __forceinline__ bool in_bounds(const MapParams &m, int32_t x, int32_t y, int32_t z)
+{
+  return iabs32(wsub(x, m.pos[0])) <= m.size[0] / 2 && iabs32(wsub(y, m.pos[1])) <= m.size[1] / 2 &&
+         iabs32(wsub(z, m.pos[2])) <= m.size[2] / 2;
+}
+// in_bounds_with_buffer_pos / _neg — device_map.h:116-128 (unsigned compare: `buffer` is size_t there)
+__device__ __forceinline__ bool in_bounds_buffer(const MapParams &m, int32_t x, int32_t y, int32_t z, int64_t buffer)
+{
+  uint64_t ax = (uint64_t)(int64_t)iabs32(wsub(x, m.pos[0]));
+  uint64_t ay = (uint64_t)(int64_t)iabs32(wsub(y, m.pos[1]));
+  uint64_t az = (uint64_t)(int64_t)iabs32(wsub(z, m.pos[2]));
+  return ax <= (uint64_t)((int64_t)(m.size[0] / 2) + buffer) && ay <= (uint64_t)((int64_t)(m.size[1] / 2) + buffer) &&
+         az <= (uint64_t)((int64_t)(m.size[2] / 2) + buffer);
+}
+
+// weight ramp — update_tsdf.cu:90-94
+__device__ __forceinline__ int32_t tsdf_weight(int32_t value, int32_t tau, int32_t weight_epsilon)
+{
+  int32_t weight = WEIGHT_RESOLUTION;
+  if (value < -weight_epsilon) weight = WEIGHT_RESOLUTION * (tau + value) / (tau - weight_epsilon);
+  return weight;
+}
+
+// cu_avg_tsdf_krnl body — update_tsdf.cu:19-34; returns the updated existing entry
+__device__ __forceinline__ uint32_t integrate_entry(uint32_t existing, uint32_t fresh, int32_t max_weight)
+{
+  int32_t nv = entry_value(fresh), nw = entry_weight(fresh);
+  int32_t ev = entry_value(existing), ew = entry_weight(existing);
+  if (nw > 0 && ew > 0)
+  {
+    int32_t v = (ev * ew + nv * nw) / (ew + nw);
+    int32_t w = min(max_weight, ew + nw);
+    return pack_entry(v, w);
+  }
+  if (nw != 0 && ew <= 0) return fresh;
+  return existing;
+}
+
+} // namespace ws
