@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — scans/s of the warpsense hot path (TSDF update + Point-to-TSDF registration) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one synthetic OS1-128 scan (131 072 points) through
+    TSDFCuda::update_tsdf  (ray-march scatter + integrate into the 513^3 map @ 50 mm)  and
+    TSDFRegistration::register_cloud (Gauss-Newton to convergence against that map),
+with the scan already resident in HBM.  N > 1: every rank keeps a replica of the map and applies the full
+scan; the registration points are sharded by index and the 44-word normal equations are all-reduced over
+RCCL each iteration — total work is fixed, so "scaling" is "strong".
+
+Rank 0 prints ONE JSON line (see the driver contract); extra keys: roofline, cpu_baseline, kernels.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--map", type=int, default=512, help="map edge in voxels (the reference forces it odd: 513)")
+    ap.add_argument("--resolution", type=int, default=50)
+    ap.add_argument("--integrate", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-registration", action="store_true", help="time the TSDF update alone (diagnostics)")
+    return ap.parse_args()
+
+
+def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
+    """The reference's CPU path (port, oracle/cpu_baseline.cpp) on this box's host cores: one scan."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    m = O.OracleMap(size, tau, 0)
+    t0 = time.perf_counter()
+    threads = O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=0)
+    t1 = time.perf_counter()
+    _, it, _ = O.cpu_register_cloud(m, perturbed, np.eye(4), reg_params[0], reg_params[1], reg_params[2], res, threads=0)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "scans/s", "cores": int(threads), "kind": "port",
+            "sample": f"1 scan of the same workload: update_tsdf OpenMP overload (src/cpu/update_tsdf.cpp:566-724) "
+                      f"{t1 - t0:.2f} s + register_cloud (src/cpu/registration.cpp:14-177, {it} iterations) {t2 - t1:.2f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import warpsense_amd as W
+    from warpsense_amd import _lib, synthetic as S
+    from warpsense_amd.dist import HipGnBackend, sharded_register_cloud
+
+    tau, mw, res = 1000, 640, args.resolution
+    size = (args.map, args.map, args.map)
+    reg_params = (200, 0.1, 0.03)
+    ctx = W.Context(local_rank)
+    ctx.use_torch_stream()  # one stream for the library, torch and the RCCL hand-off
+    params = W.Params(W.MapParams(resolution=res, max_distance=tau / 1000.0, max_weight=mw // 64,
+                                  size=tuple(s * res / 1000.0 for s in size)),
+                      W.RegistrationParams(*reg_params))
+    lm = W.LocalMap(size[0], size[1], size[2], tau, 0)
+    host_map = lm.device_map()
+    host_map.data_ = None  # fresh map: let the library fill both device maps with (tau, 0)
+    tsdf = W.TSDFCuda(host_map, tau, mw, res, ctx)
+    tsdf.set_integrate(W.WS_INTEGRATE_DENSE if args.integrate == "dense" else W.WS_INTEGRATE_SPARSE)
+    reg = W.RegistrationCuda(None, ctx)
+    del lm
+
+    points = S.os1_128_scan()
+    perturbed = S.transform_points_mm(points, S.perturbation())
+    d_points = torch.from_numpy(points).cuda()
+    d_pert = torch.from_numpy(perturbed).cuda()
+    n = points.shape[0]
+    eye = np.eye(4, dtype=np.float32)
+    backend = HipGnBackend(reg, tsdf, res)
+    reg.prepare_registration(d_pert)  # resident in HBM before the timed region
+    its = []
+
+    def step():
+        tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
+        if args.no_registration:
+            return
+        if world == 1:
+            _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
+        else:
+            _, it = sharded_register_cloud(backend, n, eye, *reg_params)
+        its.append(it)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    its.clear()
+    tsdf_mask = sum(1 << k for k in (_lib.WS_K_MARCH_EMIT, _lib.WS_K_RESOLVE, _lib.WS_K_MARCH_COLLECT, _lib.WS_K_RESOLVE_LISTS,
+                                      _lib.WS_K_INTEGRATE))
+    ctx.prof_reset()
+    ctx.prof_enable(tsdf_mask)  # hipEvents around the 5 TSDF kernels of every step, on the stream they run on
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernels = {}
+    for k, name in enumerate(_lib.KERNEL_CLASSES[:5]):
+        ms, cnt = ctx.prof_read(k)
+        if cnt:
+            kernels[name] = {"avg_us": 1000.0 * ms / cnt, "launches": cnt}
+    stats = tsdf.stats()
+    ctx.prof_enable(0)
+
+    # registration iteration timing in a separate pass (events per iteration would perturb the timed region)
+    if not args.no_registration and world == 1:
+        ctx.prof_reset()
+        ctx.prof_enable(1 << _lib.WS_K_REG)
+        reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
+        ms, cnt = ctx.prof_read(_lib.WS_K_REG)
+        ctx.prof_enable(0)
+        if cnt:
+            kernels["reg_iteration"] = {"avg_us": 1000.0 * ms / cnt, "launches": cnt, "note": "separate pass"}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant TSDF-update kernel (algorithmic bytes per launch) ----
+    n_vox = int(np.prod([s if s % 2 else s + 1 for s in size]))
+    V, T = 35_442_598, 13_901_324  # scatter targets / distinct voxels of this scan (reproduced by the oracle)
+    streamed_vox = n_vox if args.integrate == "dense" else int(stats["dirty_tiles"]) * 64
+    alg_bytes = {"march_emit": 12 * n + 4 * V + 4 * T, "integrate": 16 * streamed_vox}
+    roofline = None
+    cand = [k for k in ("march_emit", "integrate") if k in kernels]
+    if cand:
+        dom = max(cand, key=lambda k: kernels[k]["avg_us"])
+        achieved = alg_bytes[dom] / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[dom],
+                    "avg_launch_us": kernels[dom]["avg_us"]}
+        t_update_us = sum(kernels[k]["avg_us"] for k in kernels if k != "reg_iteration")
+        b_update = 12 * n + 4 * V + 4 * T + 16 * streamed_vox
+        roofline["update_total"] = {"bytes": b_update, "device_us": t_update_us,
+                                    "achieved": b_update / (t_update_us * 1e-6) / 1e9,
+                                    "frac": b_update / (t_update_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+
+    out = {
+        "metric": "scans/sec (OS1-128 131k pts) TSDF update+reg",
+        "value": args.steps / elapsed,
+        "unit": "scans/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int32/int64 fixed point (f32 pose, f64 6x6 solve)",
+        "data": "synthetic",
+        "config": {"workload": f"OS1-128 synthetic scan, {n} pts, {size[0] + 1 - size[0] % 2}^3 TSDF map @ {res} mm, tau {tau}, "
+                               f"HIP update_tsdf + Point-to-TSDF registration (BASELINE configs[1])",
+                   "points": n, "map_voxels": n_vox, "integrate": args.integrate,
+                   "registration": "skipped" if args.no_registration else
+                   {"max_iterations": reg_params[0], "it_weight_gradient": reg_params[1], "epsilon": reg_params[2],
+                    "iterations_per_scan": float(np.mean(its)) if its else None},
+                   "parallelism": "single GPU" if world == 1 else f"map replicated, registration points sharded x{world}, "
+                                                                   "RCCL all-reduce of 44 int64 per iteration",
+                   "contested_voxels": stats["contested_voxels"], "tiles_streamed": stats["dirty_tiles"]},
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(points, perturbed, size, tau, mw, res, reg_params)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

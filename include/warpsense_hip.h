@@ -139,11 +139,13 @@ int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out
 
 /* ------------------------------------------------------------------ measurement ---- */
 /* Kernel classes for hipEvent timing (bench.py's roofline leg). */
-#define WS_K_MARCH 0     /* ray-march scatter passes                       */
-#define WS_K_RESOLVE 1   /* key -> entry resolution passes                 */
-#define WS_K_INTEGRATE 2 /* dense or sparse weighted-average pass          */
-#define WS_K_REG 3       /* one Gauss-Newton iteration (Jacobian+reduce+solve) */
-#define WS_K_COUNT 4
+#define WS_K_MARCH_EMIT 0     /* ray-march, key emission (march_kernel<EMIT>)                 */
+#define WS_K_RESOLVE 1        /* key -> entry resolution over the touched tiles               */
+#define WS_K_MARCH_COLLECT 2  /* ray-march, candidate lists of contested voxels               */
+#define WS_K_RESOLVE_LISTS 3  /* ordered fold of those lists                                  */
+#define WS_K_INTEGRATE 4      /* dense or sparse weighted-average pass (cu_avg_tsdf_krnl)     */
+#define WS_K_REG 5            /* one Gauss-Newton iteration (accumulate + finish/solve)       */
+#define WS_K_COUNT 6
 int ws_prof_enable(ws_context *ctx, uint32_t class_mask); /* 0 disables */
 /* sum of event-measured durations and number of launches per class since the last reset (synchronises) */
 int ws_prof_read(ws_context *ctx, int kernel_class, double *total_ms, int64_t *launches);

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
 WS_MAP_AVG, WS_MAP_NEW = 0, 1
 WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE = 0, 1
 WS_REG_ALL_POINTS, WS_REG_COMPAT_REFERENCE_LAUNCH = 0, 1
-WS_K_MARCH, WS_K_RESOLVE, WS_K_INTEGRATE, WS_K_REG = 0, 1, 2, 3
+WS_K_MARCH_EMIT, WS_K_RESOLVE, WS_K_MARCH_COLLECT, WS_K_RESOLVE_LISTS, WS_K_INTEGRATE, WS_K_REG = range(6)
+KERNEL_CLASSES = ["march_emit", "resolve", "march_collect", "resolve_lists", "integrate", "reg_iteration"]
 
 # every symbol include/warpsense_hip.h declares (tests check the library exports all of them)
 EXPORTS = [

@@ -33,7 +33,7 @@ def flags() -> list[str]:
     # -ffp-contract=off: the Gauss-Newton update must round like the host code of the reference (no FMA fusion);
     # correctly rounded sqrt/div are hipcc's default and are required by the integer truncations.
     return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-            "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+            "-Wall", "-Wno-unused-function", *os.environ.get("WS_EXTRA_FLAGS", "").split(), f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 
 
 def needs_build() -> bool:

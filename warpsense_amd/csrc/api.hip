@@ -399,6 +399,7 @@ int ws_reg_destroy(ws_reg *r)
   if (r->T_dev) (void)hipFree(r->T_dev);
   if (r->sums_dev) (void)hipFree(r->sums_dev);
   if (r->state_host) (void)hipHostFree(r->state_host);
+  if (r->host_flag) (void)hipHostFree(r->host_flag);
   delete r;
   return WS_OK;
 }
@@ -425,11 +426,13 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   int rc = reg_reserve(r, max_points);
   hipError_t e = hipSuccess;
   if (rc == WS_OK) e = hipMalloc((void **)&r->partials, reg_partials_bytes());
-  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->state, sizeof(GnState));
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->state, 2 * sizeof(GnState));
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->T_dev, 16 * sizeof(float));
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->sums_dev, 44 * sizeof(int64_t));
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->state_host, sizeof(GnState), hipHostMallocDefault);
-  if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, sizeof(GnState), ctx->stream);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->host_flag, 64, hipHostMallocMapped);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->host_flag_dev, r->host_flag, 0);
+  if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, 2 * sizeof(GnState), ctx->stream);
   if (rc != WS_OK || e != hipSuccess)
   {
     if (e != hipSuccess) rc = hip_fail(e, "ws_reg_create allocation", __FILE__, __LINE__);
@@ -467,7 +470,7 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
   if (res < 1) return invalid("ws_reg_iterate: map_resolution must be positive");
   hipStream_t s = r->ctx->stream;
   WS_HIP(hipMemcpyAsync(r->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, s)); // registration.cu:351
-  int rc = launch_reg_accumulate(r, m, r->T_dev, res, flags, 0, r->n, r->sums_dev, false);
+  int rc = launch_reg_accumulate(r, m, r->T_dev, res, flags, 0, r->n, r->sums_dev);
   if (rc != WS_OK) return rc;
   int64_t sums[44];
   WS_HIP(hipMemcpyAsync(sums, r->sums_dev, sizeof sums, hipMemcpyDeviceToHost, s));
@@ -486,21 +489,24 @@ int ws_reg_begin(ws_reg *r, const float T_in[16], int32_t max_iterations, float 
   // the pinned staging block may still be read by an earlier async copy
   WS_HIP(hipStreamSynchronize(r->ctx->stream));
   std::memset(h, 0, sizeof(GnState));
-  std::memcpy(h->T, T_in, 16 * sizeof(float));
+  std::memcpy(h->core.T, T_in, 16 * sizeof(float));
   // Point center = total_transform.block<3,1>(0,3).cast<int>() — tsdf_registration.cpp:33
-  for (int k = 0; k < 3; ++k) h->center[k] = (int32_t)T_in[12 + k];
-  h->alpha = 0.f;
-  h->it_weight_gradient = it_weight_gradient;
-  h->epsilon = epsilon;
-  h->max_iterations = max_iterations;
-  WS_HIP(hipMemcpyAsync(r->state, h, sizeof(GnState), hipMemcpyHostToDevice, r->ctx->stream));
+  for (int k = 0; k < 3; ++k) h->core.center[k] = (int32_t)T_in[12 + k];
+  h->core.alpha = 0.f;
+  h->core.it_weight_gradient = it_weight_gradient;
+  h->core.epsilon = epsilon;
+  h->core.max_iterations = max_iterations;
+  *(volatile int32_t *)r->host_flag = 0;
+  WS_HIP(hipMemcpyAsync(&r->state[0], h, sizeof(GnState), hipMemcpyHostToDevice, r->ctx->stream));
+  WS_HIP(hipMemcpyAsync(&r->state[1], h, sizeof(GnState), hipMemcpyHostToDevice, r->ctx->stream));
+  r->latest = 0;
   return WS_OK;
 }
 
 int ws_reg_accumulate_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev)
 {
   if (!r || !m || !sums_dev) return invalid("ws_reg_accumulate_dev: NULL argument");
-  return launch_reg_accumulate(r, m, nullptr, res, flags, first, count, sums_dev, false);
+  return launch_reg_accumulate(r, m, nullptr, res, flags, first, count, sums_dev);
 }
 
 int ws_reg_solve_dev(ws_reg *r, const int64_t *sums_dev)
@@ -512,9 +518,9 @@ int ws_reg_solve_dev(ws_reg *r, const int64_t *sums_dev)
 int ws_reg_poll(ws_reg *r, int32_t *finished, int32_t *iterations, float T_out[16])
 {
   if (!r) return invalid("ws_reg_poll: reg is NULL");
-  WS_HIP(hipMemcpyAsync(r->state_host, r->state, sizeof(GnState), hipMemcpyDeviceToHost, r->ctx->stream));
+  WS_HIP(hipMemcpyAsync(r->state_host, &r->state[r->latest], sizeof(GnState), hipMemcpyDeviceToHost, r->ctx->stream));
   WS_HIP(hipStreamSynchronize(r->ctx->stream));
-  const GnState *h = r->state_host;
+  const GnCore *h = &r->state_host->core;
   if (finished) *finished = (h->finished || h->iterations >= h->max_iterations) ? 1 : 0;
   if (iterations) *iterations = h->iterations;
   if (T_out) std::memcpy(T_out, h->T, 16 * sizeof(float));
@@ -528,22 +534,22 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
   if (res < 1) return invalid("ws_register_cloud: map_resolution must be positive");
   int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
   if (rc != WS_OK) return rc;
-  // The loop runs on the device; the host only enqueues batches and looks at the `finished` flag in
-  // between (iterations past convergence exit at once on the device).
-  const int batch = 16;
-  int done = 0, fin = 0, iters = 0;
-  while (!fin && done < max_iterations)
+  // The whole loop runs on the device: launch k applies update k (from the partial sums launch k-1 left
+  // behind) and accumulates for iteration k.  The host just enqueues; the device raises a flag in
+  // host-mapped memory on convergence so the host can stop early (launches already enqueued exit at once).
+  const volatile int32_t *flag = r->host_flag;
+  int launched = 0;
+  for (int k = 0; k <= max_iterations; ++k)
   {
-    int todo = max_iterations - done < batch ? max_iterations - done : batch;
-    for (int i = 0; i < todo; ++i)
-    {
-      rc = launch_reg_accumulate(r, m, nullptr, res, flags, 0, r->n, nullptr, true);
-      if (rc != WS_OK) return rc;
-    }
-    done += todo;
-    rc = ws_reg_poll(r, &fin, &iters, T_out);
+    if (*flag) break;
+    rc = launch_reg_iteration(r, m, res, flags, k);
     if (rc != WS_OK) return rc;
+    launched = k + 1;
   }
+  r->latest = launched > 0 ? ((launched - 1) & 1) : 0;
+  int fin = 0, iters = 0;
+  rc = ws_reg_poll(r, &fin, &iters, T_out);
+  if (rc != WS_OK) return rc;
   if (iterations) *iterations = iters;
   return WS_OK;
 }

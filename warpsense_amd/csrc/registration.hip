@@ -4,64 +4,287 @@
 // (src/warpsense/cuda/registration.cu:14-257,310-368) and moves the Gauss-Newton update of
 // cuda::TSDFRegistration::register_cloud (src/warpsense/tsdf_registration.cpp:55-92) onto the device.
 //
-//   reg_accumulate_kernel  one fused pass: fixed-point transform, voxel + 6-neighbour gather, gradient,
-//                          Jacobian, and the per-lane accumulation of the 21 unique terms of J J^T, the 6
-//                          of J v, |v| and the count in int64 registers; wave64 shuffle tree, LDS across
-//                          the 4 waves, one 29-word partial per workgroup.  No Jacobian/value/mask round
-//                          trip through HBM (the reference writes and re-reads 51 B per point).
-//   reg_finish_kernel      one workgroup: sums the partials (exact integer sums -> order independent,
-//                          bit-identical to the reference's tree), mirrors h to 6x6, and optionally runs
-//                          the 6x6 solve, xi -> SE(3) and the convergence test in double/float like the
-//                          host code of the reference.
+// One launch of reg_iter_kernel is one Gauss-Newton iteration:
+//   phase A  (k > 0) every workgroup sums the 256 x 29 int64 partials the previous launch left in HBM
+//            (exact integer sums -> order independent, bit-identical to the reference's tree), one lane
+//            runs the 6x6 solve, xi -> SE(3) and the convergence test exactly like the reference's host
+//            code (double LU, float pose).  Doing this redundantly per workgroup costs nothing extra
+//            (they all wait for the same ~60 KB from L2) and saves a kernel boundary and a launch.
+//   phase B  fixed-point transform, voxel + 6-neighbour gather, gradient, Jacobian, per-lane accumulation
+//            of the 21 unique terms of J J^T, the 6 of J v, |v| and the count in int64 registers
+//            (v_mad_i64_i32), a transposing wave64 reduction (32 values in 32 shuffles instead of 32 x 6),
+//            LDS across the 4 waves, one 29-word partial per workgroup.
+// No Jacobian / value / mask arrays ever reach HBM (the reference writes and re-reads 51 B per point).
+// State and partials are double buffered by launch parity, so no fences or atomics are needed.
 #include "ws_device.h"
 
 namespace ws
 {
 constexpr int REG_BLOCKS = 256;  // one workgroup per CU
-constexpr int REG_THREADS = 512; // 8 waves
+constexpr int REG_THREADS = 256; // 4 waves
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c
+constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
+static_assert(REG_BLOCKS == REG_THREADS, "phase A reads one partial per thread");
 
-struct AccArgs
+// exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
+struct FastDiv
+{
+  uint64_t M;
+  int32_t k;
+  int32_t d;
+};
+
+__host__ FastDiv make_fastdiv(int32_t d)
+{
+  FastDiv f;
+  f.d = d;
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  f.k = 31 + l;
+  f.M = (uint64_t)(((unsigned __int128)1 << f.k) / (unsigned)d) + 1; // ceil for non powers of two; exact enough for powers of two too
+  if (((unsigned __int128)1 << f.k) % (unsigned)d == 0) f.M -= 1;
+  return f;
+}
+
+// C-style truncating division of any int32 by the prepared positive divisor
+__device__ __forceinline__ int32_t div_trunc(int32_t x, const FastDiv &f)
+{
+  const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
+  uint32_t q;
+  if (ax == 0x80000000u)
+    q = ax / (uint32_t)f.d; // |INT_MIN| is outside the multiply-shift range
+  else
+    q = (uint32_t)(((uint64_t)ax * f.M) >> f.k); // ax < 2^31, M <= 2^32: no overflow
+  return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
+}
+
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask)
+{
+  int lo = __shfl_xor((int)(uint32_t)((uint64_t)v & 0xffffffffull), mask, 64);
+  int hi = __shfl_xor((int)(uint32_t)((uint64_t)v >> 32), mask, 64);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// One stage of the transposing butterfly: lanes whose `BIT` is clear keep the lower HALF values and
+// receive the partner's lower half, the others keep/receive the upper half.
+template <int HALF, int BIT>
+__device__ __forceinline__ void reduce_stage(int64_t (&v)[REG_SLOTS], int lane)
+{
+  const bool upper = (lane & BIT) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i)
+  {
+    const int64_t send = upper ? v[i] : v[i + HALF];
+    const int64_t keep = upper ? v[i + HALF] : v[i];
+    v[i] = wadd64(keep, shfl_xor_i64(send, BIT));
+  }
+}
+
+// Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
+// trailing barrier). Every stage halves the values a lane still carries, so a wave needs
+// 16+8+4+2+1+1 = 32 exchanges for 32 values instead of 32 x 6.
+__device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS], int64_t *red)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  reduce_stage<16, 32>(v, lane);
+  reduce_stage<8, 16>(v, lane);
+  reduce_stage<4, 8>(v, lane);
+  reduce_stage<2, 4>(v, lane);
+  reduce_stage<1, 2>(v, lane);
+  v[0] = wadd64(v[0], shfl_xor_i64(v[0], 1));
+  // lane l now holds the wave total of slot (l >> 1)
+  if ((lane & 1) == 0) wave_part[wave][lane >> 1] = v[0];
+  __syncthreads();
+  if (threadIdx.x < REG_SLOTS)
+  {
+    int64_t s = 0;
+#pragma unroll
+    for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, wave_part[w][threadIdx.x]);
+    red[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// row-major upper triangle index of (i <= j)
+__host__ __device__ constexpr int tri_index(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+// 29 reduced terms -> the reference's 44 words: h 6x6 column-major (math/matrix6x6.h:112-115), g[6], e, c
+__device__ __forceinline__ void expand_sums(const int64_t *terms, int64_t *sums)
+{
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sums[j * 6 + i] = terms[i <= j ? tri_index(i, j) : tri_index(j, i)];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sums[36 + i] = terms[21 + i];
+  sums[42] = (int64_t)(int32_t)terms[27]; // e and c are `int` in the reference (registration.cu:16-21)
+  sums[43] = (int64_t)(int32_t)terms[28];
+}
+
+// ---- 6x6 solve, fully unrolled so every index is static (no scratch): LU with partial pivoting in
+// double, the same operation order as oracle/ws_oracle.c:wso_solve6 (Eigen hf.inverse()*g, tsdf_registration.cpp:69)
+__device__ __forceinline__ int solve6(double (&A)[6][6], double (&b)[6], double (&x)[6])
+{
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+  {
+    int piv = k;
+    double best = fabs(A[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+    {
+      const double c = fabs(A[i][k]);
+      if (c > best)
+      {
+        best = c;
+        piv = i;
+      }
+    }
+    if (best == 0.0) return -1;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+    {
+      if (piv == i)
+      {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+        {
+          const double t = A[k][j];
+          A[k][j] = A[i][j];
+          A[i][j] = t;
+        }
+        const double t = b[k];
+        b[k] = b[i];
+        b[i] = t;
+      }
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+    {
+      const double f = A[i][k] / A[k][k];
+#pragma unroll
+      for (int j = k; j < 6; ++j) A[i][j] -= f * A[k][j];
+      b[i] -= f * b[k];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i)
+  {
+    double s = b[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
+    x[i] = s / A[i][i];
+  }
+  return 0;
+}
+
+// One Gauss-Newton update (tsdf_registration.cpp:63-92, registration/util.h:5-39), single lane.
+__device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
+{
+  if (st.finished || st.iterations >= st.max_iterations) return;
+  const int32_t e = (int32_t)sums[42], c = (int32_t)sums[43];
+  st.iterations += 1;
+  if (c == 0)
+  {
+    st.finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
+    return;
+  }
+  double hf[6][6], gf[6], xi[6];
+  const double w = (double)(st.alpha * (float)c);
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+  {
+    gf[r] = (double)sums[36 + r];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) hf[r][q] = (double)sums[q * 6 + r] + (r == q ? w : 0.0);
+  }
+  if (solve6(hf, gf, xi) != 0)
+  {
+    st.finished = 1;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
+
+  // xi_to_transform
+  const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+  float L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  if (theta != 0.0)
+  {
+    const double lx = xi[0] / theta, ly = xi[1] / theta, lz = xi[2] / theta;
+    L[0][1] = (float)-lz; L[0][2] = (float)ly;
+    L[1][0] = (float)lz;  L[1][2] = (float)-lx;
+    L[2][0] = (float)-ly; L[2][1] = (float)lx;
+  }
+  const float s = (float)sin(theta), omc = (float)(1 - cos(theta));
+  float R[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+    {
+      float ll = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ll = __fadd_rn(ll, __fmul_rn(__fmul_rn(omc, L[i][k]), L[k][j]));
+      R[i][j] = __fadd_rn(__fadd_rn((i == j ? 1.f : 0.f), __fmul_rn(s, L[i][j])), ll);
+    }
+  float tr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tr[i] = 0.f;
+  tr[15] = 1.f;
+  const float oc0 = -(float)st.center[0], oc1 = -(float)st.center[1], oc2 = -(float)st.center[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tr[j * 4 + i] = R[i][j];
+    const float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
+    tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), (float)xi[3 + i]);
+  }
+  st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
+  float out[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(tr[k * 4 + i], st.T[j * 4 + k]));
+      out[j * 4 + i] = acc;
+    }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st.T[i] = out[i];
+
+  const float err = __fdiv_rn((float)e, (float)c);
+  if (fabsf(err - st.prev[2]) < st.epsilon && fabsf(err - st.prev[0]) < st.epsilon) st.finished = 1;
+  st.prev[0] = st.prev[1];
+  st.prev[1] = st.prev[2];
+  st.prev[2] = st.prev[3];
+  st.prev[3] = err;
+}
+
+struct PointArgs
 {
   const int32_t *points;
   uint32_t first;
   uint32_t end; // exclusive
   const uint32_t *map_data;
   MapParams map;
-  int32_t res;
-  const float *T;         // 16 floats, column-major
-  const GnState *state;   // may be null (ws_reg_iterate)
-  int64_t *partials;      // [REG_TERMS][REG_BLOCKS]
+  FastDiv resdiv;
 };
 
-__device__ __forceinline__ int64_t shfl_down_i64(int64_t v, int delta)
+// phase B: accumulate the 29 terms of this lane's points (registration.cu:194-257 + :41-118 fused)
+__device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, int64_t (&acc)[REG_SLOTS])
 {
-  int lo = __shfl_down((int)(uint32_t)((uint64_t)v & 0xffffffffull), delta, 64);
-  int hi = __shfl_down((int)(uint32_t)((uint64_t)v >> 32), delta, 64);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-
-__global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
-{
-  __shared__ int64_t lds[REG_THREADS / 64][REG_TERMS];
-  if (a.state != nullptr)
-  {
-    if (a.state->finished || a.state->iterations >= a.state->max_iterations) return;
-  }
-
   // cu_to_int_mat (cuda/util.h:24-35): (int)(float * 32768)
   int32_t M[12];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) M[j * 3 + i] = (int32_t)(a.T[j * 4 + i] * (float)MATRIX_RESOLUTION);
+    for (int i = 0; i < 3; ++i) M[j * 3 + i] = (int32_t)(T[j * 4 + i] * (float)MATRIX_RESOLUTION);
   // registration.cu:208: center = (int) translation of the CURRENT transform
-  const int32_t cx = (int32_t)a.T[12], cy = (int32_t)a.T[13], cz = (int32_t)a.T[14];
-  const int32_t res = a.res;
-
-  int64_t acc[REG_TERMS];
-#pragma unroll
-  for (int k = 0; k < REG_TERMS; ++k) acc[k] = 0;
+  const int32_t cx = (int32_t)T[12], cy = (int32_t)T[13], cz = (int32_t)T[14];
 
   for (uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x; idx < a.end; idx += REG_BLOCKS * REG_THREADS)
   {
@@ -70,7 +293,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
     int32_t qx = wadd(wadd(wadd(wmul(M[0], px), wmul(M[3], py)), wmul(M[6], pz)), M[9]) / MATRIX_RESOLUTION;
     int32_t qy = wadd(wadd(wadd(wmul(M[1], px), wmul(M[4], py)), wmul(M[7], pz)), M[10]) / MATRIX_RESOLUTION;
     int32_t qz = wadd(wadd(wadd(wmul(M[2], px), wmul(M[5], py)), wmul(M[8], pz)), M[11]) / MATRIX_RESOLUTION;
-    const int32_t bx = qx / res, by = qy / res, bz = qz / res;
+    const int32_t bx = div_trunc(qx, a.resdiv), by = div_trunc(qy, a.resdiv), bz = div_trunc(qz, a.resdiv);
     qx = wsub(qx, cx);
     qy = wsub(qy, cy);
     qz = wsub(qz, cz);
@@ -100,232 +323,179 @@ __global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
       const int32_t nv = entry_value(zn), lv = entry_value(zl);
       if (entry_weight(zn) != 0 && entry_weight(zl) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) gz = (nv - lv) / 2;
     }
-    // point.cross(gradient) in int (math/vector3.h:269-277), widened to long
-    int64_t J[6];
+    // point.cross(gradient) in int (math/vector3.h:269-277); J = (cross, gradient) as long
+    int32_t J[6];
     J[0] = wsub(wmul(qy, gz), wmul(qz, gy));
     J[1] = wsub(wmul(qz, gx), wmul(qx, gz));
     J[2] = wsub(wmul(qx, gy), wmul(qy, gx));
     J[3] = gx;
     J[4] = gy;
     J[5] = gz;
-    const int64_t v = entry_value(cur);
+    const int32_t v = entry_value(cur);
 
-    // 21 unique terms of J J^T (registration.cu:55-97), row-major upper triangle
-    int t = 0;
+    // 21 unique terms of J J^T (registration.cu:55-97); int32 x int32 + int64 maps onto v_mad_i64_i32
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = i; j < 6; ++j) acc[t] = wadd64(acc[t], wmul64(J[i], J[j])), ++t;
+      for (int j = i; j < 6; ++j) acc[tri_index(i, j)] = wadd64(acc[tri_index(i, j)], (int64_t)J[i] * (int64_t)J[j]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], wmul64(J[i], v));
+    for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], (int64_t)J[i] * (int64_t)v);
     acc[27] += (v < 0 ? -v : v);
     acc[28] += 1;
   }
-
-  // wave64 shuffle tree, then LDS across the waves
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < REG_TERMS; ++k)
-  {
-    int64_t v = acc[k];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = wadd64(v, shfl_down_i64(v, d));
-    if (lane == 0) lds[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < REG_TERMS)
-  {
-    int64_t s = 0;
-#pragma unroll
-    for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, lds[w][threadIdx.x]);
-    a.partials[(size_t)threadIdx.x * REG_BLOCKS + blockIdx.x] = s;
-  }
 }
 
-// ---- 6x6 solve + pose update, single lane (tsdf_registration.cpp:63-92, registration/util.h:5-39) ----
-__device__ int solve6(double A[6][6], double b[6], double x[6])
+struct IterArgs
 {
-  for (int k = 0; k < 6; ++k)
-  {
-    int piv = k;
-    double best = fabs(A[k][k]);
-    for (int i = k + 1; i < 6; ++i)
-      if (fabs(A[i][k]) > best)
-      {
-        best = fabs(A[i][k]);
-        piv = i;
-      }
-    if (best == 0.0) return -1;
-    if (piv != k)
-    {
-      for (int j = 0; j < 6; ++j)
-      {
-        double t = A[k][j];
-        A[k][j] = A[piv][j];
-        A[piv][j] = t;
-      }
-      double t = b[k];
-      b[k] = b[piv];
-      b[piv] = t;
-    }
-    for (int i = k + 1; i < 6; ++i)
-    {
-      double f = A[i][k] / A[k][k];
-      for (int j = k; j < 6; ++j) A[i][j] -= f * A[k][j];
-      b[i] -= f * b[k];
-    }
-  }
-  for (int i = 5; i >= 0; --i)
-  {
-    double s = b[i];
-    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
-    x[i] = s / A[i][i];
-  }
-  return 0;
-}
-
-__device__ void gn_update(GnState *st, const int64_t sums[44])
-{
-  if (st->finished || st->iterations >= st->max_iterations) return;
-  const int32_t e = (int32_t)sums[42], c = (int32_t)sums[43];
-  st->iterations += 1;
-  for (int k = 0; k < 44; ++k) st->sums[k] = sums[k];
-  if (c == 0)
-  {
-    st->finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
-    return;
-  }
-  double hf[6][6], gf[6], xi[6];
-  const double w = (double)(st->alpha * (float)c);
-  for (int r = 0; r < 6; ++r)
-  {
-    gf[r] = (double)sums[36 + r];
-    for (int q = 0; q < 6; ++q) hf[r][q] = (double)sums[q * 6 + r] + (r == q ? w : 0.0);
-  }
-  if (solve6(hf, gf, xi) != 0)
-  {
-    st->finished = 1;
-    return;
-  }
-  for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
-
-  // xi_to_transform
-  const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
-  float L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  if (theta != 0.0)
-  {
-    const double lx = xi[0] / theta, ly = xi[1] / theta, lz = xi[2] / theta;
-    L[0][1] = (float)-lz; L[0][2] = (float)ly;
-    L[1][0] = (float)lz;  L[1][2] = (float)-lx;
-    L[2][0] = (float)-ly; L[2][1] = (float)lx;
-  }
-  const float s = (float)sin(theta), omc = (float)(1 - cos(theta));
-  float R[3][3];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-    {
-      float ll = 0.f;
-      for (int k = 0; k < 3; ++k) ll = __fadd_rn(ll, __fmul_rn(__fmul_rn(omc, L[i][k]), L[k][j]));
-      R[i][j] = __fadd_rn(__fadd_rn((i == j ? 1.f : 0.f), __fmul_rn(s, L[i][j])), ll);
-    }
-  float tr[16];
-  for (int i = 0; i < 16; ++i) tr[i] = 0.f;
-  tr[15] = 1.f;
-  for (int i = 0; i < 3; ++i)
-  {
-    for (int j = 0; j < 3; ++j) tr[j * 4 + i] = R[i][j];
-    const float oc0 = -(float)st->center[0], oc1 = -(float)st->center[1], oc2 = -(float)st->center[2];
-    float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
-    tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st->center[i]), (float)xi[3 + i]);
-  }
-  st->alpha = __fadd_rn(st->alpha, st->it_weight_gradient);
-  float out[16];
-  for (int j = 0; j < 4; ++j)
-    for (int i = 0; i < 4; ++i)
-    {
-      float acc = 0.f;
-      for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(tr[k * 4 + i], st->T[j * 4 + k]));
-      out[j * 4 + i] = acc;
-    }
-  for (int i = 0; i < 16; ++i) st->T[i] = out[i];
-
-  const float err = __fdiv_rn((float)e, (float)c);
-  if (fabsf(err - st->prev[2]) < st->epsilon && fabsf(err - st->prev[0]) < st->epsilon) st->finished = 1;
-  st->prev[0] = st->prev[1];
-  st->prev[1] = st->prev[2];
-  st->prev[2] = st->prev[3];
-  st->prev[3] = err;
-}
-
-struct FinishArgs
-{
-  const int64_t *partials; // [REG_TERMS][REG_BLOCKS]
-  int64_t *sums_out;       // 44 or null
-  GnState *state;          // null -> no early exit / no solve
-  int solve;
+  PointArgs pts;
+  GnState *state;     // [2], double buffered by launch parity
+  int64_t *partials;  // [2][REG_SLOTS][REG_BLOCKS]
+  int32_t k;          // launch index 0 .. max_iterations
+  int32_t *host_flag; // host-mapped: set when the loop has finished (lets the host stop enqueueing)
 };
 
-// maps (i <= j) of the row-major upper triangle to its running index
-__device__ __forceinline__ int tri_index(int i, int j)
+// One launch == one Gauss-Newton iteration (see the header of this file).
+__global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
 {
-  // i <= j ; rows have 6,5,4,3,2,1 entries
-  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  __shared__ float T_sh[16];
+  __shared__ int stop_sh;
+
+#ifdef WS_REG_TIMING
+  long long ts[6];
+  ts[0] = wall_clock64();
+#define WS_STAMP(i) ts[i] = wall_clock64()
+#else
+#define WS_STAMP(i)
+#endif
+  const GnState *prev = &a.state[(a.k + 1) & 1];
+  GnState *cur = &a.state[a.k & 1];
+  const bool need_update = a.k > 0 && !prev->core.finished && prev->core.iterations < prev->core.max_iterations;
+
+  if (need_update)
+  {
+    // phase A: total of the previous launch's partials (every workgroup, redundantly)
+    const int64_t *pp = a.partials + (size_t)((a.k + 1) & 1) * REG_SLOTS * REG_BLOCKS;
+    int64_t v[REG_SLOTS];
+#pragma unroll
+    for (int t = 0; t < REG_SLOTS; ++t) v[t] = t < REG_TERMS ? pp[(size_t)t * REG_BLOCKS + threadIdx.x] : 0;
+    WS_STAMP(1);
+    block_reduce32(v, wave_part, red);
+  }
+  WS_STAMP(2);
+  if (threadIdx.x == 0)
+  {
+    GnCore st = prev->core;
+    if (need_update)
+    {
+      int64_t sums[44];
+      expand_sums(red, sums);
+      gn_update(st, sums);
+      if (blockIdx.x == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < 44; ++i) cur->sums[i] = sums[i];
+      }
+    }
+    const int stop = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
+    stop_sh = stop;
+    if (blockIdx.x == 0)
+    {
+      cur->core = st;
+      if (stop && a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  WS_STAMP(3);
+  if (stop_sh) return;
+
+  // phase B
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+  int64_t acc[REG_SLOTS];
+#pragma unroll
+  for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+  accumulate_points(a.pts, T, acc);
+  WS_STAMP(4);
+  block_reduce32(acc, wave_part, red);
+  if (threadIdx.x < REG_SLOTS)
+    a.partials[(size_t)(a.k & 1) * REG_SLOTS * REG_BLOCKS + (size_t)threadIdx.x * REG_BLOCKS + blockIdx.x] = red[threadIdx.x];
+#ifdef WS_REG_TIMING
+  WS_STAMP(5);
+  if (blockIdx.x == 7 && threadIdx.x == 0 && a.k == 20)
+    printf("reg_iter k=%d ticks(100MHz): load %lld reduce %lld solve %lld accumulate %lld reduce %lld\n", a.k, ts[1] - ts[0], ts[2] - ts[1],
+           ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
+#endif
 }
 
-__global__ __launch_bounds__(256) void reg_finish_kernel(FinishArgs a)
+// ---- the same pieces as separate kernels: perform_registration (host gets h,g,e,c) and the multi-GPU
+// path (partials -> 44 sums in HBM -> RCCL all-reduce -> solve) ----
+struct AccArgs
 {
-  __shared__ int64_t terms[REG_TERMS];
-  __shared__ int64_t sums[44];
-  if (a.state != nullptr)
-  {
-    if (a.state->finished || a.state->iterations >= a.state->max_iterations) return;
-  }
-  // 8 lanes per term: 29 * 8 = 232 active lanes
-  const int term = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  int64_t s = 0;
-  if (term < REG_TERMS)
-  {
-    for (int b = sub; b < REG_BLOCKS; b += 8) s = wadd64(s, a.partials[(size_t)term * REG_BLOCKS + b]);
-  }
-  s = wadd64(s, shfl_down_i64(s, 4));
-  s = wadd64(s, shfl_down_i64(s, 2));
-  s = wadd64(s, shfl_down_i64(s, 1));
-  if (term < REG_TERMS && sub == 0) terms[term] = s;
-  __syncthreads();
-  if (threadIdx.x < 36)
-  {
-    // Matrix6x6l is column-major: h.at(i,j) = data[j][i] (math/matrix6x6.h:112-115)
-    const int j = threadIdx.x / 6, i = threadIdx.x % 6;
-    sums[threadIdx.x] = terms[i <= j ? tri_index(i, j) : tri_index(j, i)];
-  }
-  else if (threadIdx.x < 44)
-  {
-    int64_t v = terms[21 + (threadIdx.x - 36)];
-    if (threadIdx.x >= 42) v = (int64_t)(int32_t)v; // e and c are `int` in the reference (registration.cu:16-21)
-    sums[threadIdx.x] = v;
-  }
-  __syncthreads();
-  if (a.sums_out != nullptr && threadIdx.x < 44) a.sums_out[threadIdx.x] = sums[threadIdx.x];
-  if (a.solve && a.state != nullptr && threadIdx.x == 0) gn_update(a.state, sums);
+  PointArgs pts;
+  const float *T;       // 16 floats, column-major (device)
+  const GnState *state; // null: no early exit
+  int64_t *partials;    // [REG_SLOTS][REG_BLOCKS] (buffer 0)
+};
+
+__global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  if (a.state != nullptr && (a.state->core.finished || a.state->core.iterations >= a.state->core.max_iterations)) return;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = a.T[i];
+  int64_t acc[REG_SLOTS];
+#pragma unroll
+  for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+  accumulate_points(a.pts, T, acc);
+  block_reduce32(acc, wave_part, red);
+  if (threadIdx.x < REG_SLOTS) a.partials[(size_t)threadIdx.x * REG_BLOCKS + blockIdx.x] = red[threadIdx.x];
 }
 
-// the solve alone, fed with externally (all-)reduced sums
+__global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *partials, const GnState *state, int64_t *sums_out)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  if (state != nullptr && (state->core.finished || state->core.iterations >= state->core.max_iterations)) return;
+  int64_t v[REG_SLOTS];
+#pragma unroll
+  for (int t = 0; t < REG_SLOTS; ++t) v[t] = t < REG_TERMS ? partials[(size_t)t * REG_BLOCKS + threadIdx.x] : 0;
+  block_reduce32(v, wave_part, red);
+  if (threadIdx.x == 0)
+  {
+    int64_t sums[44];
+    expand_sums(red, sums);
+#pragma unroll
+    for (int k = 0; k < 44; ++k) sums_out[k] = sums[k];
+  }
+}
+
+// the solve alone, fed with externally (all-)reduced sums; updates state buffer 0
 __global__ void reg_solve_kernel(GnState *state, const int64_t *sums_dev)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0)
   {
     int64_t sums[44];
+#pragma unroll
     for (int k = 0; k < 44; ++k) sums[k] = sums_dev[k];
     sums[42] = (int64_t)(int32_t)sums[42];
     sums[43] = (int64_t)(int32_t)sums[43];
-    gn_update(state, sums);
+    GnCore st = state->core;
+    gn_update(st, sums);
+    state->core = st;
+#pragma unroll
+    for (int k = 0; k < 44; ++k) state->sums[k] = sums[k];
   }
 }
 
-int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags, size_t first,
-                          size_t count, int64_t *sums_dev, bool fused_solve)
+static PointArgs make_point_args(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count)
 {
-  ws_context *ctx = r->ctx;
   size_t end = first + count;
   if (end > r->n) end = r->n;
   if (flags & WS_REG_COMPAT_REFERENCE_LAUNCH)
@@ -341,27 +511,28 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
     if (end > lim) end = lim;
   }
   if (first > end) first = end;
+  PointArgs p;
+  p.points = r->points;
+  p.first = (uint32_t)first;
+  p.end = (uint32_t)end;
+  p.map_data = m->data[WS_MAP_AVG];
+  p.map = m->par[WS_MAP_AVG];
+  p.resdiv = make_fastdiv(res);
+  return p;
+}
 
+int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags, size_t first,
+                          size_t count, int64_t *sums_dev)
+{
+  ws_context *ctx = r->ctx;
   AccArgs a;
-  a.points = r->points;
-  a.first = (uint32_t)first;
-  a.end = (uint32_t)end;
-  a.map_data = m->data[WS_MAP_AVG];
-  a.map = m->par[WS_MAP_AVG];
-  a.res = res;
-  a.T = T_dev_or_null ? T_dev_or_null : r->state->T;
-  a.state = T_dev_or_null ? nullptr : r->state;
+  a.pts = make_point_args(r, m, res, flags, first, count);
+  a.T = T_dev_or_null ? T_dev_or_null : r->state[0].core.T;
+  a.state = T_dev_or_null ? nullptr : &r->state[0];
   a.partials = r->partials;
-
-  FinishArgs f;
-  f.partials = r->partials;
-  f.sums_out = sums_dev;
-  f.state = T_dev_or_null ? nullptr : r->state;
-  f.solve = fused_solve ? 1 : 0;
-
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_accumulate_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
-  hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, f);
+  hipLaunchKernelGGL(reg_sum_kernel, dim3(1), dim3(REG_THREADS), 0, ctx->stream, (const int64_t *)r->partials, a.state, sums_dev);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;
@@ -369,11 +540,27 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
 
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev)
 {
-  hipLaunchKernelGGL(reg_solve_kernel, dim3(1), dim3(64), 0, r->ctx->stream, r->state, sums_dev);
+  hipLaunchKernelGGL(reg_solve_kernel, dim3(1), dim3(64), 0, r->ctx->stream, &r->state[0], sums_dev);
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
 
-size_t reg_partials_bytes() { return sizeof(int64_t) * REG_TERMS * REG_BLOCKS; }
+int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k)
+{
+  ws_context *ctx = r->ctx;
+  IterArgs a;
+  a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  a.state = r->state;
+  a.partials = r->partials;
+  a.k = k;
+  a.host_flag = r->host_flag_dev;
+  prof_begin(ctx, WS_K_REG);
+  hipLaunchKernelGGL(reg_iter_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  prof_end(ctx, WS_K_REG);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+size_t reg_partials_bytes() { return sizeof(int64_t) * 2 * REG_SLOTS * REG_BLOCKS; }
 
 } // namespace ws

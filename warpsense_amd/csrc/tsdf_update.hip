@@ -480,30 +480,30 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 grid_lists((m->contested_cap + 255) / 256);
   const bool s0 = !m->new_is_default;
 
-  prof_begin(ctx, WS_K_MARCH);
+  prof_begin(ctx, WS_K_MARCH_EMIT);
   if (s0)
     hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
   else
     hipLaunchKernelGGL((march_kernel<MARCH_EMIT, false>), grid_rays, block, 0, s, ma);
-  prof_end(ctx, WS_K_MARCH);
+  prof_end(ctx, WS_K_MARCH_EMIT);
 
   prof_begin(ctx, WS_K_RESOLVE);
   hipLaunchKernelGGL(resolve_kernel, grid_tiles, block, 0, s, ra);
   prof_end(ctx, WS_K_RESOLVE);
 
-  prof_begin(ctx, WS_K_MARCH);
+  prof_begin(ctx, WS_K_MARCH_COLLECT);
   if (s0)
     hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, true>), grid_rays, block, 0, s, ma);
   else
     hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, false>), grid_rays, block, 0, s, ma);
-  prof_end(ctx, WS_K_MARCH);
+  prof_end(ctx, WS_K_MARCH_COLLECT);
 
-  prof_begin(ctx, WS_K_RESOLVE);
+  prof_begin(ctx, WS_K_RESOLVE_LISTS);
   if (s0)
     hipLaunchKernelGGL((resolve_lists_kernel<true>), grid_lists, block, 0, s, ra);
   else
     hipLaunchKernelGGL((resolve_lists_kernel<false>), grid_lists, block, 0, s, ra);
-  prof_end(ctx, WS_K_RESOLVE);
+  prof_end(ctx, WS_K_RESOLVE_LISTS);
   WS_HIP(hipGetLastError());
   return WS_OK;
 }

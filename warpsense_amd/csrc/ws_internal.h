@@ -53,7 +53,7 @@ struct TsdfCounters // device-resident, zeroed at the start of every update
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
-struct GnState
+struct GnCore
 {
   float T[16];      // total_transform, column-major
   int32_t center[3];
@@ -65,6 +65,10 @@ struct GnState
   int32_t iterations;
   int32_t finished;
   int32_t pad;
+};
+struct GnState
+{
+  GnCore core;
   int64_t sums[44]; // last h(36) g(6) e c
 };
 
@@ -84,8 +88,8 @@ struct ws_context
   };
   std::vector<Span> spans;       // recorded, not yet resolved
   std::vector<hipEvent_t> pool;  // free events
-  double prof_ms[WS_K_COUNT] = {0, 0, 0, 0};
-  int64_t prof_n[WS_K_COUNT] = {0, 0, 0, 0};
+  double prof_ms[WS_K_COUNT] = {};
+  int64_t prof_n[WS_K_COUNT] = {};
 };
 
 struct ws_map
@@ -116,9 +120,12 @@ struct ws_reg
   ws_context *ctx = nullptr;
   int32_t *points = nullptr;
   size_t cap = 0, n = 0;
-  int64_t *partials = nullptr; // [29][REG_BLOCKS]
-  ws::GnState *state = nullptr;
-  ws::GnState *state_host = nullptr; // pinned
+  int64_t *partials = nullptr; // [2][32][REG_BLOCKS]
+  ws::GnState *state = nullptr;      // [2] device, double buffered by launch parity
+  ws::GnState *state_host = nullptr; // pinned staging
+  int32_t *host_flag = nullptr;      // pinned + mapped: the device sets it when the loop has finished
+  int32_t *host_flag_dev = nullptr;  // device view of host_flag
+  int latest = 0;                    // state buffer holding the newest state
   float *T_dev = nullptr;            // transform for ws_reg_iterate
   int64_t *sums_dev = nullptr;       // 44
 };
@@ -147,6 +154,7 @@ int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n);
 int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
 
 int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags,
-                          size_t first, size_t count, int64_t *sums_dev, bool fused_solve);
+                          size_t first, size_t count, int64_t *sums_dev);
+int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
 } // namespace ws
