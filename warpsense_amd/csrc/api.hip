@@ -166,8 +166,8 @@ static int map_free(ws_map *m)
 {
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->scan_dev,
-                  m->counters, m->contested_vox_lo, m->contested_vox_hi, m->heads, m->arena};
+  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->dirty_list, m->rays, m->scan_dev,
+                  m->counters, m->arena};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -197,7 +197,6 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   m->max_weight = max_weight;
   m->res = res;
   // contested-voxel capacity: generous fixed pools (usage is reported by ws_tsdf_stats)
-  m->contested_cap = 1u << 22; // 4 Mi voxels
   m->arena_cap = 1u << 24;     // 16 Mi records (256 MiB)
 
   hipStream_t s = ctx->stream;
@@ -219,11 +218,10 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->kpos, (size_t)m->n_vox * sizeof(uint64_t)));
   TRY(hipMalloc((void **)&m->kneg, (size_t)m->n_vox * sizeof(uint64_t)));
   TRY(hipMalloc((void **)&m->dirty, (size_t)m->n_tiles));
+  TRY(hipMalloc((void **)&m->dirty_list, (size_t)m->n_tiles * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * 48));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
-  TRY(hipMalloc((void **)&m->contested_vox_lo, (size_t)m->contested_cap * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->contested_vox_hi, (size_t)m->contested_cap * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->heads, (size_t)m->contested_cap * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
   TRY(hipMemsetAsync(m->kpos, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
@@ -373,7 +371,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
   out->contested_voxels = m->counters_host->contested;
   out->contested_records = m->counters_host->records;
-  out->dirty_tiles = m->counters_host->dirty_tiles;
+  out->dirty_tiles = m->counters_host->last_dirty_tiles;
   out->error_flags = (int32_t)m->counters_host->error;
   if (out->error_flags & 1)
   {

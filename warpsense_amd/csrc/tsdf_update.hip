@@ -21,10 +21,54 @@
 //
 // new_map after resolve* is bit-identical to what the reference kernel leaves there when its threads
 // run one after the other (oracle/ws_oracle.c: wso_update_min).
+#include <cstddef>
+
 #include "ws_device.h"
 
 namespace ws
 {
+
+// Per-ray constants of update_tsdf.cu:52-63, computed once by ray_setup_kernel.
+struct RaySetup // 48 bytes
+{
+  int32_t dx, dy, dz;    // direction_vector = point - pos (mm)
+  int32_t distance;      // (int)|direction_vector|
+  int32_t ivx, ivy, ivz; // interpolation_vector (unit length == MATRIX_RESOLUTION)
+  int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
+  uint64_t div_m;        // multiply-shift constants for the division by `distance`
+  int32_t div_k;
+  int32_t pad;
+};
+
+// exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
+struct FastDiv
+{
+  uint64_t M;
+  int32_t k;
+  int32_t d;
+};
+__host__ __device__ inline FastDiv make_fastdiv(int32_t d)
+{
+  FastDiv f;
+  f.d = d;
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  f.k = 31 + l;
+  const uint64_t p = 1ull << f.k; // k <= 62
+  f.M = p / (uint64_t)d + ((p % (uint64_t)d) ? 1 : 0);
+  return f;
+}
+// C-style truncating division of any int32 by the prepared positive divisor
+__device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, int32_t d)
+{
+  const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
+  uint32_t q;
+  if (ax == 0x80000000u)
+    q = ax / (uint32_t)d; // |INT_MIN| is outside the multiply-shift range
+  else
+    q = (uint32_t)(((uint64_t)ax * M) >> k); // ax < 2^31, M <= 2^32
+  return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
+}
 
 struct MarchArgs
 {
@@ -35,15 +79,55 @@ struct MarchArgs
   MapParams map; // new_map's parameters (the reference indexes new_map in the scatter, update_tsdf.cu:55-125)
   int32_t tau;
   int32_t res;
+  FastDiv resdiv;
+  RaySetup *rays;
   uint64_t *kpos;
   uint64_t *kneg;
   uint8_t *dirty;
   const uint32_t *new_data; // only read when HAS_S0
   TsdfCounters *counters;
-  uint32_t *heads;
   ContestedRecord *arena;
   uint32_t arena_cap;
+  int32_t collect_min_len; // COLLECT: steps below this length cannot reach a contested voxel
 };
+
+// Bump allocation for the lanes that reach this point together: one atomic per wave, not per lane.
+// (A single shared counter hit once per lane costs ~4 ns per hit on MI355X, i.e. milliseconds per pass.)
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter)
+{
+  const unsigned long long mask = __ballot(1);
+  const int lane = (int)(threadIdx.x & 63);
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Record allocation for the collect pass: every wave owns a chunk of the arena (cursor/end in LDS) and
+// only goes to the shared counter when the chunk is used up.
+constexpr uint32_t RECORD_CHUNK = 128;
+__device__ __forceinline__ uint32_t wave_alloc_chunked(uint32_t *counter, volatile uint32_t *cur, volatile uint32_t *end)
+{
+  const unsigned long long mask = __ballot(1);
+  const int lane = (int)(threadIdx.x & 63);
+  const int leader = __ffsll((long long)mask) - 1;
+  const uint32_t need = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if (lane == leader)
+  {
+    uint32_t c = *cur;
+    if (c + need > *end)
+    {
+      c = atomicAdd(counter, RECORD_CHUNK);
+      *end = c + RECORD_CHUNK;
+    }
+    *cur = c + need;
+    base = c;
+  }
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
 
 enum
 {
@@ -51,64 +135,136 @@ enum
   MARCH_COLLECT = 1
 };
 
-// One lane walks one ray (update_tsdf.cu:45-128).
-template <int MODE, bool HAS_S0>
-__global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
+// update_tsdf.cu:52-63 for one ray per lane
+__global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
 {
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix >= a.n) return;
-  if (MODE == MARCH_COLLECT)
-  {
-    if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-  }
-
-  const int32_t res = a.res, tau = a.tau;
-  const int32_t weight_epsilon = tau / 10;
-  const int32_t half = res / 2;
+  RaySetup r;
+  r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
+  r.div_m = 0;
+  r.div_k = 0;
+  r.pad = 0;
+  const int32_t res = a.res, tau = a.tau, half = res / 2;
   const int32_t px = a.xyz[3 * (size_t)ix + 0], py = a.xyz[3 * (size_t)ix + 1], pz = a.xyz[3 * (size_t)ix + 2];
-
-  // cu_to_map (cuda/util.h:111-114) + in_bounds_with_buffer_pos (update_tsdf.cu:55)
+  bool ok;
   {
+    // cu_to_map (cuda/util.h:111-114) + in_bounds_with_buffer_pos (update_tsdf.cu:55)
     const float fr = (float)res;
     const int32_t cx = (int32_t)floorf(__fdiv_rn((float)px, fr));
     const int32_t cy = (int32_t)floorf(__fdiv_rn((float)py, fr));
     const int32_t cz = (int32_t)floorf(__fdiv_rn((float)pz, fr));
-    if (!in_bounds_buffer(a.map, cx, cy, cz, (int64_t)(tau / res / 2))) return;
+    ok = in_bounds_buffer(a.map, cx, cy, cz, (int64_t)(tau / res / 2));
   }
+  if (ok)
+  {
+    // cu_to_mm (cuda/util.h:116-123)
+    const int32_t posx = wadd(wmul(a.scanner_pos[0], res), half);
+    const int32_t posy = wadd(wmul(a.scanner_pos[1], res), half);
+    const int32_t posz = wadd(wmul(a.scanner_pos[2], res), half);
+    const int32_t dx = wsub(px, posx), dy = wsub(py, posy), dz = wsub(pz, posz);
+    const int32_t distance = l2norm_i(dx, dy, dz);
+    // distance == 0: guard (the reference divides by zero here; src/cpu/update_tsdf.cpp:593 has the guard)
+    if (distance > 0)
+    {
+      // update_tsdf.cu:59-63, in int64 like the reference's `long`
+      const int64_t MR = MATRIX_RESOLUTION;
+      const int64_t ndx = wmul64(dx, MR) / distance, ndy = wmul64(dy, MR) / distance, ndz = wmul64(dz, MR) / distance;
+      const int64_t ux = a.up[0], uy = a.up[1], uz = a.up[2];
+      const int64_t c1x = wsub64(wmul64(ndy, uz), wmul64(ndz, uy)) / MR;
+      const int64_t c1y = wsub64(wmul64(ndz, ux), wmul64(ndx, uz)) / MR;
+      const int64_t c1z = wsub64(wmul64(ndx, uy), wmul64(ndy, ux)) / MR;
+      int64_t ivx = wsub64(wmul64(ndy, c1z), wmul64(ndz, c1y));
+      int64_t ivy = wsub64(wmul64(ndz, c1x), wmul64(ndx, c1z));
+      int64_t ivz = wsub64(wmul64(ndx, c1y), wmul64(ndy, c1x));
+      const int64_t inorm = l2norm_l(ivx, ivy, ivz);
+      if (inorm != 0) // guard (src/cpu/update_tsdf.cpp:602)
+      {
+        ivx = wmul64(ivx, MR) / inorm;
+        ivy = wmul64(ivy, MR) / inorm;
+        ivz = wmul64(ivz, MR) / inorm;
+        const int64_t len_end = (int64_t)distance + tau;
+        const int64_t steps = (len_end - 1) / half + 1;
+        const int64_t max_delta_z = (int64_t)DZ_PER_DISTANCE * len_end / MATRIX_RESOLUTION;
+        const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
+        if (steps > 65536 || (max_delta_z * 2) / res + 1 > 256 || !small_iv)
+        {
+          atomicOr(&a.counters->error, 2u); // outside the range of the order key
+        }
+        else
+        {
+          r.dx = dx; r.dy = dy; r.dz = dz;
+          r.distance = distance;
+          r.ivx = (int32_t)ivx; r.ivy = (int32_t)ivy; r.ivz = (int32_t)ivz;
+          r.steps = (int32_t)steps;
+          const FastDiv fd = make_fastdiv(distance);
+          r.div_m = fd.M;
+          r.div_k = fd.k;
+        }
+      }
+    }
+  }
+  a.rays[ix] = r;
+}
 
-  // cu_to_mm (cuda/util.h:116-123)
+// 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of its ray
+// (CH = ceil(steps/32)), so every lane has the same amount of work whatever the ray length, and a scan
+// of 131 072 rays puts 4 M lanes in flight instead of 131 072 (update_tsdf.cu:67-125 per step).
+template <int MODE, bool HAS_S0>
+__global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
+{
+  __shared__ uint32_t chunk_cur[4], chunk_end[4];
+  if (MODE == MARCH_COLLECT)
+  {
+    if (threadIdx.x < 4) chunk_cur[threadIdx.x] = chunk_end[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  if (MODE == MARCH_COLLECT)
+  {
+    if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  }
+  const uint32_t ix = blockIdx.x * 8u + (threadIdx.x >> 5);
+  if (ix >= a.n) return;
+  const RaySetup r = a.rays[ix];
+  if (r.steps == 0) return;
+  const int32_t c = threadIdx.x & 31;
+  const int32_t res = a.res, tau = a.tau;
+  const int32_t weight_epsilon = tau / 10;
+  const int32_t half = res / 2;
+  // COLLECT only needs the steps with len = 1 + k*half >= collect_min_len
+  int32_t kbeg = 0;
+  if (MODE == MARCH_COLLECT && a.collect_min_len > 1) kbeg = (a.collect_min_len - 1 + half - 1) / half;
+  if (kbeg >= r.steps) return;
+  const int32_t ch = (r.steps - kbeg + 31) >> 5;
+  const int32_t k0 = kbeg + c * ch;
+  const int32_t k1 = min(k0 + ch, r.steps);
+  if (k0 >= k1) return;
+
   const int32_t posx = wadd(wmul(a.scanner_pos[0], res), half);
   const int32_t posy = wadd(wmul(a.scanner_pos[1], res), half);
   const int32_t posz = wadd(wmul(a.scanner_pos[2], res), half);
-  const int32_t dx = wsub(px, posx), dy = wsub(py, posy), dz = wsub(pz, posz);
-  const int32_t distance = l2norm_i(dx, dy, dz);
-  if (distance == 0) return; // guard (the reference divides by zero here; src/cpu/update_tsdf.cpp:593 has the guard)
-
-  // update_tsdf.cu:59-63, in int64 like the reference's `long`
+  const int32_t px = wadd(posx, r.dx), py = wadd(posy, r.dy), pz = wadd(posz, r.dz);
   const int64_t MR = MATRIX_RESOLUTION;
-  const int64_t ndx = wmul64(dx, MR) / distance, ndy = wmul64(dy, MR) / distance, ndz = wmul64(dz, MR) / distance;
-  const int64_t ux = a.up[0], uy = a.up[1], uz = a.up[2];
-  const int64_t c1x = wsub64(wmul64(ndy, uz), wmul64(ndz, uy)) / MR;
-  const int64_t c1y = wsub64(wmul64(ndz, ux), wmul64(ndx, uz)) / MR;
-  const int64_t c1z = wsub64(wmul64(ndx, uy), wmul64(ndy, ux)) / MR;
-  int64_t ivx = wsub64(wmul64(ndy, c1z), wmul64(ndz, c1y));
-  int64_t ivy = wsub64(wmul64(ndz, c1x), wmul64(ndx, c1z));
-  int64_t ivz = wsub64(wmul64(ndx, c1y), wmul64(ndy, c1x));
-  const int64_t inorm = l2norm_l(ivx, ivy, ivz);
-  if (inorm == 0) return; // guard (src/cpu/update_tsdf.cpp:602)
-  ivx = wmul64(ivx, MR) / inorm;
-  ivy = wmul64(ivy, MR) / inorm;
-  ivz = wmul64(ivz, MR) / inorm;
+  const int64_t ivx = r.ivx, ivy = r.ivy, ivz = r.ivz;
+  const uint64_t rM = a.resdiv.M;
+  const int32_t rK = a.resdiv.k;
 
-  int32_t prevx = 0, prevy = 0; // update_tsdf.cu:65 (z of prev is never compared)
-  uint32_t iter = 0;
-  const int32_t len_end = distance + tau;
-  for (int32_t len = 1; len <= len_end; len += half, ++iter)
+  // `prev` of update_tsdf.cu:65-76 is always the (x, y) index of the previous step (or (0,0) before the first)
+  int32_t prevx = 0, prevy = 0;
+  if (k0 > 0)
   {
-    const int32_t projx = wadd(posx, wmul(dx, len) / distance);
-    const int32_t projy = wadd(posy, wmul(dy, len) / distance);
-    const int32_t projz = wadd(posz, wmul(dz, len) / distance);
-    const int32_t ixx = projx / res, iyy = projy / res, izz = projz / res;
+    const int32_t len = 1 + (k0 - 1) * half;
+    prevx = div_trunc(wadd(posx, div_trunc(wmul(r.dx, len), r.div_m, r.div_k, r.distance)), rM, rK, res);
+    prevy = div_trunc(wadd(posy, div_trunc(wmul(r.dy, len), r.div_m, r.div_k, r.distance)), rM, rK, res);
+  }
+
+  for (int32_t k = k0; k < k1; ++k)
+  {
+    const int32_t len = 1 + k * half;
+    const int32_t projx = wadd(posx, div_trunc(wmul(r.dx, len), r.div_m, r.div_k, r.distance));
+    const int32_t projy = wadd(posy, div_trunc(wmul(r.dy, len), r.div_m, r.div_k, r.distance));
+    const int32_t projz = wadd(posz, div_trunc(wmul(r.dz, len), r.div_m, r.div_k, r.distance));
+    const int32_t ixx = div_trunc(projx, rM, rK, res), iyy = div_trunc(projy, rM, rK, res), izz = div_trunc(projz, rM, rK, res);
     if (ixx == prevx && iyy == prevy) continue;
     prevx = ixx;
     prevy = iyy;
@@ -118,7 +274,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
     const int32_t tcx = wadd(wmul(ixx, res), half), tcy = wadd(wmul(iyy, res), half), tcz = wadd(wmul(izz, res), half);
     int32_t value = l2norm_i(wsub(px, tcx), wsub(py, tcy), wsub(pz, tcz));
     value = value < tau ? value : tau;
-    if (len > distance) value = -value;
+    if (len > r.distance) value = -value;
     const int32_t weight = tsdf_weight(value, tau, weight_epsilon);
     if (weight == 0) continue;
     const uint32_t absval = (uint32_t)(value < 0 ? -value : value) & 0x7fffu;
@@ -130,22 +286,17 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
     const int32_t lowx = wsub(projx, (int32_t)(wmul64(delta_z, ivx) / MR));
     const int32_t lowy = wsub(projy, (int32_t)(wmul64(delta_z, ivy) / MR));
     const int32_t lowz = wsub(projz, (int32_t)(wmul64(delta_z, ivz) / MR));
-    if (iter > 0xffffu || iter_steps > 256)
-    {
-      atomicOr(&a.counters->error, 2u);
-      return;
-    }
 
     for (int32_t step = 0; step < iter_steps; ++step)
     {
       const int64_t sm = (int64_t)wmul(step, res);
-      const int32_t vx = wadd(lowx, (int32_t)(wmul64(sm, ivx) / MR)) / res;
-      const int32_t vy = wadd(lowy, (int32_t)(wmul64(sm, ivy) / MR)) / res;
-      const int32_t vz = wadd(lowz, (int32_t)(wmul64(sm, ivz) / MR)) / res;
+      const int32_t vx = div_trunc(wadd(lowx, (int32_t)(wmul64(sm, ivx) / MR)), rM, rK, res);
+      const int32_t vy = div_trunc(wadd(lowy, (int32_t)(wmul64(sm, ivy) / MR)), rM, rK, res);
+      const int32_t vz = div_trunc(wadd(lowz, (int32_t)(wmul64(sm, ivz) / MR)), rM, rK, res);
       if (!in_bounds(a.map, vx, vy, vz)) continue;
       const int64_t idx = get_index(a.map, vx, vy, vz);
       const bool positive = (step == mid);
-      const uint64_t t = ((uint64_t)ix << 24) | ((uint64_t)iter << 8) | (uint64_t)step;
+      const uint64_t t = ((uint64_t)ix << 24) | ((uint64_t)(uint32_t)k << 8) | (uint64_t)step;
 
       if (HAS_S0)
       {
@@ -158,6 +309,9 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
 
       if (MODE == MARCH_EMIT)
       {
+        // touched-tile flag: a plain byte store (every writer stores the same value); the list of
+        // touched tiles is compacted from the flags afterwards — a shared append counter here would
+        // serialise the whole march (measured: 2.3 ms for 381 k appends)
         const int64_t tile = idx >> TILE_SHIFT;
         if (a.dirty[tile] == 0) a.dirty[tile] = 1;
         if (positive)
@@ -173,18 +327,18 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
       }
       else
       {
-        const uint64_t k = a.kpos[idx];
-        if ((k >> 60) == 0xCull)
+        if (a.kpos[idx] == KEY_CONTESTED_TAG)
         {
-          const uint32_t slot = (uint32_t)(k & 0xffffffffull);
-          const uint32_t rec = atomicAdd(&a.counters->records, 1u);
+          const int w = (int)(threadIdx.x >> 6);
+          const uint32_t rec = wave_alloc_chunked(&a.counters->records, &chunk_cur[w], &chunk_end[w]);
           if (rec < a.arena_cap)
           {
-            ContestedRecord r;
-            r.key = (t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu);
-            r.next = atomicExch(&a.heads[slot], rec);
-            r.pad = 0;
-            a.arena[rec] = r;
+            ContestedRecord cr;
+            cr.key = (t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu);
+            // the list head of a contested voxel lives in the low half of its (now unused) kneg word
+            cr.next = atomicExch(reinterpret_cast<uint32_t *>(&a.kneg[idx]), rec);
+            cr.pad = 0;
+            a.arena[rec] = cr;
           }
           else
           {
@@ -200,36 +354,42 @@ struct ResolveArgs
 {
   uint64_t *kpos;
   uint64_t *kneg;
-  uint8_t *dirty;
+  const uint32_t *dirty_list;
   uint32_t *new_data;
   int64_t n_vox;
-  int64_t n_tiles;
   int32_t tau;
   TsdfCounters *counters;
-  uint32_t *contested_lo;
-  uint32_t *contested_hi;
-  uint32_t *heads;
-  uint32_t contested_cap;
   const ContestedRecord *arena;
   uint32_t arena_cap;
 };
 
-// One wave scans 64 tile flags, then walks its dirty tiles with one lane per voxel.
+// touched-tile flags -> list of tile ids (order irrelevant); clears the flags it consumes
+__global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int64_t n_tiles, uint32_t *list, TsdfCounters *counters)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ((n_tiles + 63) & ~63ll); i += stride)
+  {
+    const bool flag = i < n_tiles && dirty[i] != 0;
+    if (flag)
+    {
+      dirty[i] = 0;
+      list[wave_alloc(&counters->dirty_tiles)] = (uint32_t)i;
+    }
+  }
+}
+
+constexpr int LIST_GRID_BLOCKS = 2048; // persistent grid over the touched-tile list: 8192 waves
+
+// One wave per touched 64-voxel tile (one lane per voxel), waves stride over the tile list.
 __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
 {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t tile0 = wave * 64;
-  if (tile0 >= a.n_tiles) return;
+  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int32_t weight_epsilon = a.tau / 10;
-  const int64_t my_tile = tile0 + lane;
-  const bool flag = my_tile < a.n_tiles && a.dirty[my_tile] != 0;
-  unsigned long long mask = __ballot(flag);
-  while (mask)
+  int n_contested = 0;
+  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
   {
-    const int b = __ffsll((long long)mask) - 1;
-    mask &= mask - 1;
-    const int64_t idx = ((tile0 + b) << TILE_SHIFT) + lane;
+    const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
     if (idx >= a.n_vox) continue;
     const uint64_t kp = a.kpos[idx], kn = a.kneg[idx];
     if (kp == KEY_INF && kn == KEY_INF) continue; // untouched voxel: new_map keeps its entry
@@ -238,6 +398,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
     bool positive = false;
     if (kp != KEY_INF)
     {
+      if (kp == KEY_CONTESTED_TAG) continue; // already handed to the ordered fallback
       value = (int32_t)(int16_t)(kp & 0xffffu);
       positive = true;
       if (kn != KEY_INF)
@@ -255,106 +416,94 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
     }
     if (decided)
     {
-      int32_t w = tsdf_weight(value, a.tau, weight_epsilon);
+      const int32_t w = tsdf_weight(value, a.tau, weight_epsilon);
       a.new_data[idx] = pack_entry(value, positive ? w : -w);
       a.kpos[idx] = KEY_INF;
       if (kn != KEY_INF) a.kneg[idx] = KEY_INF;
     }
     else
     {
-      const uint32_t slot = atomicAdd(&a.counters->contested, 1u);
-      if (slot < a.contested_cap)
-      {
-        a.contested_lo[slot] = (uint32_t)((uint64_t)idx & 0xffffffffull);
-        a.contested_hi[slot] = (uint32_t)((uint64_t)idx >> 32);
-        a.heads[slot] = 0xffffffffu;
-        a.kpos[idx] = KEY_CONTESTED_TAG | slot;
-        a.kneg[idx] = KEY_INF;
-      }
-      else
-      {
-        atomicOr(&a.counters->error, 1u);
-        a.kpos[idx] = KEY_INF;
-        a.kneg[idx] = KEY_INF;
-      }
+      // contested: tag the voxel; its kneg word becomes the (empty) head of the candidate list
+      a.kpos[idx] = KEY_CONTESTED_TAG;
+      a.kneg[idx] = 0xffffffffull;
+      n_contested += 1;
     }
   }
+  // one counter update per wave for the whole pass (a per-voxel atomic on one address costs milliseconds)
+  for (int d = 32; d > 0; d >>= 1) n_contested += __shfl_down(n_contested, d, 64);
+  if (lane == 0 && n_contested) atomicAdd(&a.counters->contested, (uint32_t)n_contested);
 }
 
-// One lane per contested voxel: fold its candidates in ascending key order with the accept rule of
-// atomic_tsdf_min (cuda/util.h:70-102): accept iff stored weight <= 0 and |new| <= |stored|.
+// Ordered fallback: walk the touched tiles again, one lane per voxel; a lane whose voxel is tagged folds
+// that voxel's candidate list in ascending key order with the accept rule of atomic_tsdf_min
+// (cuda/util.h:70-102): accept iff stored weight <= 0 and |new| <= |stored|.
 template <bool HAS_S0>
 __global__ __launch_bounds__(256) void resolve_lists_kernel(ResolveArgs a)
 {
-  const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-  uint32_t n = __hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (n > a.contested_cap) n = a.contested_cap;
-  if (slot >= n) return;
-  const int64_t idx = (int64_t)(((uint64_t)a.contested_hi[slot] << 32) | a.contested_lo[slot]);
+  if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int32_t weight_epsilon = a.tau / 10;
-  uint32_t state = HAS_S0 ? a.new_data[idx] : pack_entry(a.tau, 0);
-  int32_t sv = entry_value(state), sw = entry_weight(state);
-  int32_t sa = sv < 0 ? -sv : sv;
-  const uint32_t head = a.heads[slot];
-  uint64_t last = 0;
-  bool first = true;
-  while (sw <= 0)
+  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
   {
-    // next record in key order (lists are short: a handful of rays reach a far voxel)
-    uint64_t best = KEY_INF;
-    for (uint32_t r = head; r != 0xffffffffu && r < a.arena_cap; r = a.arena[r].next)
+    const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
+    if (idx >= a.n_vox) continue;
+    if (a.kpos[idx] != KEY_CONTESTED_TAG) continue;
+    const uint32_t head = (uint32_t)(a.kneg[idx] & 0xffffffffull);
+    const uint32_t state = HAS_S0 ? a.new_data[idx] : pack_entry(a.tau, 0);
+    int32_t sv = entry_value(state), sw = entry_weight(state);
+    int32_t sa = sv < 0 ? -sv : sv;
+    uint64_t last = 0;
+    bool first = true;
+    while (sw <= 0)
     {
-      const uint64_t k = a.arena[r].key;
-      if ((first || k > last) && k < best) best = k;
+      // next record in key order (lists are short: a handful of rays reach a far voxel)
+      uint64_t best = KEY_INF;
+      for (uint32_t r = head; r != 0xffffffffu && r < a.arena_cap; r = a.arena[r].next)
+      {
+        const uint64_t k = a.arena[r].key;
+        if ((first || k > last) && k < best) best = k;
+      }
+      if (best == KEY_INF) break;
+      first = false;
+      last = best;
+      const int32_t v = (int32_t)(int16_t)(best & 0xffffu);
+      const int32_t av = v < 0 ? -v : v;
+      if (av <= sa)
+      {
+        const int32_t w = tsdf_weight(v, a.tau, weight_epsilon);
+        sv = v;
+        sa = av;
+        sw = (best & (1ull << 16)) ? -w : w;
+      }
     }
-    if (best == KEY_INF) break;
-    first = false;
-    last = best;
-    const int32_t v = (int32_t)(int16_t)(best & 0xffffu);
-    const int32_t av = v < 0 ? -v : v;
-    if (av <= sa)
-    {
-      const int32_t w = tsdf_weight(v, a.tau, weight_epsilon);
-      sv = v;
-      sa = av;
-      sw = (best & (1ull << 16)) ? -w : w;
-    }
+    a.new_data[idx] = pack_entry(sv, sw);
+    a.kpos[idx] = KEY_INF;
+    a.kneg[idx] = KEY_INF;
   }
-  a.new_data[idx] = pack_entry(sv, sw);
-  a.kpos[idx] = KEY_INF;
 }
 
 struct IntegrateArgs
 {
   uint32_t *new_data;
   uint32_t *avg_data;
-  uint8_t *dirty;
+  const uint32_t *dirty_list;
   int64_t n_vox;
-  int64_t n_tiles;
   int32_t max_weight;
   int32_t tau;
   TsdfCounters *counters;
 };
 
-// cu_avg_tsdf_krnl (update_tsdf.cu:13-43) over the touched tiles only.
+// cu_avg_tsdf_krnl (update_tsdf.cu:13-43) over the touched tiles only: one wave per tile.
 __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t tile0 = wave * 64;
-  if (tile0 >= a.n_tiles) return;
-  const int64_t my_tile = tile0 + lane;
-  const bool flag = my_tile < a.n_tiles && a.dirty[my_tile] != 0;
-  unsigned long long mask = __ballot(flag);
-  if (mask == 0) return;
-  if (flag) a.dirty[my_tile] = 0;
-  if (lane == 0) atomicAdd(&a.counters->dirty_tiles, (uint32_t)__popcll(mask));
+  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t reset = pack_entry(a.tau, 0);
-  while (mask)
+  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
   {
-    const int b = __ffsll((long long)mask) - 1;
-    mask &= mask - 1;
-    const int64_t idx = ((tile0 + b) << TILE_SHIFT) + lane;
+    const uint32_t tile = a.dirty_list[i];
+    const int64_t idx = ((int64_t)tile << TILE_SHIFT) + lane;
     if (idx >= a.n_vox) continue;
     const uint32_t fresh = a.new_data[idx];
     if (fresh == reset) continue;
@@ -363,6 +512,13 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
     if (updated != existing) a.avg_data[idx] = updated;
     a.new_data[idx] = reset;
   }
+}
+
+// bookkeeping after an integrate pass: remember how many tiles were streamed, restart the list
+__global__ void finish_update_kernel(TsdfCounters *c)
+{
+  c->last_dirty_tiles = c->dirty_tiles;
+  c->dirty_tiles = 0;
 }
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
@@ -393,12 +549,6 @@ __global__ __launch_bounds__(256) void integrate_dense_kernel(IntegrateArgs a)
     a.avg_data[i] = integrate_entry(a.avg_data[i], a.new_data[i], a.max_weight);
     a.new_data[i] = reset;
   }
-}
-
-__global__ __launch_bounds__(256) void clear_dirty_kernel(uint8_t *dirty, int64_t n_tiles)
-{
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tiles; i += stride) dirty[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *dst, uint32_t v, int64_t n)
@@ -435,7 +585,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
-  WS_HIP(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
+  // per-scatter counters (the touched-tile list survives until the integrate pass consumes it)
+  WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, dirty_tiles), s));
   if (n == 0) return WS_OK;
 
   MarchArgs ma;
@@ -449,38 +600,45 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.map = m->par[WS_MAP_NEW];
   ma.tau = m->tau;
   ma.res = m->res;
+  ma.resdiv = make_fastdiv(m->res);
+  ma.rays = (RaySetup *)m->rays;
   ma.kpos = m->kpos;
   ma.kneg = m->kneg;
   ma.dirty = m->dirty;
   ma.new_data = m->data[WS_MAP_NEW];
   ma.counters = m->counters;
-  ma.heads = m->heads;
   ma.arena = m->arena;
   ma.arena_cap = m->arena_cap;
+  {
+    // Negative-weight (off-ray) candidates only exist where iter_steps >= 2, i.e. delta_z*2 >= res
+    // (update_tsdf.cu:101-102): len >= ceil(ceil(res/2) * 32768 / 100).  A contested voxel holds such a
+    // candidate, and every other candidate of the same voxel has a ray length within one voxel
+    // diagonal + fan of it, so the collect pass can start 4 voxels below that length.
+    const int64_t dz_min = (m->res + 1) / 2;
+    const int64_t len_neg = (dz_min * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
+    const int64_t lo = len_neg - 4 * (int64_t)m->res - 2 * dz_min;
+    ma.collect_min_len = lo > 1 ? (int32_t)(lo > INT32_MAX ? INT32_MAX : lo) : 1;
+  }
 
   ResolveArgs ra;
   ra.kpos = m->kpos;
   ra.kneg = m->kneg;
-  ra.dirty = m->dirty;
+  ra.dirty_list = m->dirty_list;
   ra.new_data = m->data[WS_MAP_NEW];
   ra.n_vox = m->n_vox;
-  ra.n_tiles = m->n_tiles;
   ra.tau = m->tau;
   ra.counters = m->counters;
-  ra.contested_lo = m->contested_vox_lo;
-  ra.contested_hi = m->contested_vox_hi;
-  ra.heads = m->heads;
-  ra.contested_cap = m->contested_cap;
   ra.arena = m->arena;
   ra.arena_cap = m->arena_cap;
 
   const dim3 block(256);
-  const dim3 grid_rays((unsigned)((n + 255) / 256));
-  const dim3 grid_tiles((unsigned)((m->n_tiles + 64 * 4 - 1) / (64 * 4)));
-  const dim3 grid_lists((m->contested_cap + 255) / 256);
+  const dim3 grid_setup((unsigned)((n + 255) / 256));
+  const dim3 grid_rays((unsigned)((n + 7) / 8));
+  const dim3 grid_list(LIST_GRID_BLOCKS);
   const bool s0 = !m->new_is_default;
 
   prof_begin(ctx, WS_K_MARCH_EMIT);
+  hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, ma);
   if (s0)
     hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
   else
@@ -488,7 +646,12 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   prof_end(ctx, WS_K_MARCH_EMIT);
 
   prof_begin(ctx, WS_K_RESOLVE);
-  hipLaunchKernelGGL(resolve_kernel, grid_tiles, block, 0, s, ra);
+  {
+    int64_t cb = (m->n_tiles + 255) / 256;
+    if (cb > 2048) cb = 2048;
+    hipLaunchKernelGGL(compact_dirty_kernel, dim3((unsigned)cb), block, 0, s, m->dirty, m->n_tiles, m->dirty_list, m->counters);
+  }
+  hipLaunchKernelGGL(resolve_kernel, grid_list, block, 0, s, ra);
   prof_end(ctx, WS_K_RESOLVE);
 
   prof_begin(ctx, WS_K_MARCH_COLLECT);
@@ -500,9 +663,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   prof_begin(ctx, WS_K_RESOLVE_LISTS);
   if (s0)
-    hipLaunchKernelGGL((resolve_lists_kernel<true>), grid_lists, block, 0, s, ra);
+    hipLaunchKernelGGL((resolve_lists_kernel<true>), grid_list, block, 0, s, ra);
   else
-    hipLaunchKernelGGL((resolve_lists_kernel<false>), grid_lists, block, 0, s, ra);
+    hipLaunchKernelGGL((resolve_lists_kernel<false>), grid_list, block, 0, s, ra);
   prof_end(ctx, WS_K_RESOLVE_LISTS);
   WS_HIP(hipGetLastError());
   return WS_OK;
@@ -515,9 +678,8 @@ int launch_tsdf_integrate(ws_map *m)
   IntegrateArgs ia;
   ia.new_data = m->data[WS_MAP_NEW];
   ia.avg_data = m->data[WS_MAP_AVG];
-  ia.dirty = m->dirty;
+  ia.dirty_list = m->dirty_list;
   ia.n_vox = m->n_vox;
-  ia.n_tiles = m->n_tiles;
   ia.max_weight = m->max_weight;
   ia.tau = m->tau;
   ia.counters = m->counters;
@@ -531,15 +693,13 @@ int launch_tsdf_integrate(ws_map *m)
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(integrate_dense_kernel, dim3((unsigned)blocks), block, 0, s, ia);
-    hipLaunchKernelGGL(clear_dirty_kernel, dim3((unsigned)((m->n_tiles + 255) / 256 > 2048 ? 2048 : (m->n_tiles + 255) / 256)),
-                       block, 0, s, m->dirty, m->n_tiles);
   }
   else
   {
-    const dim3 grid_tiles((unsigned)((m->n_tiles + 64 * 4 - 1) / (64 * 4)));
-    hipLaunchKernelGGL(integrate_sparse_kernel, grid_tiles, block, 0, s, ia);
+    hipLaunchKernelGGL(integrate_sparse_kernel, dim3(LIST_GRID_BLOCKS), block, 0, s, ia);
   }
   prof_end(ctx, WS_K_INTEGRATE);
+  hipLaunchKernelGGL(finish_update_kernel, dim3(1), dim3(1), 0, s, m->counters);
   WS_HIP(hipGetLastError());
   m->new_is_default = true;
   return WS_OK;

@@ -19,7 +19,7 @@ constexpr size_t MAX_SCAN_POINTS = 1000000; // update_tsdf.h:33
 
 constexpr int TILE_SHIFT = 6; // dirty-tile granularity: 64 consecutive voxels (256 B of a map)
 constexpr uint64_t KEY_INF = ~0ull;
-constexpr uint64_t KEY_CONTESTED_TAG = 0xCull << 60;
+constexpr uint64_t KEY_CONTESTED_TAG = 0xCull << 60; // kpos of a voxel handed to the ordered fallback (never a valid key: t < 2^44)
 
 // ring-buffer parameters passed BY VALUE to kernels (the reference chases three device pointers per
 // access, device_map.h:93-101)
@@ -49,7 +49,9 @@ struct TsdfCounters // device-resident, zeroed at the start of every update
   uint32_t contested;  // number of contested voxels
   uint32_t records;    // arena records used
   uint32_t error;      // bit0 arena/list overflow, bit1 key range
-  uint32_t dirty_tiles;
+  uint32_t dirty_tiles;      // length of the touched-tile list (survives until the integrate pass)
+  uint32_t last_dirty_tiles; // tiles the last integrate pass streamed
+  uint32_t pad[3];
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -100,18 +102,17 @@ struct ws_map
   int64_t n_tiles = 0;
   uint32_t *data[2] = {nullptr, nullptr};
   uint64_t *kpos = nullptr, *kneg = nullptr;
-  uint8_t *dirty = nullptr;
+  uint8_t *dirty = nullptr;       // one flag per 64-voxel tile
+  uint32_t *dirty_list = nullptr; // touched tiles of the scan in flight
+  void *rays = nullptr;           // per-ray set-up records (48 B x 1 000 000)
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
   int integrate_mode = WS_INTEGRATE_SPARSE;
   int32_t *scan_dev = nullptr; // 1 000 000-point upload buffer
   // contested-voxel machinery
   ws::TsdfCounters *counters = nullptr;
-  uint32_t *contested_vox_lo = nullptr; // linear voxel index (low 32 bits)
-  uint32_t *contested_vox_hi = nullptr; // high bits (2049^3 maps)
-  uint32_t *heads = nullptr;
   ws::ContestedRecord *arena = nullptr;
-  uint32_t contested_cap = 0, arena_cap = 0;
+  uint32_t arena_cap = 0;
   ws::TsdfCounters *counters_host = nullptr; // pinned
 };
 
