@@ -41,6 +41,16 @@ static inline int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
   return (int64_t)sqrtf((float)sq);
 }
 
+int32_t wso_l2norm_i(int32_t x, int32_t y, int32_t z) { return l2norm_i(x, y, z); }
+int64_t wso_l2norm_l(int64_t x, int64_t y, int64_t z) { return l2norm_l(x, y, z); }
+/* Vector3<int>::cross, math/vector3.h:269-277 */
+void wso_cross_i(const int32_t a[3], const int32_t b[3], int32_t out[3])
+{
+  out[0] = wsub(wmul(a[1], b[2]), wmul(a[2], b[1]));
+  out[1] = wsub(wmul(a[2], b[0]), wmul(a[0], b[2]));
+  out[2] = wsub(wmul(a[0], b[1]), wmul(a[1], b[0]));
+}
+
 /* ---------- TSDFEntry (include/map/tsdf.h:16-23,32-46) ---------- */
 uint32_t wso_pack(int16_t value, int16_t weight)
 {
@@ -160,6 +170,30 @@ int wso_tsdf_min(uint32_t *addr, uint32_t new_raw)
   return 1;
 }
 
+/* update_tsdf.cu:57-63: distance and the unit interpolation vector of one ray, all in `long` like the reference.
+ * returns -1 for distance == 0, -2 for interpolation_norm == 0 (the reference divides by zero there) */
+int wso_ray_setup(const int32_t point[3], const int32_t pos[3], const int32_t up[3], int32_t *distance_out, int64_t iv[3])
+{
+  const int64_t MR = WSO_MATRIX_RESOLUTION;
+  int32_t dir[3] = {wsub(point[0], pos[0]), wsub(point[1], pos[1]), wsub(point[2], pos[2])};
+  int32_t distance = l2norm_i(dir[0], dir[1], dir[2]); /* :58 */
+  *distance_out = distance;
+  if (distance == 0) return -1;
+  int64_t nd[3], c1[3];
+  for (int k = 0; k < 3; ++k) nd[k] = wmul64((int64_t)dir[k], MR) / distance;
+  int64_t u[3] = {up[0], up[1], up[2]};
+  c1[0] = wsub64(wmul64(nd[1], u[2]), wmul64(nd[2], u[1])) / MR;
+  c1[1] = wsub64(wmul64(nd[2], u[0]), wmul64(nd[0], u[2])) / MR;
+  c1[2] = wsub64(wmul64(nd[0], u[1]), wmul64(nd[1], u[0])) / MR;
+  iv[0] = wsub64(wmul64(nd[1], c1[2]), wmul64(nd[2], c1[1]));
+  iv[1] = wsub64(wmul64(nd[2], c1[0]), wmul64(nd[0], c1[2]));
+  iv[2] = wsub64(wmul64(nd[0], c1[1]), wmul64(nd[1], c1[0]));
+  int64_t inorm = l2norm_l(iv[0], iv[1], iv[2]);
+  if (inorm == 0) return -2;
+  for (int k = 0; k < 3; ++k) iv[k] = wmul64(iv[k], MR) / inorm;
+  return 0;
+}
+
 /* ---------- cu_min_tsdf_krnl, update_tsdf.cu:45-128, one "thread" after the other ---------- */
 void wso_update_min(wso_map *new_map, const int32_t *xyz, size_t n, const int32_t scanner_pos[3],
                     const int32_t up[3], int32_t tau, int32_t res, wso_update_stats *stats)
@@ -181,22 +215,9 @@ void wso_update_min(wso_map *new_map, const int32_t *xyz, size_t n, const int32_
     st.rays_in_bounds++;
 
     int32_t dir[3] = {wsub(point[0], pos[0]), wsub(point[1], pos[1]), wsub(point[2], pos[2])};
-    int32_t distance = l2norm_i(dir[0], dir[1], dir[2]); /* :58 */
-    if (distance == 0) { st.rays_degenerate++; continue; } /* guard, see header */
-
-    /* :59-62, all in long */
-    int64_t nd[3], c1[3], iv[3];
-    for (int k = 0; k < 3; ++k) nd[k] = wmul64((int64_t)dir[k], MR) / distance;
-    int64_t u[3] = {up[0], up[1], up[2]};
-    c1[0] = wsub64(wmul64(nd[1], u[2]), wmul64(nd[2], u[1])) / MR;
-    c1[1] = wsub64(wmul64(nd[2], u[0]), wmul64(nd[0], u[2])) / MR;
-    c1[2] = wsub64(wmul64(nd[0], u[1]), wmul64(nd[1], u[0])) / MR;
-    iv[0] = wsub64(wmul64(nd[1], c1[2]), wmul64(nd[2], c1[1]));
-    iv[1] = wsub64(wmul64(nd[2], c1[0]), wmul64(nd[0], c1[2]));
-    iv[2] = wsub64(wmul64(nd[0], c1[1]), wmul64(nd[1], c1[0]));
-    int64_t inorm = l2norm_l(iv[0], iv[1], iv[2]);
-    if (inorm == 0) { st.rays_degenerate++; continue; } /* guard, see header */
-    for (int k = 0; k < 3; ++k) iv[k] = wmul64(iv[k], MR) / inorm;
+    int32_t distance;
+    int64_t iv[3];
+    if (wso_ray_setup(point, pos, up, &distance, iv) != 0) { st.rays_degenerate++; continue; } /* guards, see header */
 
     int32_t prev[3] = {0, 0, 0}; /* :65 */
     for (int32_t len = 1; len <= distance + tau; len += res / 2) /* :67 */
@@ -464,51 +485,63 @@ static void matmul4f(const float A[16], const float B[16], float C[16])
 }
 
 /* ---------- TSDFRegistration::register_cloud, tsdf_registration.cpp:28-96 ---------- */
+/* state set-up of :30-52 */
+void wso_gn_begin(wso_gn_state *st, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon)
+{
+  memset(st, 0, sizeof *st);
+  memcpy(st->T, T_in, 16 * sizeof(float));
+  for (int k = 0; k < 3; ++k) st->center[k] = (int32_t)T_in[12 + k]; /* :33 */
+  st->alpha = 0.f;
+  st->it_weight_gradient = it_weight_gradient;
+  st->epsilon = epsilon;
+  st->max_iterations = max_iterations;
+}
+
+/* one pass through the loop body after perform_registration returned h,g,e,c (:63-92); sums = h[36] g[6] e c */
+void wso_gn_update(wso_gn_state *st, const int64_t sums[44])
+{
+  if (st->finished || st->iterations >= st->max_iterations) return;
+  const int32_t e = (int32_t)sums[42], c = (int32_t)sums[43];
+  st->iterations += 1;
+  if (c == 0) { st->finished = 1; return; } /* guard, see header */
+
+  double hf[36], gf[6], xi[6];
+  double w = (double)(st->alpha * (float)c); /* alpha * gpu_c is a float product, :66 */
+  for (int r = 0; r < 6; ++r)
+  {
+    gf[r] = (double)sums[36 + r];
+    for (int q = 0; q < 6; ++q) hf[r * 6 + q] = (double)sums[q * 6 + r] + (r == q ? w : 0.0);
+  }
+  if (wso_solve6(hf, gf, xi) != 0) { st->finished = 1; return; }
+  for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
+
+  float tr[16];
+  wso_xi_to_transform(xi, st->center, tr);
+  st->alpha += st->it_weight_gradient;
+  matmul4f(tr, st->T, st->T);
+
+  float err = (float)e / c;
+  if (fabsf(err - st->prev[2]) < st->epsilon && fabsf(err - st->prev[0]) < st->epsilon) st->finished = 1;
+  st->prev[0] = st->prev[1]; st->prev[1] = st->prev[2]; st->prev[2] = st->prev[3];
+  st->prev[3] = err;
+}
+
 int wso_register_cloud(const wso_map *map, const int32_t *xyz, size_t n, const float T_in[16],
                        int32_t max_iterations, float it_weight_gradient, float epsilon, int32_t res,
                        uint32_t flags, float T_out[16], int64_t *trace, int32_t trace_cap)
 {
-  float total[16];
-  memcpy(total, T_in, sizeof total);
-  int32_t center[3] = {(int32_t)total[12], (int32_t)total[13], (int32_t)total[14]}; /* :33 */
-  float alpha = 0.f;
-  float prev[4] = {0, 0, 0, 0};
-  int finished = 0, it = 0;
-  for (int i = 0; i < max_iterations && !finished; ++i)
+  wso_gn_state st;
+  wso_gn_begin(&st, T_in, max_iterations, it_weight_gradient, epsilon);
+  while (!st.finished && st.iterations < st.max_iterations)
   {
-    int64_t h[36], g[6];
+    int64_t sums[44];
     int32_t e, c;
-    wso_reg_iterate(map, total, xyz, n, res, h, g, &e, &c, flags);
-    it = i + 1;
-    if (trace && i < trace_cap)
-    {
-      memcpy(trace + 44 * (size_t)i, h, sizeof h);
-      memcpy(trace + 44 * (size_t)i + 36, g, sizeof g);
-      trace[44 * (size_t)i + 42] = e;
-      trace[44 * (size_t)i + 43] = c;
-    }
-    if (c == 0) break; /* guard, see header */
-
-    double hf[36], gf[6], xi[6];
-    double w = (double)(alpha * (float)c); /* alpha * gpu_c is a float product, :66 */
-    for (int r = 0; r < 6; ++r)
-    {
-      gf[r] = (double)g[r];
-      for (int q = 0; q < 6; ++q) hf[r * 6 + q] = (double)h[q * 6 + r] + (r == q ? w : 0.0);
-    }
-    if (wso_solve6(hf, gf, xi) != 0) break;
-    for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
-
-    float tr[16];
-    wso_xi_to_transform(xi, center, tr);
-    alpha += it_weight_gradient;
-    matmul4f(tr, total, total);
-
-    float err = (float)e / c;
-    if (fabsf(err - prev[2]) < epsilon && fabsf(err - prev[0]) < epsilon) finished = 1;
-    prev[0] = prev[1]; prev[1] = prev[2]; prev[2] = prev[3];
-    prev[3] = err;
+    wso_reg_iterate(map, st.T, xyz, n, res, sums, sums + 36, &e, &c, flags);
+    sums[42] = e;
+    sums[43] = c;
+    if (trace && st.iterations < trace_cap) memcpy(trace + 44 * (size_t)st.iterations, sums, sizeof sums);
+    wso_gn_update(&st, sums);
   }
-  memcpy(T_out, total, sizeof total);
-  return it;
+  memcpy(T_out, st.T, 16 * sizeof(float));
+  return st.iterations;
 }

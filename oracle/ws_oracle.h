@@ -71,6 +71,12 @@ int32_t wso_dz_per_distance(void);
 /* tsdf_mapping.cpp:77-85 */
 void wso_convert_pose(const float pose[16], int32_t res, int32_t pos_vox[3], int32_t up[3]);
 
+/* ---- vector math (math/vector3.h) and the per-ray set-up of update_tsdf.cu:57-63 ---- */
+int32_t wso_l2norm_i(int32_t x, int32_t y, int32_t z);
+int64_t wso_l2norm_l(int64_t x, int64_t y, int64_t z);
+void wso_cross_i(const int32_t a[3], const int32_t b[3], int32_t out[3]);
+int wso_ray_setup(const int32_t point[3], const int32_t pos_mm[3], const int32_t up[3], int32_t *distance_out, int64_t iv[3]);
+
 /* ---- atomic_tsdf_min executed serially (cuda/util.h:70-109); returns 1 if the entry was replaced ---- */
 int wso_tsdf_min(uint32_t *addr, uint32_t new_raw);
 
@@ -93,6 +99,20 @@ void wso_reg_iterate(const wso_map *map, const float T[16], const int32_t *xyz, 
 /* ---- host Gauss-Newton loop (tsdf_registration.cpp:28-96, registration/util.h:5-39) ---- */
 int wso_solve6(const double A[36] /*row-major*/, const double b[6], double x[6]);
 void wso_xi_to_transform(const double xi[6], const int32_t center[3], float T[16] /*col-major*/);
+typedef struct
+{
+  float T[16]; /* total_transform, column-major */
+  int32_t center[3];
+  float alpha;
+  float prev[4];
+  float it_weight_gradient;
+  float epsilon;
+  int32_t max_iterations;
+  int32_t iterations;
+  int32_t finished;
+} wso_gn_state;
+void wso_gn_begin(wso_gn_state *st, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon);
+void wso_gn_update(wso_gn_state *st, const int64_t sums[44] /* h[36] col-major, g[6], e, c */);
 /* returns iterations executed; trace (optional) receives per iteration: h[36] g[6] e c -> 44 int64 */
 int wso_register_cloud(const wso_map *map, const int32_t *xyz, size_t n, const float T_in[16],
                        int32_t max_iterations, float it_weight_gradient, float epsilon, int32_t res,

@@ -1,0 +1,231 @@
+"""CPU tests that PIN the oracle (oracle/ws_oracle.c) — no GPU needed.
+
+1. the reference's own known-answer tests for this path,
+2. golden vectors produced by the reference's own headers (oracle/_ref -> tests/golden/ref_headers.npz,
+   generator: tests/golden/make_ref_goldens.py), and — where /root/reference is present — oracle/_ref live,
+3. the whole-scan counters the survey recorded from the reference kernel source.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_headers.npz")
+
+
+def calc_weight(value, tau, weight_epsilon):
+    """include/warpsense/test/common.h:16-26"""
+    w = 64
+    if value < -weight_epsilon:
+        w = int(64 * (tau + value) / (tau - weight_epsilon))
+    return w
+
+
+# ------------------------------------------------------------------ 1. reference KATs
+def test_kat_tsdf_write_cuda_semantics():
+    """test/map.cpp:9-90 and test/cuda.cpp:268-414: point (5500,500,500), res 1000, tau 3000, 21^3 map."""
+    tau, res, mw = 3000, 1000, 10 * 64
+    avg = O.OracleMap((20, 20, 20), tau, 0)
+    new = avg.copy()
+    assert list(avg.size) == [21, 21, 21] and list(avg.offset) == [10, 10, 10] and list(avg.pos) == [0, 0, 0]  # test/test.cu:63-126
+    pos, up = O.convert_pose(np.eye(4), res)
+    assert list(pos) == [0, 0, 0] and list(up) == [0, 0, 32768]
+    st = O.update_tsdf(avg, new, np.array([[5500, 500, 500]], dtype=np.int32), pos, up, tau, mw, res)
+    expect = [3000, 3000, 2000, 1000, 0, -1000, -2000]
+    for x, v in zip(range(1, 8), expect):
+        val, w = avg.entry(x, 0, 0)
+        assert val == v and w == calc_weight(v, tau, tau // 10), (x, val, w)
+    assert [avg.entry(x, 0, 0)[1] for x in range(1, 8)] == [64, 64, 64, 64, 64, 47, 23]
+    assert avg.entry(8, 0, 0) == (3000, 0)
+    assert st.write_calls == 7 and int((avg.data != O.pack(tau, 0)).sum()) == 7
+    assert np.all(new.data == O.pack(tau, 0))
+
+
+def test_kat_tsdf_write_cpu_port():
+    """the same KAT through the CPU-baseline port (the reference runs it on src/cpu/update_tsdf.cpp:397-564)."""
+    tau, res, mw = 3000, 1000, 640
+    for threads in (1, 2):
+        m = O.OracleMap((20, 20, 20), tau, 0)
+        O.cpu_update_tsdf(m, np.array([[5500, 500, 500]], dtype=np.int32), [0, 0, 0], [0, 0, 32768], tau, mw, res, threads)
+        assert [m.entry(x, 0, 0) for x in range(1, 9)] == [(3000, 64), (3000, 64), (2000, 64), (1000, 64), (0, 64),
+                                                           (-1000, 47), (-2000, 23), (3000, 0)]
+
+
+def test_kat_map_bounds():
+    """test/cuda.cpp:28-105 / test/map.cpp:240-300: 5^3 map, default (4, 6)."""
+    m = O.OracleMap((5, 5, 5), 4, 6)
+    assert list(m.size) == [5, 5, 5] and list(m.offset) == [2, 2, 2]
+    for (x, y, z), (v, w) in {(-2, 2, 0): (0, 0), (-1, 2, 0): (1, 1), (-2, 1, 0): (2, 1), (-1, 1, 0): (3, 2),
+                              (-2, 0, 0): (4, 3), (-1, 0, 0): (5, 5)}.items():
+        m.set_entry(x, y, z, v, w)
+    assert m.in_bounds(0, 2, -2) and not m.in_bounds(22, 0, 0)
+    assert m.entry(0, 0, 0) == (4, 6) and m.entry(-1, 2, 0) == (1, 1)
+    # shifted window of test/map.cpp:303-309: pos (24,0,0), offset (26 % 5, 2, 2)
+    s = O.OracleMap((5, 5, 5), 4, 6, pos=(24, 0, 0), offset=(26 % 5, 2, 2))
+    assert not s.in_bounds(0, 2, -2) and s.in_bounds(22, 0, 0)
+    seen = {s.index(x, y, z) for x in range(22, 27) for y in range(-2, 3) for z in range(-2, 3)}
+    assert seen == set(range(125))  # the ring mapping is a bijection onto the storage
+
+
+def test_kat_ring_buffer_shift():
+    """test/map.cpp:240-365 (map_raw) on the host LocalMap mirror: offsets after shifts, values survive unload/reload."""
+    import warpsense_amd as W
+    lm = W.LocalMap(5, 5, 5, 4, 6)
+    for (x, y, z), (v, w) in {(-2, 2, 0): (0, 0), (-1, 2, 0): (1, 1), (-2, 1, 0): (2, 1), (-1, 1, 0): (3, 2),
+                              (-2, 0, 0): (4, 3), (-1, 0, 0): (5, 5)}.items():
+        lm.set_value(x, y, z, v, w)
+    for x in (5, 10, 15, 20, 24):
+        lm.shift((x, 0, 0))
+    assert list(lm.pos) == [24, 0, 0] and list(lm.offset) == [26 % 5, 2, 2]
+    assert not lm.in_bounds(0, 2, -2) and lm.in_bounds(22, 0, 0) and lm.value(24, 0, 0) == (4, 6)
+    lm.set_value(24, 0, 0, 24, 0)
+    lm.shift((24, 5, 0)); lm.set_value(24, 5, 0, 24, 5)
+    lm.shift((19, 5, 0)); lm.set_value(19, 5, 0, 19, 5)
+    lm.shift((19, 0, 0)); lm.set_value(19, 0, 0, 19, 0)
+    lm.shift((24, 0, 0)); assert lm.value(24, 0, 0) == (24, 0)
+    lm.shift((19, 0, 0)); assert lm.value(19, 0, 0) == (19, 0)
+    lm.shift((24, 5, 0)); assert lm.value(24, 5, 0) == (24, 5)
+    lm.shift((19, 5, 0)); assert lm.value(19, 5, 0) == (19, 5)
+    lm.shift((24, 0, 0)); assert lm.value(24, 0, 0) == (24, 0)
+    for x in (19, 14, 9, 4, 0):
+        lm.shift((x, 0, 0))
+    assert list(lm.pos) == [0, 0, 0] and list(lm.offset) == [2, 2, 2]
+    assert lm.value(0, 0, 0) == (4, 6) and lm.value(-1, 2, 0) == (1, 1)
+    # the oracle's index math agrees with the mirror after shifting
+    om = O.OracleMap((5, 5, 5), 4, 6, pos=lm.pos, offset=lm.offset, data=lm.data.copy())
+    assert om.entry(-1, 2, 0) == (1, 1)
+
+
+def test_kat_atomic_tsdf_min():
+    """test/cuda.cpp:968-990: 100 000 entries (v, 0), v in [1, 1000] -> the minimum value survives."""
+    rng = np.random.default_rng(3)
+    vals = rng.integers(1, 1001, 100_000).astype(np.int16)
+    cell = (C.c_uint32 * 1)(int(O.pack(32767, 0)))
+    L = O.lib()
+    for v in vals:
+        L.wso_tsdf_min(cell, int(O.pack(int(v), 0)))
+    assert O.unpack(cell[0])[0] == vals.min()
+    # a positive weight freezes the voxel (cuda/util.h:74-78)
+    cell[0] = int(O.pack(500, 64))
+    assert L.wso_tsdf_min(cell, int(O.pack(1, 64))) == 0 and O.unpack(cell[0]) == (500, 64)
+    # ties are replaced (|new| <= |old|), sign of the value is ignored by the comparison
+    cell[0] = int(O.pack(-300, -64))
+    assert L.wso_tsdf_min(cell, int(O.pack(300, -10))) == 1 and O.unpack(cell[0]) == (300, -10)
+
+
+@pytest.mark.parametrize("J", [[0, 1, 2, 3, 4, 5], [-1, 1, 2, 3, 4, -5], [0, 1, -2, 12, 4, 5], [0, -1, 20, 3, -4, 5]])
+def test_kat_jacobi_outer_product(J):
+    """test/cuda.cpp:837-923: h == J J^T for the four vectors."""
+    jac = np.array([J], dtype=np.int64)
+    vals = np.array([7], dtype=np.int16)
+    mask = np.array([1], dtype=np.uint8)
+    h = np.zeros(36, dtype=np.int64)
+    g = np.zeros(6, dtype=np.int64)
+    e, c = C.c_int32(0), C.c_int32(0)
+    O.lib().wso_reduce(O._p(jac), O._p(vals), O._p(mask), 1, O._p(h), O._p(g), C.byref(e), C.byref(c), 0)
+    Jv = np.array(J, dtype=np.int64)
+    assert np.array_equal(h.reshape(6, 6).T, np.outer(Jv, Jv))
+    assert np.array_equal(g, Jv * 7) and e.value == 7 and c.value == 1
+
+
+def test_kat_transform_point():
+    """test/cuda.cpp:760-827: (1,0,0) rotated by +-90 deg about z -> (0,+-1,0) in fixed point."""
+    for theta, want in ((np.pi / 2, (0, 1, 0)), (-np.pi / 2, (0, -1, 0))):
+        T = np.eye(4, dtype=np.float32)
+        T[0, 0] = np.cos(np.float32(theta)); T[0, 1] = -np.sin(np.float32(theta))
+        T[1, 0] = np.sin(np.float32(theta)); T[1, 1] = np.cos(np.float32(theta))
+        M = np.zeros(16, dtype=np.int32)
+        O.lib().wso_to_int_mat(O._p(O.colmajor(T)), O._p(M))
+        out = np.zeros(3, dtype=np.int32)
+        O.lib().wso_transform_point(O._p(np.array([1, 0, 0], dtype=np.int32)), O._p(M), O._p(out))
+        assert tuple(out) == want
+
+
+def test_kat_data_sizes_and_consts():
+    """test/test.cu:48-61, include/warpsense/consts.h."""
+    g = np.load(GOLD)
+    assert list(g["consts"]) == [32768, 64, 4, 8]
+    assert O.lib().wso_dz_per_distance() == 100
+
+
+# ------------------------------------------------------------------ 2. golden vectors from the reference headers
+def _check_against(get_index, in_bounds, in_pos, in_neg, l2i, l2l, cross, ray_setup, pack):
+    g = np.load(GOLD)
+    for m, q, r in zip(g["ring_maps"], g["ring_queries"], g["ring_results"]):
+        om = O.OracleMap(m[0:3], 0, 0, pos=m[3:6], offset=m[6:9])
+        v = om.view()
+        x, y, z = (int(t) for t in q)
+        inb, idx, ipos, ineg, buf = (int(t) for t in r)
+        assert bool(O.lib().wso_in_bounds(C.byref(v), x, y, z)) == bool(inb)
+        if inb:
+            assert O.lib().wso_get_index(C.byref(v), x, y, z) == idx
+        assert bool(O.lib().wso_in_bounds_with_buffer_pos(C.byref(v), x, y, z, buf)) == bool(ipos)
+        assert bool(O.lib().wso_in_bounds_with_buffer_neg(C.byref(v), x, y, z, buf)) == bool(ineg)
+    L = O.lib()
+    L.wso_l2norm_i.restype = C.c_int32
+    L.wso_l2norm_l.restype = C.c_int64
+    L.wso_l2norm_l.argtypes = [C.c_int64] * 3
+    assert np.array_equal(np.array([L.wso_l2norm_i(int(a), int(b), int(c)) for a, b, c in g["l2_in"]]), g["l2_i"])
+    assert np.array_equal(np.array([L.wso_l2norm_l(int(a), int(b), int(c)) for a, b, c in g["l2l_in"]]), g["l2_l"])
+    out = np.zeros(3, dtype=np.int32)
+    for a, b, want in zip(g["cross_a"], g["cross_b"], g["cross_out"]):
+        L.wso_cross_i(O._p(np.ascontiguousarray(a)), O._p(np.ascontiguousarray(b)), O._p(out))
+        assert np.array_equal(out, want)
+    iv = np.zeros(3, dtype=np.int64)
+    for p, pos, up, dist, want_iv, rc in zip(g["ray_points"], g["ray_pos"], g["ray_up"], g["ray_distance"], g["ray_interp"], g["ray_rc"]):
+        d = C.c_int32(0)
+        got = L.wso_ray_setup(O._p(np.ascontiguousarray(p)), O._p(np.ascontiguousarray(pos)), O._p(np.ascontiguousarray(up)),
+                              C.byref(d), O._p(iv))
+        assert got == rc and d.value == dist
+        if rc == 0:
+            assert np.array_equal(iv, want_iv)
+    assert np.array_equal(O.pack(g["entry_vw"][:, 0], g["entry_vw"][:, 1]), g["entry_raw"])
+    # at(i,j) = 10 i + j written through the reference accessors: storage must be column-major
+    assert np.array_equal(g["m4_layout"].reshape(4, 4).T, np.add.outer(10 * np.arange(4), np.arange(4)))
+    assert np.array_equal(g["m6_layout"].reshape(6, 6).T, np.add.outer(10 * np.arange(6), np.arange(6)))
+
+
+def test_golden_reference_headers():
+    _check_against(*[None] * 9)
+
+
+def test_live_reference_headers_if_present():
+    """Where oracle/_ref was built (this container), cross-check fresh random inputs against it directly."""
+    R = O.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(99)
+    L = O.lib()
+    for _ in range(20):
+        size = (rng.integers(1, 30, 3) * 2 + 1).astype(np.int32)
+        pos = rng.integers(-100, 100, 3).astype(np.int32)
+        off = np.array([rng.integers(0, s) for s in size], dtype=np.int32)
+        data = np.zeros(int(np.prod(size)), dtype=np.uint32)
+        h = R.ref_map_create(size.ctypes.data, pos.ctypes.data, off.ctypes.data, data.ctypes.data)
+        om = O.OracleMap(size, 0, 0, pos=pos, offset=off)
+        v = om.view()
+        for _ in range(200):
+            q = pos + rng.integers(-(size // 2), size // 2 + 1)
+            x, y, z = (int(t) for t in q)
+            assert R.ref_get_index(h, x, y, z) == L.wso_get_index(C.byref(v), x, y, z)
+        R.ref_map_destroy(h)
+
+
+# ------------------------------------------------------------------ 3. whole-scan counters of the reference kernel source
+def test_synthetic_scan_counters_match_reference_kernel():
+    """BASELINE.md §2 / SURVEY.md §8d: the reference's cu_min_tsdf_krnl on the synthetic OS1-128 scan makes
+    V = 35 442 598 write_tsdf_min calls, touches T = 13 901 324 voxels, 1 522 214 of them end with a negative weight
+    (513^3 map, res 50, tau 1000, serial order).  The oracle must reproduce all three (the last one is order dependent)."""
+    pts = S.os1_128_scan()
+    assert pts.shape == (131072, 3)
+    assert abs(np.sqrt((pts.astype(np.float64) ** 2).sum(1)).mean() - 9276) < 1.0
+    new = O.OracleMap((512, 512, 512), 1000, 0)
+    st = O.update_min(new, pts, (0, 0, 0), (0, 0, 32768), 1000, 50)
+    _, w = O.unpack(new.data)
+    assert st.write_calls == 35_442_598
+    assert int((new.data != O.pack(1000, 0)).sum()) == 13_901_324
+    assert int((w < 0).sum()) == 1_522_214

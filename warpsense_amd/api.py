@@ -139,16 +139,38 @@ class DeviceMap:
         return int(np.prod(self.size_.astype(np.int64)))
 
 
-class LocalMap:
-    """In-memory part of HDF5LocalMap (src/map/hdf5_local_map.cpp:5-20): sizes forced odd, offset = size/2,
-    every voxel the default entry.  Owns the host arrays a DeviceMap views."""
+class GlobalMap:
+    """In-memory stand-in for HDF5GlobalMap's chunk store (src/map/hdf5_global_map.cpp:59-173): the world is cut
+    into 64^3-voxel chunks of raw uint32 entries, index x*4096 + y*64 + z inside a chunk (:53-57), unseen chunks
+    are filled with the default entry.  (Writing the chunks to an .h5 file is a "next" row)"""
 
-    def __init__(self, sx, sy, sz, default_value, default_weight=0):
+    CHUNK_SIZE = 64
+
+    def __init__(self, default_value, default_weight=0):
+        self.default_raw = int(pack_entry(default_value, default_weight))
+        self.chunks: dict[tuple[int, int, int], np.ndarray] = {}
+
+    def activate_chunk(self, cx, cy, cz) -> np.ndarray:
+        key = (int(cx), int(cy), int(cz))
+        c = self.chunks.get(key)
+        if c is None:
+            c = np.full(self.CHUNK_SIZE ** 3, self.default_raw, dtype=np.uint32)
+            self.chunks[key] = c
+        return c
+
+
+class LocalMap:
+    """HDF5LocalMap without the file (src/map/hdf5_local_map.cpp): a 3-D ring buffer of TSDF entries around `pos`.
+    Sizes are forced odd, offset = size/2, every voxel starts as the global map's default entry (:5-20);
+    shift() moves the window, saving the slabs that leave to the global map and loading the ones that enter
+    (:53-118).  Owns the host arrays a DeviceMap views."""
+
+    def __init__(self, sx, sy, sz, default_value, default_weight=0, global_map: GlobalMap | None = None):
         self.size = np.array([s if s % 2 == 1 else s + 1 for s in (int(sx), int(sy), int(sz))], dtype=np.int32)
         self.pos = np.zeros(3, dtype=np.int32)
         self.offset = (self.size // 2).astype(np.int32)
-        self.data = np.full(int(np.prod(self.size.astype(np.int64))), pack_entry(default_value, default_weight),
-                            dtype=np.uint32)
+        self.map_ = global_map or GlobalMap(default_value, default_weight)
+        self.data = np.full(int(np.prod(self.size.astype(np.int64))), self.map_.default_raw, dtype=np.uint32)
 
     def device_map(self) -> DeviceMap:
         return DeviceMap(self.size, self.offset, self.data, self.pos)
@@ -169,6 +191,63 @@ class LocalMap:
             raise IndexError(f"Index out of bounds: {x}; {y}; {z}")  # std::out_of_range, hdf5_local_map.h:172-181
         v, w = unpack_entry(self.data[self.get_index(x, y, z)])
         return int(v), int(w)
+
+    def set_value(self, x, y, z, value, weight):
+        if not self.in_bounds(x, y, z):
+            raise IndexError(f"Index out of bounds: {x}; {y}; {z}")
+        self.data[self.get_index(x, y, z)] = pack_entry(value, weight)
+
+    # -- save_load_area<save> (hdf5_local_map.cpp:120-198): one pass per 64^3 chunk the box touches
+    def _area(self, start, end, save: bool):
+        cs = GlobalMap.CHUNK_SIZE
+        start, end = np.minimum(start, end).astype(np.int64), np.maximum(start, end).astype(np.int64)
+        s, p, o = self.size.astype(np.int64), self.pos.astype(np.int64), self.offset.astype(np.int64)
+        c0, c1 = np.floor_divide(start, cs), np.floor_divide(end, cs)
+        for cx in range(c0[0], c1[0] + 1):
+            for cy in range(c0[1], c1[1] + 1):
+                for cz in range(c0[2], c1[2] + 1):
+                    chunk = self.map_.activate_chunk(cx, cy, cz)
+                    base = np.array([cx, cy, cz], dtype=np.int64) * cs
+                    lo = np.maximum(start, base) - base
+                    hi = np.minimum(end, base + cs - 1) - base
+                    d = [np.arange(lo[k], hi[k] + 1, dtype=np.int64) for k in range(3)]
+                    g = [d[k] + base[k] for k in range(3)]
+                    r = [(g[k] - p[k] + o[k] + s[k]) % s[k] for k in range(3)]
+                    ring = ((r[0][:, None, None] * s[1] + r[1][None, :, None]) * s[2] + r[2][None, None, :]).reshape(-1)
+                    loc = (d[0][:, None, None] * cs * cs + d[1][None, :, None] * cs + d[2][None, None, :]).reshape(-1)
+                    if save:
+                        chunk[loc] = self.data[ring]
+                    else:
+                        self.data[ring] = chunk[loc]
+
+    def shift(self, new_pos):
+        """HDF5LocalMap::shift (hdf5_local_map.cpp:53-118), axis by axis."""
+        new_pos = np.asarray(new_pos, dtype=np.int64)
+        diff = new_pos - self.pos
+        assert np.all(np.abs(diff) <= self.size)
+        for axis in range(3):
+            if diff[axis] == 0:
+                continue
+            start = self.pos.astype(np.int64) - self.size // 2
+            end = self.pos.astype(np.int64) + self.size // 2
+            if diff[axis] > 0:
+                end[axis] = start[axis] + diff[axis] - 1
+            else:
+                start[axis] = end[axis] + diff[axis] + 1
+            self._area(start, end, save=True)
+            self.pos[axis] += diff[axis]
+            self.offset[axis] = (self.offset[axis] + diff[axis] + self.size[axis]) % self.size[axis]
+            start = self.pos.astype(np.int64) - self.size // 2
+            end = self.pos.astype(np.int64) + self.size // 2
+            if diff[axis] > 0:
+                start[axis] = end[axis] - (diff[axis] - 1)
+            else:
+                end[axis] = start[axis] - diff[axis] - 1
+            self._area(start, end, save=False)
+
+    def write_back(self):
+        """hdf5_local_map.cpp:210-217: save the whole window to the global map."""
+        self._area(self.pos.astype(np.int64) - self.size // 2, self.pos.astype(np.int64) + self.size // 2, save=True)
 
 
 class DeviceMapMemWrapper:
