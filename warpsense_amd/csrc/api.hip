@@ -167,7 +167,7 @@ static int map_free(ws_map *m)
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
   void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->dirty_list, m->rays, m->scan_dev,
-                  m->counters, m->arena};
+                  m->counters, m->arena, m->contested_per_wave};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -223,6 +223,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
   TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));
+  TRY(hipMalloc((void **)&m->contested_per_wave, 8192 * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(m->contested_per_wave, 0, 8192 * sizeof(uint32_t), s));
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
   TRY(hipMemsetAsync(m->kpos, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
   TRY(hipMemsetAsync(m->kneg, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
@@ -369,7 +371,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   if (!m || !out) return invalid("ws_tsdf_stats: NULL argument");
   WS_HIP(hipMemcpyAsync(m->counters_host, m->counters, sizeof(TsdfCounters), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  out->contested_voxels = m->counters_host->contested;
+  out->contested_voxels = m->counters_host->last_contested;
   out->contested_records = m->counters_host->records;
   out->dirty_tiles = m->counters_host->last_dirty_tiles;
   out->error_flags = (int32_t)m->counters_host->error;

@@ -88,6 +88,7 @@ struct MarchArgs
   TsdfCounters *counters;
   ContestedRecord *arena;
   uint32_t arena_cap;
+  uint32_t arena_slice;    // records reserved per workgroup of the collect pass
   int32_t collect_min_len; // COLLECT: steps below this length cannot reach a contested voxel
 };
 
@@ -104,10 +105,11 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter)
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Record allocation for the collect pass: every wave owns a chunk of the arena (cursor/end in LDS) and
-// only goes to the shared counter when the chunk is used up.
-constexpr uint32_t RECORD_CHUNK = 128;
-__device__ __forceinline__ uint32_t wave_alloc_chunked(uint32_t *counter, volatile uint32_t *cur, volatile uint32_t *end)
+// Record allocation for the collect pass.  A shared bump counter costs ~10-20 ns per hit on MI355X even
+// when only wave leaders touch it, so every workgroup owns a fixed slice of the arena and allocates from it
+// with an LDS cursor; the shared counter (placed behind the slices) is only used when a slice overflows.
+__device__ __forceinline__ uint32_t block_alloc(uint32_t *lds_cursor, uint32_t slice_base, uint32_t slice_len, uint32_t *overflow_counter,
+                                                uint32_t overflow_base)
 {
   const unsigned long long mask = __ballot(1);
   const int lane = (int)(threadIdx.x & 63);
@@ -116,14 +118,11 @@ __device__ __forceinline__ uint32_t wave_alloc_chunked(uint32_t *counter, volati
   uint32_t base = 0;
   if (lane == leader)
   {
-    uint32_t c = *cur;
-    if (c + need > *end)
-    {
-      c = atomicAdd(counter, RECORD_CHUNK);
-      *end = c + RECORD_CHUNK;
-    }
-    *cur = c + need;
-    base = c;
+    const uint32_t c = atomicAdd(lds_cursor, need); // LDS atomic
+    if (c + need <= slice_len)
+      base = slice_base + c;
+    else
+      base = overflow_base + atomicAdd(overflow_counter, need);
   }
   base = (uint32_t)__shfl((int)base, leader, 64);
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -213,10 +212,10 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
 template <int MODE, bool HAS_S0>
 __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
 {
-  __shared__ uint32_t chunk_cur[4], chunk_end[4];
+  __shared__ uint32_t record_cursor;
   if (MODE == MARCH_COLLECT)
   {
-    if (threadIdx.x < 4) chunk_cur[threadIdx.x] = chunk_end[threadIdx.x] = 0;
+    if (threadIdx.x == 0) record_cursor = 0;
     __syncthreads();
   }
   if (MODE == MARCH_COLLECT)
@@ -309,28 +308,31 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
 
       if (MODE == MARCH_EMIT)
       {
-        // touched-tile flag: a plain byte store (every writer stores the same value); the list of
-        // touched tiles is compacted from the flags afterwards — a shared append counter here would
-        // serialise the whole march (measured: 2.3 ms for 381 k appends)
-        const int64_t tile = idx >> TILE_SHIFT;
-        if (a.dirty[tile] == 0) a.dirty[tile] = 1;
+        // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
+        // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
+        // pile up on one byte the way an unconditional mark does near the sensor (measured: +0.8 ms), and the
+        // atomics stay non-returning (a returning atomicMin stalls the lane for the memory round trip).
         if (positive)
         {
           const uint64_t key = (t << 16) | ((uint32_t)value & 0xffffu);
-          if (key < a.kpos[idx]) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
+          const uint64_t cur = a.kpos[idx];
+          if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
+          if (key < cur) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
         }
         else
         {
           const uint64_t key = ((uint64_t)absval << 45) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
-          if (key < a.kneg[idx]) atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)key);
+          const uint64_t cur = a.kneg[idx];
+          if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
+          if (key < cur) atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)key);
         }
       }
       else
       {
         if (a.kpos[idx] == KEY_CONTESTED_TAG)
         {
-          const int w = (int)(threadIdx.x >> 6);
-          const uint32_t rec = wave_alloc_chunked(&a.counters->records, &chunk_cur[w], &chunk_end[w]);
+          const uint32_t rec = block_alloc(&record_cursor, blockIdx.x * a.arena_slice, a.arena_slice, &a.counters->records,
+                                           gridDim.x * a.arena_slice);
           if (rec < a.arena_cap)
           {
             ContestedRecord cr;
@@ -359,22 +361,54 @@ struct ResolveArgs
   int64_t n_vox;
   int32_t tau;
   TsdfCounters *counters;
+  uint32_t *contested_per_wave; // [LIST_GRID_BLOCKS * 4]
   const ContestedRecord *arena;
   uint32_t arena_cap;
 };
 
-// touched-tile flags -> list of tile ids (order irrelevant); clears the flags it consumes
+// touched-tile flags -> list of tile ids (order irrelevant); clears the flags it consumes.
+// Each workgroup owns a contiguous range of tiles: it counts its flags, reserves its part of the list with
+// ONE atomic, then writes the ids (a shared counter hit once per wave was 226 us of this pass).
+constexpr int COMPACT_BLOCKS = 256;
 __global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int64_t n_tiles, uint32_t *list, TsdfCounters *counters)
 {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ((n_tiles + 63) & ~63ll); i += stride)
+  __shared__ uint32_t wave_total[4];
+  __shared__ uint32_t block_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t per_block = ((n_tiles + COMPACT_BLOCKS - 1) / COMPACT_BLOCKS + 255) & ~255ll;
+  const int64_t lo = (int64_t)blockIdx.x * per_block;
+  const int64_t hi = lo + per_block < n_tiles ? lo + per_block : n_tiles;
+  // pass 1: count
+  uint32_t cnt = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) cnt += dirty[i] != 0 ? 1u : 0u;
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+  if (lane == 0) wave_total[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0)
   {
-    const bool flag = i < n_tiles && dirty[i] != 0;
+    const uint32_t total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    block_base = total ? atomicAdd(&counters->dirty_tiles, total) : 0u;
+  }
+  __syncthreads();
+  // pass 2: write ids; running offset = block_base + flags seen so far in this workgroup
+  uint32_t running = block_base;
+  for (int64_t i0 = lo; i0 < hi; i0 += 256)
+  {
+    const int64_t i = i0 + threadIdx.x;
+    const bool flag = i < hi && dirty[i] != 0;
+    const unsigned long long mask = __ballot(flag);
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_total[w];
+    const uint32_t chunk_total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
     if (flag)
     {
+      list[running + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
       dirty[i] = 0;
-      list[wave_alloc(&counters->dirty_tiles)] = (uint32_t)i;
     }
+    running += chunk_total;
+    __syncthreads();
   }
 }
 
@@ -429,9 +463,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
       n_contested += 1;
     }
   }
-  // one counter update per wave for the whole pass (a per-voxel atomic on one address costs milliseconds)
+  // no shared counter (even one atomic per wave on a single address costs ~100 us here): a wave that saw a
+  // contested voxel raises the flag with a plain store, the exact count is kept per wave for the statistics
   for (int d = 32; d > 0; d >>= 1) n_contested += __shfl_down(n_contested, d, 64);
-  if (lane == 0 && n_contested) atomicAdd(&a.counters->contested, (uint32_t)n_contested);
+  if (lane == 0)
+  {
+    a.contested_per_wave[blockIdx.x * 4u + (threadIdx.x >> 6)] = (uint32_t)n_contested;
+    if (n_contested) a.counters->contested = 1;
+  }
 }
 
 // Ordered fallback: walk the touched tiles again, one lane per voxel; a lane whose voxel is tagged folds
@@ -515,10 +554,20 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 }
 
 // bookkeeping after an integrate pass: remember how many tiles were streamed, restart the list
-__global__ void finish_update_kernel(TsdfCounters *c)
+__global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, const uint32_t *contested_per_wave, int n_waves)
 {
-  c->last_dirty_tiles = c->dirty_tiles;
-  c->dirty_tiles = 0;
+  __shared__ uint32_t part[4];
+  uint32_t s = 0;
+  for (int i = threadIdx.x; i < n_waves; i += 256) s += contested_per_wave[i];
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    c->last_contested = part[0] + part[1] + part[2] + part[3];
+    c->last_dirty_tiles = c->dirty_tiles;
+    c->dirty_tiles = 0;
+  }
 }
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
@@ -610,6 +659,11 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.arena = m->arena;
   ma.arena_cap = m->arena_cap;
   {
+    // half of the arena is split evenly between the workgroups, the other half is the shared overflow area
+    const uint32_t blocks = (uint32_t)((n + 7) / 8);
+    ma.arena_slice = (m->arena_cap / 2) / (blocks ? blocks : 1);
+  }
+  {
     // Negative-weight (off-ray) candidates only exist where iter_steps >= 2, i.e. delta_z*2 >= res
     // (update_tsdf.cu:101-102): len >= ceil(ceil(res/2) * 32768 / 100).  A contested voxel holds such a
     // candidate, and every other candidate of the same voxel has a ray length within one voxel
@@ -628,6 +682,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.n_vox = m->n_vox;
   ra.tau = m->tau;
   ra.counters = m->counters;
+  ra.contested_per_wave = m->contested_per_wave;
   ra.arena = m->arena;
   ra.arena_cap = m->arena_cap;
 
@@ -647,9 +702,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   prof_begin(ctx, WS_K_RESOLVE);
   {
-    int64_t cb = (m->n_tiles + 255) / 256;
-    if (cb > 2048) cb = 2048;
-    hipLaunchKernelGGL(compact_dirty_kernel, dim3((unsigned)cb), block, 0, s, m->dirty, m->n_tiles, m->dirty_list, m->counters);
+    hipLaunchKernelGGL(compact_dirty_kernel, dim3(COMPACT_BLOCKS), block, 0, s, m->dirty, m->n_tiles, m->dirty_list, m->counters);
   }
   hipLaunchKernelGGL(resolve_kernel, grid_list, block, 0, s, ra);
   prof_end(ctx, WS_K_RESOLVE);
@@ -699,7 +752,7 @@ int launch_tsdf_integrate(ws_map *m)
     hipLaunchKernelGGL(integrate_sparse_kernel, dim3(LIST_GRID_BLOCKS), block, 0, s, ia);
   }
   prof_end(ctx, WS_K_INTEGRATE);
-  hipLaunchKernelGGL(finish_update_kernel, dim3(1), dim3(1), 0, s, m->counters);
+  hipLaunchKernelGGL(finish_update_kernel, dim3(1), dim3(256), 0, s, m->counters, (const uint32_t *)m->contested_per_wave, LIST_GRID_BLOCKS * 4);
   WS_HIP(hipGetLastError());
   m->new_is_default = true;
   return WS_OK;

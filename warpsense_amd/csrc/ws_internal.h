@@ -46,12 +46,13 @@ struct ContestedRecord // 16 bytes
 
 struct TsdfCounters // device-resident, zeroed at the start of every update
 {
-  uint32_t contested;  // number of contested voxels
+  uint32_t contested;  // non-zero: the last resolve pass found contested voxels
   uint32_t records;    // arena records used
   uint32_t error;      // bit0 arena/list overflow, bit1 key range
   uint32_t dirty_tiles;      // length of the touched-tile list (survives until the integrate pass)
   uint32_t last_dirty_tiles; // tiles the last integrate pass streamed
-  uint32_t pad[3];
+  uint32_t last_contested;   // contested voxels of the last update
+  uint32_t pad[2];
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -113,6 +114,7 @@ struct ws_map
   ws::TsdfCounters *counters = nullptr;
   ws::ContestedRecord *arena = nullptr;
   uint32_t arena_cap = 0;
+  uint32_t *contested_per_wave = nullptr; // statistics, one slot per wave of the resolve pass
   ws::TsdfCounters *counters_host = nullptr; // pinned
 };
 
