@@ -22,9 +22,10 @@ namespace ws
 {
 constexpr int REG_BLOCKS = 256;  // one workgroup per CU
 constexpr int REG_THREADS = 256; // 4 waves
-constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c
+constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
+static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
-static_assert(REG_BLOCKS == REG_THREADS, "phase A reads one partial per thread");
+static_assert(REG_BLOCKS == REG_THREADS && REG_THREADS == 256, "sum_partials: 4 waves x 64 workgroups, 2 lanes per slot");
 
 // exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
 struct FastDiv
@@ -274,82 +275,163 @@ struct PointArgs
   FastDiv resdiv;
 };
 
-// phase B: accumulate the 29 terms of this lane's points (registration.cu:194-257 + :41-118 fused)
-__device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, int64_t (&acc)[REG_SLOTS])
+// ---- phase B building blocks (registration.cu:194-257 + :41-118 fused) ----
+struct IntTransform
 {
-  // cu_to_int_mat (cuda/util.h:24-35): (int)(float * 32768)
   int32_t M[12];
+  int32_t cx, cy, cz;
+};
+
+// cu_to_int_mat (cuda/util.h:24-35): (int)(float * 32768); registration.cu:208: center = (int) translation of the CURRENT transform
+__device__ __forceinline__ IntTransform make_int_transform(const float *T)
+{
+  IntTransform t;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) M[j * 3 + i] = (int32_t)(T[j * 4 + i] * (float)MATRIX_RESOLUTION);
-  // registration.cu:208: center = (int) translation of the CURRENT transform
-  const int32_t cx = (int32_t)T[12], cy = (int32_t)T[13], cz = (int32_t)T[14];
+    for (int i = 0; i < 3; ++i) t.M[j * 3 + i] = (int32_t)(T[j * 4 + i] * (float)MATRIX_RESOLUTION);
+  t.cx = (int32_t)T[12];
+  t.cy = (int32_t)T[13];
+  t.cz = (int32_t)T[14];
+  return t;
+}
 
-  for (uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x; idx < a.end; idx += REG_BLOCKS * REG_THREADS)
+struct Gathered
+{
+  int32_t qx, qy, qz; // transformed point minus center
+  uint32_t cur, xn, xl, yn, yl, zn, zl;
+  bool ok;
+};
+
+// transform one point and issue its 7 gathers (nothing here waits for memory)
+__device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTransform &t, int32_t px, int32_t py, int32_t pz, bool valid)
+{
+  Gathered g;
+  // cu_transform_point (cuda/util.h:11-22), int32 wrap like the reference
+  int32_t qx = wadd(wadd(wadd(wmul(t.M[0], px), wmul(t.M[3], py)), wmul(t.M[6], pz)), t.M[9]) / MATRIX_RESOLUTION;
+  int32_t qy = wadd(wadd(wadd(wmul(t.M[1], px), wmul(t.M[4], py)), wmul(t.M[7], pz)), t.M[10]) / MATRIX_RESOLUTION;
+  int32_t qz = wadd(wadd(wadd(wmul(t.M[2], px), wmul(t.M[5], py)), wmul(t.M[8], pz)), t.M[11]) / MATRIX_RESOLUTION;
+  const int32_t bx = div_trunc(qx, a.resdiv), by = div_trunc(qy, a.resdiv), bz = div_trunc(qz, a.resdiv);
+  g.qx = wsub(qx, t.cx);
+  g.qy = wsub(qy, t.cy);
+  g.qz = wsub(qz, t.cz);
+  g.ok = valid && in_bounds_buffer(a.map, bx, by, bz, -1); // in_bounds_with_buffer_neg(buf, 1), registration.cu:217
+  g.cur = g.xn = g.xl = g.yn = g.yl = g.zn = g.zl = 0;
+  if (g.ok)
   {
-    const int32_t px = a.points[3 * (size_t)idx + 0], py = a.points[3 * (size_t)idx + 1], pz = a.points[3 * (size_t)idx + 2];
-    // cu_transform_point (cuda/util.h:11-22), int32 wrap like the reference
-    int32_t qx = wadd(wadd(wadd(wmul(M[0], px), wmul(M[3], py)), wmul(M[6], pz)), M[9]) / MATRIX_RESOLUTION;
-    int32_t qy = wadd(wadd(wadd(wmul(M[1], px), wmul(M[4], py)), wmul(M[7], pz)), M[10]) / MATRIX_RESOLUTION;
-    int32_t qz = wadd(wadd(wadd(wmul(M[2], px), wmul(M[5], py)), wmul(M[8], pz)), M[11]) / MATRIX_RESOLUTION;
-    const int32_t bx = div_trunc(qx, a.resdiv), by = div_trunc(qy, a.resdiv), bz = div_trunc(qz, a.resdiv);
-    qx = wsub(qx, cx);
-    qy = wsub(qy, cy);
-    qz = wsub(qz, cz);
-    if (!in_bounds_buffer(a.map, bx, by, bz, -1)) continue; // in_bounds_with_buffer_neg(buf, 1), registration.cu:217
-
-    // all 7 gathers are issued before the first use (the 6 neighbours are in bounds by the test above)
-    const uint32_t cur = a.map_data[get_index(a.map, bx, by, bz)];
-    const uint32_t xn = a.map_data[get_index(a.map, bx + 1, by, bz)];
-    const uint32_t xl = a.map_data[get_index(a.map, bx - 1, by, bz)];
-    const uint32_t yn = a.map_data[get_index(a.map, bx, by + 1, bz)];
-    const uint32_t yl = a.map_data[get_index(a.map, bx, by - 1, bz)];
-    const uint32_t zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
-    const uint32_t zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
-    if (entry_weight(cur) == 0) continue;
-
-    // registration.cu:233-246
-    int32_t gx = 0, gy = 0, gz = 0;
-    {
-      const int32_t nv = entry_value(xn), lv = entry_value(xl);
-      if (entry_weight(xn) != 0 && entry_weight(xl) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) gx = (nv - lv) / 2;
-    }
-    {
-      const int32_t nv = entry_value(yn), lv = entry_value(yl);
-      if (entry_weight(yn) != 0 && entry_weight(yl) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) gy = (nv - lv) / 2;
-    }
-    {
-      const int32_t nv = entry_value(zn), lv = entry_value(zl);
-      if (entry_weight(zn) != 0 && entry_weight(zl) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) gz = (nv - lv) / 2;
-    }
-    // point.cross(gradient) in int (math/vector3.h:269-277); J = (cross, gradient) as long
-    int32_t J[6];
-    J[0] = wsub(wmul(qy, gz), wmul(qz, gy));
-    J[1] = wsub(wmul(qz, gx), wmul(qx, gz));
-    J[2] = wsub(wmul(qx, gy), wmul(qy, gx));
-    J[3] = gx;
-    J[4] = gy;
-    J[5] = gz;
-    const int32_t v = entry_value(cur);
-
-    // 21 unique terms of J J^T (registration.cu:55-97); int32 x int32 + int64 maps onto v_mad_i64_i32
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j) acc[tri_index(i, j)] = wadd64(acc[tri_index(i, j)], (int64_t)J[i] * (int64_t)J[j]);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], (int64_t)J[i] * (int64_t)v);
-    acc[27] += (v < 0 ? -v : v);
-    acc[28] += 1;
+    // the 6 neighbours are in bounds by the test above
+    g.cur = a.map_data[get_index(a.map, bx, by, bz)];
+    g.xn = a.map_data[get_index(a.map, bx + 1, by, bz)];
+    g.xl = a.map_data[get_index(a.map, bx - 1, by, bz)];
+    g.yn = a.map_data[get_index(a.map, bx, by + 1, bz)];
+    g.yl = a.map_data[get_index(a.map, bx, by - 1, bz)];
+    g.zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
+    g.zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
   }
+  return g;
+}
+
+__device__ __forceinline__ int32_t central_gradient(uint32_t next, uint32_t last)
+{
+  // registration.cu:233-246: both neighbours observed and not of strictly opposite sign
+  const int32_t nv = entry_value(next), lv = entry_value(last);
+  if (entry_weight(next) != 0 && entry_weight(last) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) return (nv - lv) / 2;
+  return 0;
+}
+
+__device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[REG_SLOTS])
+{
+  if (!g.ok || entry_weight(g.cur) == 0) return;
+  const int32_t gx = central_gradient(g.xn, g.xl), gy = central_gradient(g.yn, g.yl), gz = central_gradient(g.zn, g.zl);
+  // point.cross(gradient) in int (math/vector3.h:269-277); J = (cross, gradient) as long
+  int32_t J[6];
+  J[0] = wsub(wmul(g.qy, gz), wmul(g.qz, gy));
+  J[1] = wsub(wmul(g.qz, gx), wmul(g.qx, gz));
+  J[2] = wsub(wmul(g.qx, gy), wmul(g.qy, gx));
+  J[3] = gx;
+  J[4] = gy;
+  J[5] = gz;
+  const int32_t v = entry_value(g.cur);
+  // 21 unique terms of J J^T (registration.cu:55-97); int32 x int32 + int64 maps onto v_mad_i64_i32
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) acc[tri_index(i, j)] = wadd64(acc[tri_index(i, j)], (int64_t)J[i] * (int64_t)J[j]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], (int64_t)J[i] * (int64_t)v);
+  acc[27] += (v < 0 ? -v : v);
+  acc[28] += 1;
+}
+
+constexpr uint32_t REG_STRIDE = REG_BLOCKS * REG_THREADS; // points covered by one pass of the grid
+
+// raw coordinates of this lane's first two points, loaded before anything else in the kernel
+struct Prefetched
+{
+  int32_t p[2][3];
+  bool valid[2];
+};
+__device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a)
+{
+  Prefetched f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+  {
+    const uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x + (uint32_t)u * REG_STRIDE;
+    f.valid[u] = idx < a.end;
+    const size_t o = f.valid[u] ? 3 * (size_t)idx : 0;
+    f.p[u][0] = f.valid[u] ? a.points[o + 0] : 0;
+    f.p[u][1] = f.valid[u] ? a.points[o + 1] : 0;
+    f.p[u][2] = f.valid[u] ? a.points[o + 2] : 0;
+  }
+  return f;
+}
+
+__device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, const Prefetched &f, int64_t (&acc)[REG_SLOTS])
+{
+  const IntTransform t = make_int_transform(T);
+  // the two prefetched points: 14 gathers in flight before the first is consumed
+  const Gathered g0 = gather_point(a, t, f.p[0][0], f.p[0][1], f.p[0][2], f.valid[0]);
+  const Gathered g1 = gather_point(a, t, f.p[1][0], f.p[1][1], f.p[1][2], f.valid[1]);
+  consume_point(g0, acc);
+  consume_point(g1, acc);
+  // clouds larger than two passes of the grid (N > 131 072)
+  for (uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x + 2 * REG_STRIDE; idx < a.end; idx += REG_STRIDE)
+  {
+    const Gathered g = gather_point(a, t, a.points[3 * (size_t)idx + 0], a.points[3 * (size_t)idx + 1], a.points[3 * (size_t)idx + 2], true);
+    consume_point(g, acc);
+  }
+}
+
+// Sum of the partials [REG_BLOCKS][REG_SLOTS] a previous launch left in HBM -> red[0..31] in LDS.
+// Lane l of wave w adds slot (l >> 1) over 32 of the wave's 64 workgroups: 32 independent, fully coalesced
+// loads per lane (one memory latency), one shuffle, one LDS hop.
+__device__ __forceinline__ void sum_partials(const int64_t *pp, int64_t (*wave_part)[REG_SLOTS], int64_t *red)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane >> 1;
+  const int64_t *base = pp + ((size_t)wave * 64 + (size_t)(lane & 1) * 32) * REG_SLOTS + slot;
+  int64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s = wadd64(s, base[(size_t)i * REG_SLOTS]);
+  s = wadd64(s, shfl_xor_i64(s, 1));
+  if ((lane & 1) == 0) wave_part[wave][slot] = s;
+  __syncthreads();
+  if (threadIdx.x < REG_SLOTS)
+  {
+    int64_t t = 0;
+#pragma unroll
+    for (int w = 0; w < REG_THREADS / 64; ++w) t = wadd64(t, wave_part[w][threadIdx.x]);
+    red[threadIdx.x] = t;
+  }
+  __syncthreads();
 }
 
 struct IterArgs
 {
   PointArgs pts;
   GnState *state;     // [2], double buffered by launch parity
-  int64_t *partials;  // [2][REG_SLOTS][REG_BLOCKS]
+  int64_t *partials;  // [2][REG_BLOCKS][REG_SLOTS]
   int32_t k;          // launch index 0 .. max_iterations
   int32_t *host_flag; // host-mapped: set when the loop has finished (lets the host stop enqueueing)
 };
@@ -372,16 +454,14 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
   const GnState *prev = &a.state[(a.k + 1) & 1];
   GnState *cur = &a.state[a.k & 1];
   const bool need_update = a.k > 0 && !prev->core.finished && prev->core.iterations < prev->core.max_iterations;
+  // this lane's points do not depend on the transform: fetch them now, under phase A
+  const Prefetched pref = prefetch_points(a.pts);
 
   if (need_update)
   {
     // phase A: total of the previous launch's partials (every workgroup, redundantly)
-    const int64_t *pp = a.partials + (size_t)((a.k + 1) & 1) * REG_SLOTS * REG_BLOCKS;
-    int64_t v[REG_SLOTS];
-#pragma unroll
-    for (int t = 0; t < REG_SLOTS; ++t) v[t] = t < REG_TERMS ? pp[(size_t)t * REG_BLOCKS + threadIdx.x] : 0;
     WS_STAMP(1);
-    block_reduce32(v, wave_part, red);
+    sum_partials(a.partials + (size_t)((a.k + 1) & 1) * REG_SLOTS * REG_BLOCKS, wave_part, red);
   }
   WS_STAMP(2);
   if (threadIdx.x == 0)
@@ -419,11 +499,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
   int64_t acc[REG_SLOTS];
 #pragma unroll
   for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-  accumulate_points(a.pts, T, acc);
+  accumulate_points(a.pts, T, pref, acc);
   WS_STAMP(4);
   block_reduce32(acc, wave_part, red);
   if (threadIdx.x < REG_SLOTS)
-    a.partials[(size_t)(a.k & 1) * REG_SLOTS * REG_BLOCKS + (size_t)threadIdx.x * REG_BLOCKS + blockIdx.x] = red[threadIdx.x];
+    a.partials[(size_t)(a.k & 1) * REG_SLOTS * REG_BLOCKS + (size_t)blockIdx.x * REG_SLOTS + threadIdx.x] = red[threadIdx.x];
 #ifdef WS_REG_TIMING
   WS_STAMP(5);
   if (blockIdx.x == 7 && threadIdx.x == 0 && a.k == 20)
@@ -439,7 +519,7 @@ struct AccArgs
   PointArgs pts;
   const float *T;       // 16 floats, column-major (device)
   const GnState *state; // null: no early exit
-  int64_t *partials;    // [REG_SLOTS][REG_BLOCKS] (buffer 0)
+  int64_t *partials;    // [REG_BLOCKS][REG_SLOTS] (buffer 0)
 };
 
 __global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
@@ -453,9 +533,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
   int64_t acc[REG_SLOTS];
 #pragma unroll
   for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-  accumulate_points(a.pts, T, acc);
+  accumulate_points(a.pts, T, prefetch_points(a.pts), acc);
   block_reduce32(acc, wave_part, red);
-  if (threadIdx.x < REG_SLOTS) a.partials[(size_t)threadIdx.x * REG_BLOCKS + blockIdx.x] = red[threadIdx.x];
+  if (threadIdx.x < REG_SLOTS) a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x] = red[threadIdx.x];
 }
 
 __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *partials, const GnState *state, int64_t *sums_out)
@@ -463,10 +543,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *par
   __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
   __shared__ int64_t red[REG_SLOTS];
   if (state != nullptr && (state->core.finished || state->core.iterations >= state->core.max_iterations)) return;
-  int64_t v[REG_SLOTS];
-#pragma unroll
-  for (int t = 0; t < REG_SLOTS; ++t) v[t] = t < REG_TERMS ? partials[(size_t)t * REG_BLOCKS + threadIdx.x] : 0;
-  block_reduce32(v, wave_part, red);
+  sum_partials(partials, wave_part, red);
   if (threadIdx.x == 0)
   {
     int64_t sums[44];

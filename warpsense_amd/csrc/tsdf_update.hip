@@ -23,52 +23,10 @@
 // run one after the other (oracle/ws_oracle.c: wso_update_min).
 #include <cstddef>
 
-#include "ws_device.h"
+#include "ws_march.h"
 
 namespace ws
 {
-
-// Per-ray constants of update_tsdf.cu:52-63, computed once by ray_setup_kernel.
-struct RaySetup // 48 bytes
-{
-  int32_t dx, dy, dz;    // direction_vector = point - pos (mm)
-  int32_t distance;      // (int)|direction_vector|
-  int32_t ivx, ivy, ivz; // interpolation_vector (unit length == MATRIX_RESOLUTION)
-  int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
-  uint64_t div_m;        // multiply-shift constants for the division by `distance`
-  int32_t div_k;
-  int32_t pad;
-};
-
-// exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
-struct FastDiv
-{
-  uint64_t M;
-  int32_t k;
-  int32_t d;
-};
-__host__ __device__ inline FastDiv make_fastdiv(int32_t d)
-{
-  FastDiv f;
-  f.d = d;
-  int l = 0;
-  while ((1ll << l) < d) ++l;
-  f.k = 31 + l;
-  const uint64_t p = 1ull << f.k; // k <= 62
-  f.M = p / (uint64_t)d + ((p % (uint64_t)d) ? 1 : 0);
-  return f;
-}
-// C-style truncating division of any int32 by the prepared positive divisor
-__device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, int32_t d)
-{
-  const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
-  uint32_t q;
-  if (ax == 0x80000000u)
-    q = ax / (uint32_t)d; // |INT_MIN| is outside the multiply-shift range
-  else
-    q = (uint32_t)(((uint64_t)ax * M) >> k); // ax < 2^31, M <= 2^32
-  return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
-}
 
 struct MarchArgs
 {
@@ -228,7 +186,6 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   if (r.steps == 0) return;
   const int32_t c = threadIdx.x & 31;
   const int32_t res = a.res, tau = a.tau;
-  const int32_t weight_epsilon = tau / 10;
   const int32_t half = res / 2;
   // COLLECT only needs the steps with len = 1 + k*half >= collect_min_len
   int32_t kbeg = 0;
@@ -239,117 +196,61 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   const int32_t k1 = min(k0 + ch, r.steps);
   if (k0 >= k1) return;
 
-  const int32_t posx = wadd(wmul(a.scanner_pos[0], res), half);
-  const int32_t posy = wadd(wmul(a.scanner_pos[1], res), half);
-  const int32_t posz = wadd(wmul(a.scanner_pos[2], res), half);
-  const int32_t px = wadd(posx, r.dx), py = wadd(posy, r.dy), pz = wadd(posz, r.dz);
-  const int64_t MR = MATRIX_RESOLUTION;
-  const int64_t ivx = r.ivx, ivy = r.ivy, ivz = r.ivz;
-  const uint64_t rM = a.resdiv.M;
-  const int32_t rK = a.resdiv.k;
-
-  // `prev` of update_tsdf.cu:65-76 is always the (x, y) index of the previous step (or (0,0) before the first)
-  int32_t prevx = 0, prevy = 0;
-  if (k0 > 0)
-  {
-    const int32_t len = 1 + (k0 - 1) * half;
-    prevx = div_trunc(wadd(posx, div_trunc(wmul(r.dx, len), r.div_m, r.div_k, r.distance)), rM, rK, res);
-    prevy = div_trunc(wadd(posy, div_trunc(wmul(r.dy, len), r.div_m, r.div_k, r.distance)), rM, rK, res);
-  }
-
-  for (int32_t k = k0; k < k1; ++k)
-  {
-    const int32_t len = 1 + k * half;
-    const int32_t projx = wadd(posx, div_trunc(wmul(r.dx, len), r.div_m, r.div_k, r.distance));
-    const int32_t projy = wadd(posy, div_trunc(wmul(r.dy, len), r.div_m, r.div_k, r.distance));
-    const int32_t projz = wadd(posz, div_trunc(wmul(r.dz, len), r.div_m, r.div_k, r.distance));
-    const int32_t ixx = div_trunc(projx, rM, rK, res), iyy = div_trunc(projy, rM, rK, res), izz = div_trunc(projz, rM, rK, res);
-    if (ixx == prevx && iyy == prevy) continue;
-    prevx = ixx;
-    prevy = iyy;
-    if (!in_bounds(a.map, ixx, iyy, izz)) continue;
-
-    // update_tsdf.cu:81-98
-    const int32_t tcx = wadd(wmul(ixx, res), half), tcy = wadd(wmul(iyy, res), half), tcz = wadd(wmul(izz, res), half);
-    int32_t value = l2norm_i(wsub(px, tcx), wsub(py, tcy), wsub(pz, tcz));
-    value = value < tau ? value : tau;
-    if (len > r.distance) value = -value;
-    const int32_t weight = tsdf_weight(value, tau, weight_epsilon);
-    if (weight == 0) continue;
-    const uint32_t absval = (uint32_t)(value < 0 ? -value : value) & 0x7fffu;
-
-    // update_tsdf.cu:101-105
-    const int32_t delta_z = wmul(DZ_PER_DISTANCE, len) / MATRIX_RESOLUTION;
-    const int32_t iter_steps = (delta_z * 2) / res + 1;
-    const int32_t mid = delta_z / res;
-    const int32_t lowx = wsub(projx, (int32_t)(wmul64(delta_z, ivx) / MR));
-    const int32_t lowy = wsub(projy, (int32_t)(wmul64(delta_z, ivy) / MR));
-    const int32_t lowz = wsub(projz, (int32_t)(wmul64(delta_z, ivz) / MR));
-
-    for (int32_t step = 0; step < iter_steps; ++step)
+  const MarchFrame f = make_march_frame(a.scanner_pos, res, tau, a.map);
+  march_steps(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+    const int64_t idx = get_index(a.map, vx, vy, vz);
+    const uint64_t t = order_key(ix, k, step);
+    if (HAS_S0)
     {
-      const int64_t sm = (int64_t)wmul(step, res);
-      const int32_t vx = div_trunc(wadd(lowx, (int32_t)(wmul64(sm, ivx) / MR)), rM, rK, res);
-      const int32_t vy = div_trunc(wadd(lowy, (int32_t)(wmul64(sm, ivy) / MR)), rM, rK, res);
-      const int32_t vz = div_trunc(wadd(lowz, (int32_t)(wmul64(sm, ivz) / MR)), rM, rK, res);
-      if (!in_bounds(a.map, vx, vy, vz)) continue;
-      const int64_t idx = get_index(a.map, vx, vy, vz);
-      const bool positive = (step == mid);
-      const uint64_t t = ((uint64_t)ix << 24) | ((uint64_t)(uint32_t)k << 8) | (uint64_t)step;
-
-      if (HAS_S0)
+      // candidates the initial new_map entry would reject can never be accepted later either
+      // (the stored |value| only shrinks and a positive weight freezes the voxel): drop them here
+      const uint32_t s0 = a.new_data[idx];
+      const int32_t a0 = entry_value(s0) < 0 ? -entry_value(s0) : entry_value(s0);
+      if (entry_weight(s0) > 0 || (value < 0 ? -value : value) > a0) return;
+    }
+    if (MODE == MARCH_EMIT)
+    {
+      // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
+      // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
+      // pile up on one byte the way an unconditional mark does near the sensor (measured: +0.8 ms), and the
+      // atomics stay non-returning (a returning atomicMin stalls the lane for the memory round trip).
+      if (positive)
       {
-        // candidates the initial new_map entry would reject can never be accepted later either
-        // (the stored |value| only shrinks and a positive weight freezes the voxel): drop them here
-        const uint32_t s0 = a.new_data[idx];
-        const int32_t a0 = entry_value(s0) < 0 ? -entry_value(s0) : entry_value(s0);
-        if (entry_weight(s0) > 0 || (int32_t)absval > a0) continue;
-      }
-
-      if (MODE == MARCH_EMIT)
-      {
-        // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
-        // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
-        // pile up on one byte the way an unconditional mark does near the sensor (measured: +0.8 ms), and the
-        // atomics stay non-returning (a returning atomicMin stalls the lane for the memory round trip).
-        if (positive)
-        {
-          const uint64_t key = (t << 16) | ((uint32_t)value & 0xffffu);
-          const uint64_t cur = a.kpos[idx];
-          if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
-          if (key < cur) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
-        }
-        else
-        {
-          const uint64_t key = ((uint64_t)absval << 45) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
-          const uint64_t cur = a.kneg[idx];
-          if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
-          if (key < cur) atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)key);
-        }
+        const uint64_t key = make_kpos(t, value);
+        const uint64_t cur = a.kpos[idx];
+        if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
+        if (key < cur) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
       }
       else
       {
-        if (a.kpos[idx] == KEY_CONTESTED_TAG)
+        const uint64_t key = make_kneg(t, value);
+        const uint64_t cur = a.kneg[idx];
+        if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
+        if (key < cur) atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)key);
+      }
+    }
+    else
+    {
+      if (a.kpos[idx] == KEY_CONTESTED_TAG)
+      {
+        const uint32_t rec = block_alloc(&record_cursor, blockIdx.x * a.arena_slice, a.arena_slice, &a.counters->records,
+                                         gridDim.x * a.arena_slice);
+        if (rec < a.arena_cap)
         {
-          const uint32_t rec = block_alloc(&record_cursor, blockIdx.x * a.arena_slice, a.arena_slice, &a.counters->records,
-                                           gridDim.x * a.arena_slice);
-          if (rec < a.arena_cap)
-          {
-            ContestedRecord cr;
-            cr.key = (t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu);
-            // the list head of a contested voxel lives in the low half of its (now unused) kneg word
-            cr.next = atomicExch(reinterpret_cast<uint32_t *>(&a.kneg[idx]), rec);
-            cr.pad = 0;
-            a.arena[rec] = cr;
-          }
-          else
-          {
-            atomicOr(&a.counters->error, 1u);
-          }
+          ContestedRecord cr;
+          cr.key = (t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu);
+          // the list head of a contested voxel lives in the low half of its (now unused) kneg word
+          cr.next = atomicExch(reinterpret_cast<uint32_t *>(&a.kneg[idx]), rec);
+          cr.pad = 0;
+          a.arena[rec] = cr;
+        }
+        else
+        {
+          atomicOr(&a.counters->error, 1u);
         }
       }
     }
-  }
+  });
 }
 
 struct ResolveArgs
