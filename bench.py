@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--map", type=int, default=512, help="map edge in voxels (the reference forces it odd: 513)")
     ap.add_argument("--resolution", type=int, default=50)
     ap.add_argument("--integrate", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--scatter", choices=["tiles", "global"], default="tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-registration", action="store_true", help="time the TSDF update alone (diagnostics)")
     return ap.parse_args()
@@ -89,6 +90,7 @@ def main():
     host_map.data_ = None  # fresh map: let the library fill both device maps with (tau, 0)
     tsdf = W.TSDFCuda(host_map, tau, mw, res, ctx)
     tsdf.set_integrate(W.WS_INTEGRATE_DENSE if args.integrate == "dense" else W.WS_INTEGRATE_SPARSE)
+    tsdf.set_scatter(W.WS_SCATTER_TILES if args.scatter == "tiles" else W.WS_SCATTER_GLOBAL)
     reg = W.RegistrationCuda(None, ctx)
     del lm
 
@@ -122,8 +124,9 @@ def main():
         step()
     fence()
     its.clear()
-    tsdf_mask = sum(1 << k for k in (_lib.WS_K_MARCH_EMIT, _lib.WS_K_RESOLVE, _lib.WS_K_MARCH_COLLECT, _lib.WS_K_RESOLVE_LISTS,
-                                      _lib.WS_K_INTEGRATE))
+    tsdf_classes = (_lib.WS_K_MARCH_EMIT, _lib.WS_K_RESOLVE, _lib.WS_K_MARCH_COLLECT, _lib.WS_K_RESOLVE_LISTS, _lib.WS_K_INTEGRATE,
+                    _lib.WS_K_TILE_BIN, _lib.WS_K_TILE_SCATTER)
+    tsdf_mask = sum(1 << k for k in tsdf_classes)
     ctx.prof_reset()
     ctx.prof_enable(tsdf_mask)  # hipEvents around the 5 TSDF kernels of every step, on the stream they run on
     fence()
@@ -137,7 +140,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = {}
-    for k, name in enumerate(_lib.KERNEL_CLASSES[:5]):
+    for k in tsdf_classes:
+        name = _lib.KERNEL_CLASSES[k]
         ms, cnt = ctx.prof_read(k)
         if cnt:
             kernels[name] = {"avg_us": 1000.0 * ms / cnt, "launches": cnt}

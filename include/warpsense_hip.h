@@ -101,13 +101,20 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
+/* scatter implementation: LDS-staged tiles (default) or the global-key path (always used when new_map is not (tau,0)) */
+#define WS_SCATTER_TILES 0
+#define WS_SCATTER_GLOBAL 1
+int ws_tsdf_set_scatter(ws_map *map, int mode);
 
 typedef struct
 {
   int64_t contested_voxels;  /* voxels resolved by the exact ordered fallback in the last update */
-  int64_t contested_records; /* candidate records collected for them                              */
+  int64_t contested_records; /* candidate records in the shared overflow area of the arena        */
   int64_t dirty_tiles;       /* 64-voxel tiles streamed by the last sparse integrate              */
-  int32_t error_flags;       /* bit0 arena overflow, bit1 order-key range                         */
+  int32_t error_flags;       /* bit0 arena / record capacity exceeded, bit1 order-key range       */
+  int32_t pad;
+  int64_t tile_records;      /* (ray, step-run) records binned by the LDS-tile path                */
+  int64_t tile_work_items;   /* workgroups-worth of tile work of the last update                   */
 } ws_tsdf_stats_t;
 int ws_tsdf_stats(ws_map *map, ws_tsdf_stats_t *out); /* synchronises */
 
@@ -145,7 +152,9 @@ int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out
 #define WS_K_RESOLVE_LISTS 3  /* ordered fold of those lists                                  */
 #define WS_K_INTEGRATE 4      /* dense or sparse weighted-average pass (cu_avg_tsdf_krnl)     */
 #define WS_K_REG 5            /* one Gauss-Newton iteration (accumulate + finish/solve)       */
-#define WS_K_COUNT 6
+#define WS_K_TILE_BIN 6       /* LDS-tile path: count + scan + fill of the per-tile ray records */
+#define WS_K_TILE_SCATTER 7   /* LDS-tile path: march + resolve + integrate per tile           */
+#define WS_K_COUNT 8
 int ws_prof_enable(ws_context *ctx, uint32_t class_mask); /* 0 disables */
 /* sum of event-measured durations and number of launches per class since the last reset (synchronises) */
 int ws_prof_read(ws_context *ctx, int kernel_class, double *total_ms, int64_t *launches);

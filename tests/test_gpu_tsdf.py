@@ -13,12 +13,16 @@ def _torch():
     return torch
 
 
-def make_pair(size, tau, res, max_weight, default_weight=0):
+SCATTER_MODES = ["tiles", "global"]
+
+
+def make_pair(size, tau, res, max_weight, default_weight=0, scatter="tiles"):
     import warpsense_amd as W
     lm = W.LocalMap(size[0], size[1], size[2], tau, default_weight)
     om_avg = O.OracleMap(size, tau, default_weight)
     om_new = om_avg.copy()
     t = W.TSDFCuda(lm.device_map(), tau, max_weight, res)
+    t.set_scatter(W.WS_SCATTER_TILES if scatter == "tiles" else W.WS_SCATTER_GLOBAL)
     return lm, t, om_avg, om_new
 
 
@@ -29,10 +33,11 @@ def download(t, lm, which):
     return host.data_
 
 
-def test_kat_tsdf_write():
+@pytest.mark.parametrize("scatter", SCATTER_MODES)
+def test_kat_tsdf_write(scatter):
     """test/map.cpp:9-90 / test/cuda.cpp:268-414: one point, res 1000, tau 3000, 21^3 map."""
     tau, res, mw = 3000, 1000, 640
-    lm, t, oa, on = make_pair((20, 20, 20), tau, res, mw)
+    lm, t, oa, on = make_pair((20, 20, 20), tau, res, mw, scatter=scatter)
     pts = np.array([[5500, 500, 500]], dtype=np.int32)
     t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
     avg = download(t, lm, 0)
@@ -44,13 +49,14 @@ def test_kat_tsdf_write():
     assert np.all(new == O.pack(tau, 0))
 
 
+@pytest.mark.parametrize("scatter", SCATTER_MODES)
 @pytest.mark.parametrize("tau,res,size,rings,az", [(1000, 50, (128, 128, 64), 32, 256), (600, 64, (100, 100, 60), 16, 512),
                                                    (1000, 20, (160, 160, 80), 24, 128)])
-def test_scatter_matches_oracle(tau, res, size, rings, az):
+def test_scatter_matches_oracle(tau, res, size, rings, az, scatter):
     """new_map after the scatter == serial reference kernel (oracle wso_update_min), bit for bit."""
     torch = _torch()
     mw = 640
-    lm, t, oa, on = make_pair(size, tau, res, mw)
+    lm, t, oa, on = make_pair(size, tau, res, mw, scatter=scatter)
     he = (size[0] * res * 0.4, size[1] * res * 0.35, size[2] * res * 0.3)
     pts = S.os1_128_scan(rings=rings, azimuths=az, half_extents_mm=he, seed=7)
     st = O.update_min(on, pts, (0, 0, 0), (0, 0, 32768), tau, res)
@@ -64,12 +70,13 @@ def test_scatter_matches_oracle(tau, res, size, rings, az):
     assert mism.size == 0, f"{mism.size} voxels differ, first {mism[:5]}, contested={stats}"
 
 
-def test_three_scans_avg_matches_oracle():
+@pytest.mark.parametrize("scatter", SCATTER_MODES)
+def test_three_scans_avg_matches_oracle(scatter):
     """avg_map after 3 successive updates (moving sensor) is bit-exact; new_map is back to (tau,0)."""
     torch = _torch()
     tau, res, mw = 1000, 50, 640
     size = (128, 128, 64)
-    lm, t, oa, on = make_pair(size, tau, res, mw)
+    lm, t, oa, on = make_pair(size, tau, res, mw, scatter=scatter)
     he = (2500.0, 2200.0, 900.0)
     for k, sensor in enumerate([(0, 0, 0), (120, -40, 10), (260, 30, -20)]):
         pts = S.os1_128_scan(sensor_mm=sensor, rings=32, azimuths=256, half_extents_mm=he, seed=11 + k)

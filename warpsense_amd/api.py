@@ -332,11 +332,15 @@ class TSDFCuda:
     def set_integrate(self, mode: int):
         check(self._L.ws_tsdf_set_integrate(self.handle, int(mode)), "ws_tsdf_set_integrate")
 
+    def set_scatter(self, mode: int):
+        check(self._L.ws_tsdf_set_scatter(self.handle, int(mode)), "ws_tsdf_set_scatter")
+
     def stats(self) -> dict:
         st = _lib.TsdfStats()
         check(self._L.ws_tsdf_stats(self.handle, C.byref(st)), "ws_tsdf_stats")
         return {"contested_voxels": st.contested_voxels, "contested_records": st.contested_records,
-                "dirty_tiles": st.dirty_tiles, "error_flags": st.error_flags}
+                "dirty_tiles": st.dirty_tiles, "error_flags": st.error_flags, "tile_records": st.tile_records,
+                "tile_work_items": st.tile_work_items}
 
     def device_map(self):
         return self.handle

@@ -16,8 +16,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
-SOURCES = ["api.hip", "tsdf_update.hip", "registration.hip"]
-HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_device.h"),
+SOURCES = ["api.hip", "tsdf_update.hip", "tsdf_tiles.hip", "registration.hip"]
+HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_device.h"), os.path.join(CSRC, "ws_march.h"),
+           os.path.join(CSRC, "ws_tiles.h"),
            os.path.join(ROOT, "include", "warpsense_hip.h")]
 ARCH = "gfx950"
 

@@ -167,7 +167,8 @@ static int map_free(ws_map *m)
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
   void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->dirty_list, m->rays, m->scan_dev,
-                  m->counters, m->arena, m->contested_per_wave};
+                  m->counters, m->arena, m->contested_per_wave, m->tile_count, m->tile_offset, m->tile_cursor, m->tile_records,
+                  m->tile_work, m->tile_state};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -225,6 +226,22 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));
   TRY(hipMalloc((void **)&m->contested_per_wave, 8192 * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->contested_per_wave, 0, 8192 * sizeof(uint32_t), s));
+  {
+    // LDS-tile scatter: 8 x 8 x 16 tiles of the ring buffer
+    const int64_t ntx = (size[0] + 7) >> 3, nty = (size[1] + 7) >> 3, ntz = (size[2] + 15) >> 4;
+    m->n_tiles3d = ntx * nty * ntz;
+    m->tile_records_cap = 64u << 20; // 64 Mi run records (512 MiB); a 131 072-point scan needs ~8 Mi
+    m->tile_work_cap = (uint32_t)(m->n_tiles3d + (m->tile_records_cap >> 11) + 1024);
+    TRY(hipMalloc((void **)&m->tile_count, (size_t)m->n_tiles3d * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&m->tile_offset, (size_t)m->n_tiles3d * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&m->tile_cursor, (size_t)m->n_tiles3d * sizeof(uint32_t)));
+    TRY(hipMalloc((void **)&m->tile_records, (size_t)m->tile_records_cap * sizeof(uint64_t)));
+    TRY(hipMalloc((void **)&m->tile_work, (size_t)m->tile_work_cap * 16));
+    TRY(hipMalloc((void **)&m->tile_state, 16));
+    TRY(hipMemsetAsync(m->tile_count, 0, (size_t)m->n_tiles3d * sizeof(uint32_t), s));
+    TRY(hipMemsetAsync(m->tile_cursor, 0, (size_t)m->n_tiles3d * sizeof(uint32_t), s));
+    TRY(hipMemsetAsync(m->tile_state, 0, 16, s));
+  }
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
   TRY(hipMemsetAsync(m->kpos, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
   TRY(hipMemsetAsync(m->kneg, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
@@ -310,6 +327,13 @@ int ws_tsdf_set_integrate(ws_map *m, int mode)
   return WS_OK;
 }
 
+int ws_tsdf_set_scatter(ws_map *m, int mode)
+{
+  if (!m || (mode != WS_SCATTER_TILES && mode != WS_SCATTER_GLOBAL)) return invalid("ws_tsdf_set_scatter: bad argument");
+  m->scatter_mode = mode;
+  return WS_OK;
+}
+
 int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
@@ -321,7 +345,7 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     set_error(buf);
     return WS_ERR_TOO_MANY_POINTS;
   }
-  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up);
+  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
   if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
   return rc;
 }
@@ -343,7 +367,8 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
     return WS_ERR_TOO_MANY_POINTS;
   }
   // scatter with the map's current state flag, integrate with the same flag (dense if new_map was not default)
-  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up);
+  // with the sparse integrate the tile path folds cu_avg_tsdf_krnl into its write-back (new_map stays (tau, 0))
+  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
   if (rc != WS_OK) return rc;
   return launch_tsdf_integrate(m);
 }
@@ -372,6 +397,14 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   WS_HIP(hipMemcpyAsync(m->counters_host, m->counters, sizeof(TsdfCounters), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
   out->contested_voxels = m->counters_host->last_contested;
+  {
+    uint32_t ts[4] = {0, 0, 0, 0};
+    WS_HIP(hipMemcpyAsync(ts, m->tile_state, sizeof ts, hipMemcpyDeviceToHost, m->ctx->stream));
+    WS_HIP(hipStreamSynchronize(m->ctx->stream));
+    out->contested_voxels += ts[2];
+    out->tile_records = ts[1];
+    out->tile_work_items = ts[0];
+  }
   out->contested_records = m->counters_host->records;
   out->dirty_tiles = m->counters_host->last_dirty_tiles;
   out->error_flags = (int32_t)m->counters_host->error;

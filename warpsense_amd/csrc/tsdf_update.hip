@@ -24,6 +24,7 @@
 #include <cstddef>
 
 #include "ws_march.h"
+#include "ws_tiles.h"
 
 namespace ws
 {
@@ -531,7 +532,7 @@ int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n)
   return WS_OK;
 }
 
-int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
+int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
@@ -593,13 +594,45 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 grid_list(LIST_GRID_BLOCKS);
   const bool s0 = !m->new_is_default;
 
-  prof_begin(ctx, WS_K_MARCH_EMIT);
+  // LDS-tile path: needs new_map == (tau, 0) (its local resolve starts every voxel from that state)
+  const bool tiles = m->scatter_mode == WS_SCATTER_TILES && !s0;
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, ma);
-  if (s0)
-    hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
+  if (tiles)
+  {
+    TileArgs ta;
+    ta.rays = ma.rays;
+    ta.n = ma.n;
+    ta.frame = make_march_frame(ma.scanner_pos, m->res, m->tau, ma.map);
+    ta.grid = make_tile_grid(ma.map);
+    ta.n_tiles = m->n_tiles3d;
+    ta.tile_count = m->tile_count;
+    ta.tile_offset = m->tile_offset;
+    ta.tile_cursor = m->tile_cursor;
+    ta.records = m->tile_records;
+    ta.records_cap = m->tile_records_cap;
+    ta.work = (uint4 *)m->tile_work;
+    ta.work_cap = m->tile_work_cap;
+    ta.tile_state = (TileState *)m->tile_state;
+    ta.kpos = m->kpos;
+    ta.kneg = m->kneg;
+    ta.dirty = m->dirty;
+    ta.new_data = m->data[WS_MAP_NEW];
+    ta.avg_data = m->data[WS_MAP_AVG];
+    ta.max_weight = m->max_weight;
+    ta.counters = m->counters;
+    WS_HIP(hipMemsetAsync(m->tile_state, 0, sizeof(TileState), s));
+    int rc = launch_tile_path(m, ta, n, fused);
+    if (rc != WS_OK) return rc;
+  }
   else
-    hipLaunchKernelGGL((march_kernel<MARCH_EMIT, false>), grid_rays, block, 0, s, ma);
-  prof_end(ctx, WS_K_MARCH_EMIT);
+  {
+    prof_begin(ctx, WS_K_MARCH_EMIT);
+    if (s0)
+      hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
+    else
+      hipLaunchKernelGGL((march_kernel<MARCH_EMIT, false>), grid_rays, block, 0, s, ma);
+    prof_end(ctx, WS_K_MARCH_EMIT);
+  }
 
   prof_begin(ctx, WS_K_RESOLVE);
   {

@@ -115,6 +115,15 @@ struct ws_map
   ws::ContestedRecord *arena = nullptr;
   uint32_t arena_cap = 0;
   uint32_t *contested_per_wave = nullptr; // statistics, one slot per wave of the resolve pass
+  // LDS-tile scatter (tsdf_tiles.hip)
+  int scatter_mode = WS_SCATTER_TILES;
+  int64_t n_tiles3d = 0;
+  uint32_t *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr;
+  uint64_t *tile_records = nullptr;
+  uint32_t tile_records_cap = 0;
+  void *tile_work = nullptr; // uint4 per work item
+  uint32_t tile_work_cap = 0;
+  void *tile_state = nullptr;
   ws::TsdfCounters *counters_host = nullptr; // pinned
 };
 
@@ -150,7 +159,7 @@ void prof_begin(ws_context *ctx, int cls);
 void prof_end(ws_context *ctx, int cls);
 
 // launchers implemented in the .hip files
-int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
+int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 int launch_tsdf_integrate(ws_map *m);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
 int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n);
