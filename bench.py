@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--map", type=int, default=512, help="map edge in voxels (the reference forces it odd: 513)")
     ap.add_argument("--resolution", type=int, default=50)
     ap.add_argument("--integrate", choices=["sparse", "dense"], default="sparse")
-    ap.add_argument("--scatter", choices=["tiles", "global"], default="tiles")
+    ap.add_argument("--scatter", choices=["tiles", "global"], default="global")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-registration", action="store_true", help="time the TSDF update alone (diagnostics)")
     return ap.parse_args()

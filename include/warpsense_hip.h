@@ -101,7 +101,8 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* scatter implementation: LDS-staged tiles (default) or the global-key path (always used when new_map is not (tau,0)) */
+/* scatter implementation: the global-key path (default; always used when new_map is not (tau,0)) or the experimental
+ * LDS-staged tile path (bit-identical results) */
 #define WS_SCATTER_TILES 0
 #define WS_SCATTER_GLOBAL 1
 int ws_tsdf_set_scatter(ws_map *map, int mode);

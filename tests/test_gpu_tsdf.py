@@ -16,7 +16,7 @@ def _torch():
 SCATTER_MODES = ["tiles", "global"]
 
 
-def make_pair(size, tau, res, max_weight, default_weight=0, scatter="tiles"):
+def make_pair(size, tau, res, max_weight, default_weight=0, scatter="global"):
     import warpsense_amd as W
     lm = W.LocalMap(size[0], size[1], size[2], tau, default_weight)
     om_avg = O.OracleMap(size, tau, default_weight)

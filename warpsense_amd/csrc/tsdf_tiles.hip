@@ -33,7 +33,7 @@ namespace ws
 constexpr int TB_X = 3, TB_Y = 3, TB_Z = 4; // tile = 8 x 8 x 16 voxels of ring-index space
 constexpr int TSX = 1 << TB_X, TSY = 1 << TB_Y, TSZ = 1 << TB_Z;
 constexpr int TILE_VOX = TSX * TSY * TSZ; // 1024
-constexpr uint32_t TILE_PMAX = 2048;      // records per work item
+constexpr uint32_t TILE_PMAX = 256;       // records per work item (their ray set-ups are staged in LDS)
 constexpr int BIN_RAYS = 64, BIN_LANES = 4;
 constexpr int HASH_SLOTS = 512, HASH_PROBES = 24;
 constexpr uint32_t HASH_EMPTY = 0xffffffffu;
@@ -349,11 +349,23 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
   __shared__ uint32_t result[TILE_VOX];
   __shared__ uint8_t vstate[TILE_VOX];
   __shared__ uint32_t n_active;
+  __shared__ uint32_t step_prefix[TILE_PMAX + 1]; // exclusive prefix of the records' step counts
+  __shared__ uint32_t wave_sums[4];
+  __shared__ RaySetup rays_sh[TILE_PMAX];         // one global round trip per item instead of two per record and lane
+  __shared__ uint64_t recs_sh[TILE_PMAX];
 
   const MarchFrame &f = a.frame;
   const int32_t weight_epsilon = f.weight_epsilon;
   const uint32_t n_work = a.tile_state->work_count;
   uint32_t contested_total = 0;
+#ifdef WS_TILE_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+  unsigned long long nrounds = 0, nitems = 0, nrecs = 0, nsteps = 0;
+#define TSTAMP(i) { long long now__ = wall_clock64(); tacc[i] += now__ - tlast; tlast = now__; }
+#else
+#define TSTAMP(i)
+#endif
 
   for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x)
   {
@@ -372,15 +384,74 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
     }
     if (threadIdx.x == 0) n_active = 0;
     __syncthreads();
+    TSTAMP(0);
+
+    // ---- balance: the item's records hold 1..250 steps each; lanes get equal shares of STEPS, not of records
+    // (one record per lane left ~70 % of the lanes idle).  step_prefix[i] = steps of records 0..i-1.
+    {
+      // n_rec <= TILE_PMAX == 256: one record per lane
+      const uint32_t i = threadIdx.x;
+      uint64_t rec = 0;
+      if (i < n_rec)
+      {
+        rec = a.records[first + i];
+        recs_sh[i] = rec;
+        rays_sh[i] = a.rays[(uint32_t)(rec >> 24)];
+      }
+      const uint32_t cnt = (uint32_t)(rec & 0xffu);
+      uint32_t x = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+      {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((threadIdx.x & 63) >= d) x += y;
+      }
+      if ((threadIdx.x & 63) == 63) wave_sums[threadIdx.x >> 6] = x;
+      __syncthreads();
+      uint32_t before = 0;
+      for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += wave_sums[wv];
+      if (i < n_rec) step_prefix[i] = before + x - cnt;
+      if (threadIdx.x == 0) step_prefix[n_rec] = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+      __syncthreads();
+    }
+    const uint32_t total_steps = step_prefix[n_rec];
+    const uint32_t share = (total_steps + 255u) / 256u;
+    const uint32_t my_lo = min(threadIdx.x * share, total_steps), my_hi = min(my_lo + share, total_steps);
+    // first record whose step range reaches beyond my_lo
+    uint32_t my_rec = 0;
+    {
+      uint32_t lo = 0, hi = n_rec; // invariant: step_prefix[lo] <= my_lo < step_prefix[hi]
+      while (hi - lo > 1)
+      {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (step_prefix[mid] <= my_lo)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      my_rec = lo;
+    }
+    // call body(ray, setup, ka, kb) for every (partial) record of this lane's share
+    auto for_my_steps = [&](auto &&body) {
+      uint32_t pos = my_lo, rec_i = my_rec;
+      while (pos < my_hi)
+      {
+        const uint64_t rec = recs_sh[rec_i];
+        const uint32_t ray = (uint32_t)(rec >> 24);
+        const int32_t rk0 = (int32_t)((rec >> 8) & 0xffffu);
+        const uint32_t rec_lo = step_prefix[rec_i], rec_hi = step_prefix[rec_i + 1];
+        const uint32_t seg_hi = min(rec_hi, my_hi);
+        const RaySetup r = rays_sh[rec_i];
+        body(ray, r, rk0 + (int32_t)(pos - rec_lo), rk0 + (int32_t)(seg_hi - rec_lo));
+        pos = seg_hi;
+        rec_i += 1;
+      }
+    };
+    TSTAMP(5);
 
     // ---- pass 1: every candidate of the recorded runs that lands in this tile -> LDS keys
-    for (uint32_t i = threadIdx.x; i < n_rec; i += 256)
-    {
-      const uint64_t rec = a.records[first + i];
-      const uint32_t ray = (uint32_t)(rec >> 24);
-      const int32_t k0 = (int32_t)((rec >> 8) & 0xffffu), n = (int32_t)(rec & 0xffu);
-      const RaySetup r = a.rays[ray];
-      march_steps(f, r, k0, k0 + n, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+    for_my_steps([&](uint32_t ray, const RaySetup &r, int32_t ka, int32_t kb) {
+      march_steps(f, r, ka, kb, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
         int32_t xi, yi, zi;
         ring_coords(f.map, vx, vy, vz, xi, yi, zi);
         if ((xi >> TB_X) != tx || (yi >> TB_Y) != ty || (zi >> TB_Z) != tz) return;
@@ -391,8 +462,12 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
         else
           atomicMin((unsigned long long *)&kneg[v], (unsigned long long)make_kneg(t, value));
       });
-    }
+    });
     __syncthreads();
+    TSTAMP(1);
+#ifdef WS_TILE_TIMING
+    nitems += 1; nrecs += n_rec;
+#endif
 
     // voxel v of the tile <-> linear index in the maps
     auto global_index = [&](int v, bool &inside) -> int64_t {
@@ -461,6 +536,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
     }
     __syncthreads();
     contested_total += (threadIdx.x == 0) ? n_active : 0;
+    TSTAMP(2);
 
     // ---- contested voxels: one accepted candidate per round, in key order (atomic_tsdf_min's rule,
     // cuda/util.h:70-102: accept iff stored weight <= 0 and |new| <= |stored|)
@@ -469,13 +545,8 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
       for (int v = threadIdx.x; v < TILE_VOX; v += 256)
         if (vstate[v] == VS_ACTIVE) kpos[v] = KEY_INF;
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < n_rec; i += 256)
-      {
-        const uint64_t rec = a.records[first + i];
-        const uint32_t ray = (uint32_t)(rec >> 24);
-        const int32_t k0 = (int32_t)((rec >> 8) & 0xffffu), n = (int32_t)(rec & 0xffu);
-        const RaySetup r = a.rays[ray];
-        march_steps(f, r, k0, k0 + n, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+      for_my_steps([&](uint32_t ray, const RaySetup &r, int32_t ka, int32_t kb) {
+        march_steps(f, r, ka, kb, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
           int32_t xi, yi, zi;
           ring_coords(f.map, vx, vy, vz, xi, yi, zi);
           if ((xi >> TB_X) != tx || (yi >> TB_Y) != ty || (zi >> TB_Z) != tz) return;
@@ -487,7 +558,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
           if (t + 1 <= (st >> 16) || av > (int32_t)(st & 0xffffu)) return; // already folded, or rejected by the current state
           atomicMin((unsigned long long *)&kpos[v], (unsigned long long)((t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu)));
         });
-      }
+      });
       __syncthreads();
       if (threadIdx.x == 0) n_active = 0;
       __syncthreads();
@@ -516,7 +587,11 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
         }
       }
       __syncthreads();
+#ifdef WS_TILE_TIMING
+      nrounds += 1;
+#endif
     }
+    TSTAMP(3);
 
     // ---- write-back, rows of 16 voxels along z (64 B) per 16 lanes
     for (int v = threadIdx.x; v < TILE_VOX; v += 256)
@@ -541,7 +616,13 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileArgs a)
       }
     }
     __syncthreads();
+    TSTAMP(4);
   }
+#ifdef WS_TILE_TIMING
+  if (threadIdx.x == 0 && (blockIdx.x == 5 || blockIdx.x == 1000))
+    printf("tile blk %d: items %llu recs %llu rounds %llu mysteps %llu | ticks(10ns): init %lld loads %lld march %lld classify %lld rounds %lld writeback %lld\n", blockIdx.x, nitems, nrecs,
+           nrounds, nsteps, tacc[0], tacc[5], tacc[1], tacc[2], tacc[3], tacc[4]);
+#endif
   if (threadIdx.x == 0 && contested_total) atomicAdd(&a.tile_state->contested, contested_total);
 }
 

@@ -158,6 +158,14 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
           const FastDiv fd = make_fastdiv(distance);
           r.div_m = fd.M;
           r.div_k = fd.k;
+          // conditions of march_steps_fast (ws_march.h): no int32 wrap in d*len, pos + d, voxel centres,
+          // delta_z*iv and step*res*iv
+          const int64_t dmax = max(max(llabs((long long)dx), llabs((long long)dy)), llabs((long long)dz));
+          const int64_t pmax = max(max(llabs((long long)posx), llabs((long long)posy)), llabs((long long)posz));
+          const int64_t ivmax = max(max(llabs(ivx), llabs(ivy)), llabs(ivz));
+          const bool fast = dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
+                            (2 * max_delta_z + res) * ivmax < (1ll << 31);
+          r.pad = fast ? 1 : 0;
         }
       }
     }

@@ -116,7 +116,7 @@ struct ws_map
   uint32_t arena_cap = 0;
   uint32_t *contested_per_wave = nullptr; // statistics, one slot per wave of the resolve pass
   // LDS-tile scatter (tsdf_tiles.hip)
-  int scatter_mode = WS_SCATTER_TILES;
+  int scatter_mode = WS_SCATTER_GLOBAL; // the LDS-tile path is exact but not yet faster
   int64_t n_tiles3d = 0;
   uint32_t *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr;
   uint64_t *tile_records = nullptr;

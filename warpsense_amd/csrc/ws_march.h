@@ -15,7 +15,7 @@ struct RaySetup // 48 bytes
   int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
   uint64_t div_m;        // multiply-shift constants for the division by `distance`
   int32_t div_k;
-  int32_t pad;
+  int32_t pad; // non-zero: the division-free walk (march_steps_fast) is exact for this ray
 };
 static_assert(sizeof(RaySetup) == 48, "ws_map::rays is sized for 48-byte records");
 
@@ -80,7 +80,7 @@ __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos
 // write_tsdf_min the reference would issue (update_tsdf.cu:67-125): voxel in bounds, weight != 0.
 // `positive` = on-ray entry (step == mid, positive weight), else the weight is negated.
 template <class Emit>
-__device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
+__device__ __forceinline__ void march_steps_direct(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
   const int64_t MR = MATRIX_RESOLUTION;
   const int32_t res = f.res, half = f.half, tau = f.tau;
@@ -131,6 +131,190 @@ __device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup 
       emit(k, step, vx, vy, vz, value, step == mid);
     }
   }
+}
+
+// ---- the same walk without a division or a 64-bit multiply per step ------------------------------------
+// 32-bit integer multiplies are quarter rate on CDNA and the direct form needs ~40 of them per step
+// (six multiply-shift divisions, three 64-bit products per fan step): ~700 cycles per wave and step,
+// ~300 us of pure ALU for one pass over a 131 072-ray scan.  Everything below is exact:
+//   * |d|*len = q*dist + r is carried from step to step (len grows by res/2: add the per-ray increment
+//     |d|*(res/2) = aq*dist + ar, carry once) — trunc(d*len/dist) = sign(d)*q;
+//   * proj moves by less than one voxel per step, so floor(proj/res) and the remainder are carried too;
+//     trunc(x/res) = floor unless x < 0 with a non-zero remainder;
+//   * fan offsets are small: delta_z*iv and step*res*iv fit 32 bits, /32768 toward zero is a shift.
+// RaySetup.pad != 0 marks rays for which all of this holds without int32 wrap (always, inside the
+// reference's own no-overflow domain); other rays use march_steps_direct.
+struct AxisWalk
+{
+  int32_t q, r;    // |d| * len = q * dist + r
+  int32_t aq, ar;  // per-step increment of (q, r)
+  int32_t neg;     // d < 0
+  int32_t pos;     // ray origin on this axis
+  int32_t proj;    // pos + sign(d) * q            == update_tsdf.cu:69
+  int32_t fi, rem; // floor(proj / res) and proj - fi * res in [0, res)
+};
+__device__ __forceinline__ int32_t trunc_shift15(int32_t p) { return (p + ((p >> 31) & (MATRIX_RESOLUTION - 1))) >> 15; }
+
+__device__ __forceinline__ void axis_init(AxisWalk &w, const MarchFrame &f, const RaySetup &r, int32_t d, int32_t pos, int32_t k)
+{
+  const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+  w.neg = d < 0 ? 1 : 0;
+  w.pos = pos;
+  const uint32_t inc = ad * (uint32_t)f.half;
+  w.aq = (int32_t)(((uint64_t)inc * r.div_m) >> r.div_k);
+  w.ar = (int32_t)(inc - (uint32_t)w.aq * (uint32_t)r.distance);
+  const uint32_t n = ad * (uint32_t)(1 + k * f.half);
+  w.q = (int32_t)(((uint64_t)n * r.div_m) >> r.div_k);
+  w.r = (int32_t)(n - (uint32_t)w.q * (uint32_t)r.distance);
+  w.proj = w.neg ? pos - w.q : pos + w.q;
+  const int32_t t = div_trunc(w.proj, f.rM, f.rK, f.res);
+  w.fi = t - ((w.proj < 0 && t * f.res != w.proj) ? 1 : 0);
+  w.rem = w.proj - w.fi * f.res;
+}
+__device__ __forceinline__ void axis_step(AxisWalk &w, int32_t dist, int32_t res)
+{
+  w.r += w.ar;
+  int32_t dq = w.aq;
+  if (w.r >= dist)
+  {
+    w.r -= dist;
+    dq += 1;
+  }
+  w.q += dq;
+  const int32_t dp = w.neg ? -dq : dq; // |dp| <= res/2 + 1 <= res
+  w.proj += dp;
+  w.rem += dp;
+  if (w.rem >= res)
+  {
+    w.rem -= res;
+    w.fi += 1;
+  }
+  else if (w.rem < 0)
+  {
+    w.rem += res;
+    w.fi -= 1;
+  }
+}
+// trunc(proj / res)
+__device__ __forceinline__ int32_t axis_index(const AxisWalk &w) { return w.fi + ((w.proj < 0 && w.rem != 0) ? 1 : 0); }
+// centre of that voxel minus `from`, without a multiply: index * res = proj - rem (+ res when the index was bumped)
+__device__ __forceinline__ int32_t axis_centre_delta(const AxisWalk &w, int32_t from, int32_t res, int32_t half)
+{
+  const int32_t base = w.proj - w.rem + ((w.proj < 0 && w.rem != 0) ? res : 0);
+  return from - (base + half);
+}
+// trunc((proj + e) / res) from the carried floor/remainder of proj; |e| is a few voxels at most
+__device__ __forceinline__ int32_t axis_index_offset(const AxisWalk &w, int32_t e, const MarchFrame &f)
+{
+  const int32_t res = f.res;
+  int32_t rem = w.rem + e, fi = w.fi;
+  if (rem >= res)
+  {
+    rem -= res;
+    fi += 1;
+    if (rem >= res)
+    {
+      const int32_t m = div_trunc(rem, f.rM, f.rK, res);
+      fi += m;
+      rem -= m * res;
+    }
+  }
+  else if (rem < 0)
+  {
+    rem += res;
+    fi -= 1;
+    if (rem < 0)
+    {
+      const int32_t m = div_trunc(res - 1 - rem, f.rM, f.rK, res); // ceil(-rem / res)
+      fi -= m;
+      rem += m * res;
+    }
+  }
+  return fi + ((w.proj + e < 0 && rem != 0) ? 1 : 0);
+}
+
+template <class Emit>
+__device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
+{
+  const int32_t res = f.res, half = f.half, tau = f.tau;
+  const int32_t px = f.posx + r.dx, py = f.posy + r.dy, pz = f.posz + r.dz;
+  AxisWalk wx, wy, wz;
+  const int32_t kstart = k0 > 0 ? k0 - 1 : 0;
+  axis_init(wx, f, r, r.dx, f.posx, kstart);
+  axis_init(wy, f, r, r.dy, f.posy, kstart);
+  axis_init(wz, f, r, r.dz, f.posz, kstart);
+  int32_t prevx = 0, prevy = 0;
+  if (k0 > 0)
+  {
+    prevx = axis_index(wx);
+    prevy = axis_index(wy);
+    axis_step(wx, r.distance, res);
+    axis_step(wy, r.distance, res);
+    axis_step(wz, r.distance, res);
+  }
+  int32_t len = 1 + k0 * half;
+  int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
+  for (int32_t k = k0; k < k1; ++k, len += half)
+  {
+    if (k > k0)
+    {
+      axis_step(wx, r.distance, res);
+      axis_step(wy, r.distance, res);
+      axis_step(wz, r.distance, res);
+    }
+    const int32_t ixx = axis_index(wx), iyy = axis_index(wy);
+    if (ixx == prevx && iyy == prevy) continue;
+    prevx = ixx;
+    prevy = iyy;
+    const int32_t izz = axis_index(wz);
+    if (!in_bounds(f.map, ixx, iyy, izz)) continue;
+
+    int32_t value = l2norm_i(axis_centre_delta(wx, px, res, half), axis_centre_delta(wy, py, res, half), axis_centre_delta(wz, pz, res, half));
+    value = value < tau ? value : tau;
+    if (len > r.distance) value = -value;
+    if (value < -f.weight_epsilon && tsdf_weight(value, tau, f.weight_epsilon) == 0) continue;
+
+    const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
+    if (delta_z != last_dz)
+    {
+      // delta_z grows by one every 328 mm of ray: the fan base offset is recomputed a few times per ray
+      last_dz = delta_z;
+      c0x = trunc_shift15(delta_z * r.ivx);
+      c0y = trunc_shift15(delta_z * r.ivy);
+      c0z = trunc_shift15(delta_z * r.ivz);
+    }
+    int32_t iter_steps = 1, mid = 0;
+    if (delta_z * 2 >= res)
+    {
+      iter_steps = (delta_z * 2) / res + 1;
+      mid = delta_z / res;
+    }
+    for (int32_t step = 0; step < iter_steps; ++step)
+    {
+      int32_t ex = -c0x, ey = -c0y, ez = -c0z;
+      if (step)
+      {
+        const int32_t sm = step * res;
+        ex += trunc_shift15(sm * r.ivx);
+        ey += trunc_shift15(sm * r.ivy);
+        ez += trunc_shift15(sm * r.ivz);
+      }
+      const int32_t vx = axis_index_offset(wx, ex, f);
+      const int32_t vy = axis_index_offset(wy, ey, f);
+      const int32_t vz = axis_index_offset(wz, ez, f);
+      if (!in_bounds(f.map, vx, vy, vz)) continue;
+      emit(k, step, vx, vy, vz, value, step == mid);
+    }
+  }
+}
+
+template <class Emit>
+__device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
+{
+  if (r.pad)
+    march_steps_fast(f, r, k0, k1, emit);
+  else
+    march_steps_direct(f, r, k0, k1, emit);
 }
 
 // order key of a candidate: point(20) | ray step(16) | fan step(8)
