@@ -70,8 +70,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or os.environ.get("WS_BENCH_FORCE_SHARDED") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import warpsense_amd as W
     from warpsense_amd import _lib, synthetic as S
@@ -101,6 +103,7 @@ def main():
     n = points.shape[0]
     eye = np.eye(4, dtype=np.float32)
     backend = HipGnBackend(reg, tsdf, res)
+    force_sharded = os.environ.get("WS_BENCH_FORCE_SHARDED") == "1"  # exercise the multi-rank driver on one rank
     reg.prepare_registration(d_pert)  # resident in HBM before the timed region
     its = []
 
@@ -108,7 +111,7 @@ def main():
         tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
         if args.no_registration:
             return
-        if world == 1:
+        if world == 1 and not force_sharded:
             _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
         else:
             _, it = sharded_register_cloud(backend, n, eye, *reg_params)

@@ -190,6 +190,9 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
     st.finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
     return;
   }
+#ifdef WS_REG_TIMING
+  long long g0 = wall_clock64();
+#endif
   double hf[6][6], gf[6], xi[6];
   const double w = (double)(st.alpha * (float)c);
 #pragma unroll
@@ -199,6 +202,9 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
 #pragma unroll
     for (int q = 0; q < 6; ++q) hf[r][q] = (double)sums[q * 6 + r] + (r == q ? w : 0.0);
   }
+#ifdef WS_REG_TIMING
+  long long g1 = wall_clock64();
+#endif
   if (solve6(hf, gf, xi) != 0)
   {
     st.finished = 1;
@@ -206,6 +212,9 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
+#ifdef WS_REG_TIMING
+  long long g2 = wall_clock64();
+#endif
 
   // xi_to_transform
   const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
@@ -242,6 +251,9 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
     const float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
     tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), (float)xi[3 + i]);
   }
+#ifdef WS_REG_TIMING
+  long long g3 = wall_clock64();
+#endif
   st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
   float out[16];
 #pragma unroll
@@ -263,6 +275,10 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
   st.prev[1] = st.prev[2];
   st.prev[2] = st.prev[3];
   st.prev[3] = err;
+#ifdef WS_REG_TIMING
+  if (blockIdx.x == 7 && st.iterations == 21)
+    printf("gn_update ticks(10ns): build %lld solve %lld xi2T %lld rest %lld\n", g1 - g0, g2 - g1, g3 - g2, wall_clock64() - g3);
+#endif
 }
 
 struct PointArgs

@@ -43,6 +43,9 @@ struct MarchArgs
   uint64_t *kpos;
   uint64_t *kneg;
   uint8_t *dirty;
+  uint8_t *vstate;          // one byte per voxel: VOX_KEYED / VOX_TOUCHED (split scatter)
+  int32_t keyed_len_neg;    // smallest ray length with off-ray (negative-weight) candidates
+  int32_t keyed_slack;      // see keyed_first_step()
   const uint32_t *new_data; // only read when HAS_S0
   TsdfCounters *counters;
   ContestedRecord *arena;
@@ -89,9 +92,12 @@ __device__ __forceinline__ uint32_t block_alloc(uint32_t *lds_cursor, uint32_t s
 
 enum
 {
-  MARCH_EMIT = 0,
-  MARCH_COLLECT = 1
+  MARCH_EMIT = 0,       // single pass: every candidate goes through the order keys (used when new_map is not default)
+  MARCH_COLLECT = 1,    // candidate lists of contested voxels
+  MARCH_EMIT_KEYED = 2, // pass 1 of the split scatter: negative-weight and near-surface candidates -> order keys
+  MARCH_EMIT_FREE = 3   // pass 2: free-space candidates (tau, +64) -> one byte per voxel, no atomics
 };
+constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 
 // update_tsdf.cu:52-63 for one ray per lane
 __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
@@ -199,6 +205,13 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   // COLLECT only needs the steps with len = 1 + k*half >= collect_min_len
   int32_t kbeg = 0;
   if (MODE == MARCH_COLLECT && a.collect_min_len > 1) kbeg = (a.collect_min_len - 1 + half - 1) / half;
+  // Split scatter: a candidate is "free space" iff it is on-ray (positive weight) with value == +tau; all of a
+  // ray's candidates are of that kind while len < min(len_neg, distance - tau - slack): before len_neg there is
+  // no fan, and a voxel centre further than tau from the hit point gives min(dist, tau) == tau.  The slack covers
+  // |centre - proj| (1.5 voxels per axis for the double-width cell of trunc division + the fan offset).
+  const int32_t keyed_len = min(a.keyed_len_neg, r.distance - tau - a.keyed_slack);
+  const int32_t keyed_first = keyed_len > 1 ? max(0, (keyed_len - 1) / half - 1) : 0;
+  if (MODE == MARCH_EMIT_KEYED) kbeg = keyed_first;
   if (kbeg >= r.steps) return;
   const int32_t ch = (r.steps - kbeg + 31) >> 5;
   const int32_t k0 = kbeg + c * ch;
@@ -217,7 +230,37 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
       const int32_t a0 = entry_value(s0) < 0 ? -entry_value(s0) : entry_value(s0);
       if (entry_weight(s0) > 0 || (value < 0 ? -value : value) > a0) return;
     }
-    if (MODE == MARCH_EMIT)
+    if (MODE == MARCH_EMIT_KEYED || MODE == MARCH_EMIT_FREE)
+    {
+      const bool free_space = positive && value == tau;
+      if (MODE == MARCH_EMIT_FREE)
+      {
+        if (!free_space)
+        {
+          // must have been handled by the keyed pass: flag the (impossible) case instead of losing a candidate
+          if (k < keyed_first) atomicOr(&a.counters->error, 4u);
+          return;
+        }
+        const uint8_t b = a.vstate[idx];
+        if (b & VOX_KEYED)
+        {
+          // the voxel also has ordered candidates: this one takes part in the key order
+          const uint64_t key = make_kpos(t, value);
+          if (key < a.kpos[idx]) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
+        }
+        else if (b == 0)
+        {
+          // free space only (so far the common case): the result will be (tau, 64) whoever comes first
+          a.vstate[idx] = VOX_TOUCHED;
+          const int64_t tile = idx >> TILE_SHIFT;
+          if (a.dirty[tile] == 0) a.dirty[tile] = 1;
+        }
+        return;
+      }
+      if (free_space) return; // pass 2 takes it
+      if (a.vstate[idx] != VOX_KEYED) a.vstate[idx] = VOX_KEYED;
+    }
+    if (MODE == MARCH_EMIT || MODE == MARCH_EMIT_KEYED)
     {
       // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
       // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
@@ -271,6 +314,8 @@ struct ResolveArgs
   int64_t n_vox;
   int32_t tau;
   TsdfCounters *counters;
+  uint8_t *vstate;
+  int32_t split;                // the scatter used the keyed/free-space split
   uint32_t *contested_per_wave; // [LIST_GRID_BLOCKS * 4]
   const ContestedRecord *arena;
   uint32_t arena_cap;
@@ -335,6 +380,18 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
   {
     const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
     if (idx >= a.n_vox) continue;
+    if (a.split)
+    {
+      // split scatter: one byte says whether the voxel was touched at all and whether it has order keys
+      const uint8_t b = a.vstate[idx];
+      if (b == 0) continue;
+      a.vstate[idx] = 0;
+      if (!(b & VOX_KEYED))
+      {
+        a.new_data[idx] = pack_entry(a.tau, WEIGHT_RESOLUTION); // free-space candidates only
+        continue;
+      }
+    }
     const uint64_t kp = a.kpos[idx], kn = a.kneg[idx];
     if (kp == KEY_INF && kn == KEY_INF) continue; // untouched voxel: new_map keeps its entry
     bool decided = true;
@@ -564,6 +621,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.kpos = m->kpos;
   ma.kneg = m->kneg;
   ma.dirty = m->dirty;
+  ma.vstate = m->vstate;
   ma.new_data = m->data[WS_MAP_NEW];
   ma.counters = m->counters;
   ma.arena = m->arena;
@@ -582,6 +640,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     const int64_t len_neg = (dz_min * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
     const int64_t lo = len_neg - 4 * (int64_t)m->res - 2 * dz_min;
     ma.collect_min_len = lo > 1 ? (int32_t)(lo > INT32_MAX ? INT32_MAX : lo) : 1;
+    ma.keyed_len_neg = (int32_t)(len_neg > INT32_MAX ? INT32_MAX : len_neg);
+    ma.keyed_slack = (int32_t)(2 * (dz_min + 1) + 3 * (int64_t)m->res + 4);
   }
 
   ResolveArgs ra;
@@ -592,6 +652,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.n_vox = m->n_vox;
   ra.tau = m->tau;
   ra.counters = m->counters;
+  ra.vstate = m->vstate;
+  ra.split = (m->scatter_mode != WS_SCATTER_TILES && m->new_is_default) ? 1 : 0;
   ra.contested_per_wave = m->contested_per_wave;
   ra.arena = m->arena;
   ra.arena_cap = m->arena_cap;
@@ -636,9 +698,14 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   {
     prof_begin(ctx, WS_K_MARCH_EMIT);
     if (s0)
+    {
       hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
+    }
     else
-      hipLaunchKernelGGL((march_kernel<MARCH_EMIT, false>), grid_rays, block, 0, s, ma);
+    {
+      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_KEYED, false>), grid_rays, block, 0, s, ma);
+      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_FREE, false>), grid_rays, block, 0, s, ma);
+    }
     prof_end(ctx, WS_K_MARCH_EMIT);
   }
 

@@ -104,6 +104,7 @@ struct ws_map
   uint32_t *data[2] = {nullptr, nullptr};
   uint64_t *kpos = nullptr, *kneg = nullptr;
   uint8_t *dirty = nullptr;       // one flag per 64-voxel tile
+  uint8_t *vstate = nullptr;      // one byte per voxel for the split scatter (keyed / free space)
   uint32_t *dirty_list = nullptr; // touched tiles of the scan in flight
   void *rays = nullptr;           // per-ray set-up records (48 B x 1 000 000)
   int32_t tau = 0, max_weight = 0, res = 0;

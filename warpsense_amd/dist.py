@@ -68,7 +68,7 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
         todo = min(batch, max_iterations - done)
         for _ in range(todo):
             sums = backend.accumulate(first, count)
-            if world > 1:
+            if dist.is_initialized():
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
             backend.solve(sums)
         done += todo
