@@ -166,7 +166,7 @@ static int map_free(ws_map *m)
 {
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->vstate, m->dirty_list, m->rays, m->scan_dev,
+  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->vstate, m->az_hist, m->az_off, m->ray_order, m->dirty_list, m->rays, m->scan_dev,
                   m->counters, m->arena, m->contested_per_wave, m->tile_count, m->tile_offset, m->tile_cursor, m->tile_records,
                   m->tile_work, m->tile_state};
   for (void *p : ptrs)
@@ -223,6 +223,11 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMemsetAsync(m->vstate, 0, (size_t)m->n_vox, s));
   TRY(hipMalloc((void **)&m->dirty_list, (size_t)m->n_tiles * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * 48));
+  TRY(hipMalloc((void **)&m->az_hist, 1032 * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->az_off, 1032 * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(m->az_hist, 0, 1032 * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->az_off, 0, 1032 * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
   TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));

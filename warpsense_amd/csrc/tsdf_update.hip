@@ -44,6 +44,9 @@ struct MarchArgs
   uint64_t *kneg;
   uint8_t *dirty;
   uint8_t *vstate;          // one byte per voxel: VOX_KEYED / VOX_TOUCHED (split scatter)
+  uint32_t *az_hist;        // [AZ_BINS + 1] rays per azimuth bin (last bin: rays that contribute nothing)
+  uint32_t *az_off;         // [AZ_BINS + 2] exclusive scan of az_hist
+  uint32_t *ray_order;      // ray indices sorted by azimuth bin
   int32_t keyed_len_neg;    // smallest ray length with off-ray (negative-weight) candidates
   int32_t keyed_slack;      // see keyed_first_step()
   const uint32_t *new_data; // only read when HAS_S0
@@ -98,6 +101,7 @@ enum
   MARCH_EMIT_FREE = 3   // pass 2: free-space candidates (tau, +64) -> one byte per voxel, no atomics
 };
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
+constexpr int AZ_BINS = 1024;
 
 // update_tsdf.cu:52-63 for one ray per lane
 __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
@@ -176,7 +180,54 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
       }
     }
   }
+  // azimuth bin of the ray (any monotone function of the direction would do: it only groups rays that lie in
+  // the same vertical plane, whose voxels share z-columns and therefore cache lines); bin AZ_BINS = unused ray
+  uint32_t bin = AZ_BINS;
+  if (r.steps > 0)
+  {
+    const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
+    int b = (int)((az + 3.14159265f) * ((float)AZ_BINS / 6.2831853f));
+    bin = (uint32_t)(b < 0 ? 0 : (b >= AZ_BINS ? AZ_BINS - 1 : b));
+  }
+  r.pad |= (int32_t)(bin << 1);
+  atomicAdd(&a.az_hist[bin], 1u);
   a.rays[ix] = r;
+}
+
+// exclusive scan of the AZ_BINS + 1 histogram entries (one workgroup), histogram reset for use as cursors
+__global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t *off)
+{
+  __shared__ uint32_t wave_sums[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t v = hist[threadIdx.x];
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wave_sums[wave] = x;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_sums[w];
+  off[threadIdx.x] = before + x - v;
+  hist[threadIdx.x] = 0;
+  if (threadIdx.x == 1023)
+  {
+    const uint32_t last = hist[AZ_BINS]; // not yet reset: only lanes 0..1023 reset their own entry
+    off[AZ_BINS] = before + x;           // number of rays that contribute (start of the unused bin)
+    off[AZ_BINS + 1] = before + x + last;
+    hist[AZ_BINS] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void ray_scatter_kernel(MarchArgs a)
+{
+  const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
+  if (ix >= a.n) return;
+  const uint32_t bin = (uint32_t)a.rays[ix].pad >> 1;
+  a.ray_order[a.az_off[bin] + atomicAdd(&a.az_hist[bin], 1u)] = ix;
 }
 
 // 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of its ray
@@ -195,11 +246,29 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   {
     if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   }
-  const uint32_t ix = blockIdx.x * 8u + (threadIdx.x >> 5);
-  if (ix >= a.n) return;
+  // Full-ray passes: 8 rays x 32 lanes per workgroup (see above).  Tail passes (ordered candidates, contested
+  // lists) do scattered 8-byte atomics near the surface: there a wave takes 64 rays of the same azimuth bin
+  // (ray_order) at the same quarter of the tail, so its lanes hit voxels of the same vertical plane — z-neighbours,
+  // i.e. the same cache lines — and one wave-wide atomic touches a handful of lines instead of 64.
+  constexpr bool TAIL = (MODE == MARCH_EMIT_KEYED);
+  constexpr int LANES = TAIL ? 4 : 32;
+  uint32_t ix;
+  int32_t c;
+  if (TAIL)
+  {
+    const uint32_t slot = blockIdx.x * 64u + (threadIdx.x & 63u);
+    if (slot >= a.az_off[AZ_BINS]) return;
+    ix = a.ray_order[slot];
+    c = (int32_t)(threadIdx.x >> 6);
+  }
+  else
+  {
+    ix = blockIdx.x * 8u + (threadIdx.x >> 5);
+    if (ix >= a.n) return;
+    c = (int32_t)(threadIdx.x & 31u);
+  }
   const RaySetup r = a.rays[ix];
   if (r.steps == 0) return;
-  const int32_t c = threadIdx.x & 31;
   const int32_t res = a.res, tau = a.tau;
   const int32_t half = res / 2;
   // COLLECT only needs the steps with len = 1 + k*half >= collect_min_len
@@ -213,7 +282,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   const int32_t keyed_first = keyed_len > 1 ? max(0, (keyed_len - 1) / half - 1) : 0;
   if (MODE == MARCH_EMIT_KEYED) kbeg = keyed_first;
   if (kbeg >= r.steps) return;
-  const int32_t ch = (r.steps - kbeg + 31) >> 5;
+  const int32_t ch = (r.steps - kbeg + LANES - 1) / LANES;
   const int32_t k0 = kbeg + c * ch;
   const int32_t k1 = min(k0 + ch, r.steps);
   if (k0 >= k1) return;
@@ -622,13 +691,16 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.kneg = m->kneg;
   ma.dirty = m->dirty;
   ma.vstate = m->vstate;
+  ma.az_hist = m->az_hist;
+  ma.az_off = m->az_off;
+  ma.ray_order = m->ray_order;
   ma.new_data = m->data[WS_MAP_NEW];
   ma.counters = m->counters;
   ma.arena = m->arena;
   ma.arena_cap = m->arena_cap;
   {
     // half of the arena is split evenly between the workgroups, the other half is the shared overflow area
-    const uint32_t blocks = (uint32_t)((n + 7) / 8);
+    const uint32_t blocks = (uint32_t)((n + 7) / 8); // workgroups of the collect pass
     ma.arena_slice = (m->arena_cap / 2) / (blocks ? blocks : 1);
   }
   {
@@ -661,12 +733,16 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
   const dim3 grid_rays((unsigned)((n + 7) / 8));
+  const dim3 grid_tail((unsigned)((n + 63) / 64));
   const dim3 grid_list(LIST_GRID_BLOCKS);
   const bool s0 = !m->new_is_default;
 
   // LDS-tile path: needs new_map == (tau, 0) (its local resolve starts every voxel from that state)
   const bool tiles = m->scatter_mode == WS_SCATTER_TILES && !s0;
+  WS_HIP(hipMemsetAsync(m->az_hist, 0, (AZ_BINS + 1) * sizeof(uint32_t), s)); // the scatter pass leaves its cursors there
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, ma);
+  hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, s, m->az_hist, m->az_off);
+  hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, ma);
   if (tiles)
   {
     TileArgs ta;
@@ -703,7 +779,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     }
     else
     {
-      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_KEYED, false>), grid_rays, block, 0, s, ma);
+      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_KEYED, false>), grid_tail, block, 0, s, ma);
       hipLaunchKernelGGL((march_kernel<MARCH_EMIT_FREE, false>), grid_rays, block, 0, s, ma);
     }
     prof_end(ctx, WS_K_MARCH_EMIT);

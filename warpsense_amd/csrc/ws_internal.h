@@ -107,6 +107,7 @@ struct ws_map
   uint8_t *vstate = nullptr;      // one byte per voxel for the split scatter (keyed / free space)
   uint32_t *dirty_list = nullptr; // touched tiles of the scan in flight
   void *rays = nullptr;           // per-ray set-up records (48 B x 1 000 000)
+  uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by azimuth bin
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
   int integrate_mode = WS_INTEGRATE_SPARSE;

@@ -15,7 +15,7 @@ struct RaySetup // 48 bytes
   int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
   uint64_t div_m;        // multiply-shift constants for the division by `distance`
   int32_t div_k;
-  int32_t pad; // non-zero: the division-free walk (march_steps_fast) is exact for this ray
+  int32_t pad; // bit 0: the division-free walk (march_steps_fast) is exact for this ray; bits 1..: azimuth bin
 };
 static_assert(sizeof(RaySetup) == 48, "ws_map::rays is sized for 48-byte records");
 
@@ -311,7 +311,7 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
 template <class Emit>
 __device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
-  if (r.pad)
+  if (r.pad & 1)
     march_steps_fast(f, r, k0, k1, emit);
   else
     march_steps_direct(f, r, k0, k1, emit);
