@@ -436,6 +436,12 @@ __global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int6
   }
 }
 
+#ifndef DENSE_GRID
+#define DENSE_GRID 2048
+#endif
+#ifndef DENSE_UNROLL
+#define DENSE_UNROLL 4
+#endif
 constexpr int LIST_GRID_BLOCKS = 2048; // persistent grid over the touched-tile list: 8192 waves
 
 // One wave per touched 64-voxel tile (one lane per voxel), waves stride over the tile list.
@@ -615,17 +621,37 @@ __global__ __launch_bounds__(256) void integrate_dense_kernel(IntegrateArgs a)
   const uint4 reset4 = make_uint4(reset, reset, reset, reset);
   uint4 *new4 = reinterpret_cast<uint4 *>(a.new_data);
   uint4 *avg4 = reinterpret_cast<uint4 *>(a.avg_data);
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+  constexpr int U = DENSE_UNROLL; // 128-bit accesses in flight per lane and array
+  const int64_t stride = (int64_t)gridDim.x * 256 * U;
+  for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n4; base += stride)
   {
-    const uint4 f = new4[i];
-    uint4 e = avg4[i];
-    e.x = integrate_entry(e.x, f.x, a.max_weight);
-    e.y = integrate_entry(e.y, f.y, a.max_weight);
-    e.z = integrate_entry(e.z, f.z, a.max_weight);
-    e.w = integrate_entry(e.w, f.w, a.max_weight);
-    avg4[i] = e;
-    new4[i] = reset4;
+    uint4 f[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const int64_t i = base + (int64_t)u * 256;
+      if (i < n4)
+      {
+        f[u] = __builtin_nontemporal_load(&new4[i]);
+        e[u] = __builtin_nontemporal_load(&avg4[i]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const int64_t i = base + (int64_t)u * 256;
+      if (i < n4)
+      {
+        uint4 r = e[u];
+        // untouched voxels (new == (tau, 0)) leave avg as it is: only touched ones pay for the weighted average
+        if (f[u].x != reset) r.x = integrate_entry(r.x, f[u].x, a.max_weight);
+        if (f[u].y != reset) r.y = integrate_entry(r.y, f[u].y, a.max_weight);
+        if (f[u].z != reset) r.z = integrate_entry(r.z, f[u].z, a.max_weight);
+        if (f[u].w != reset) r.w = integrate_entry(r.w, f[u].w, a.max_weight);
+        __builtin_nontemporal_store(r, &avg4[i]);
+        __builtin_nontemporal_store(reset4, &new4[i]);
+      }
+    }
   }
   // tail (n_vox is odd for the reference's odd-sized maps)
   if (blockIdx.x == 0 && threadIdx.x < (a.n_vox & 3))
@@ -827,8 +853,8 @@ int launch_tsdf_integrate(ws_map *m)
   prof_begin(ctx, WS_K_INTEGRATE);
   if (dense)
   {
-    int64_t blocks = ((m->n_vox >> 2) + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    int64_t blocks = ((m->n_vox >> 2) + 256 * DENSE_UNROLL - 1) / (256 * DENSE_UNROLL);
+    if (blocks > DENSE_GRID) blocks = DENSE_GRID;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(integrate_dense_kernel, dim3((unsigned)blocks), block, 0, s, ia);
   }
