@@ -614,18 +614,20 @@ __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, con
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
 // (read new + existing, write existing + reset new), 4 voxels per lane as 128-bit accesses.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void integrate_dense_kernel(IntegrateArgs a)
 {
   const int64_t n4 = a.n_vox >> 2;
   const uint32_t reset = pack_entry(a.tau, 0);
-  const uint4 reset4 = make_uint4(reset, reset, reset, reset);
-  uint4 *new4 = reinterpret_cast<uint4 *>(a.new_data);
-  uint4 *avg4 = reinterpret_cast<uint4 *>(a.avg_data);
+  const u32x4 reset4 = {reset, reset, reset, reset};
+  u32x4 *new4 = reinterpret_cast<u32x4 *>(a.new_data);
+  u32x4 *avg4 = reinterpret_cast<u32x4 *>(a.avg_data);
   constexpr int U = DENSE_UNROLL; // 128-bit accesses in flight per lane and array
   const int64_t stride = (int64_t)gridDim.x * 256 * U;
   for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n4; base += stride)
   {
-    uint4 f[U], e[U];
+    u32x4 f[U], e[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(256) void integrate_dense_kernel(IntegrateArgs a)
       const int64_t i = base + (int64_t)u * 256;
       if (i < n4)
       {
-        uint4 r = e[u];
+        u32x4 r = e[u];
         // untouched voxels (new == (tau, 0)) leave avg as it is: only touched ones pay for the weighted average
         if (f[u].x != reset) r.x = integrate_entry(r.x, f[u].x, a.max_weight);
         if (f[u].y != reset) r.y = integrate_entry(r.y, f[u].y, a.max_weight);
