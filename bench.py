@@ -170,15 +170,27 @@ def main():
     n_vox = int(np.prod([s if s % 2 else s + 1 for s in size]))
     V, T = 35_442_598, 13_901_324  # scatter targets / distinct voxels of this scan (reproduced by the oracle)
     streamed_vox = n_vox if args.integrate == "dense" else int(stats["dirty_tiles"]) * 64
-    alg_bytes = {"march_emit": 12 * n + 4 * V + 4 * T, "integrate": 16 * streamed_vox}
+    alg_bytes = {"march_emit": 12 * n + 4 * V + 4 * T, "tile_scatter": 12 * n + 4 * V + 4 * T, "integrate": 16 * streamed_vox}
     roofline = None
-    cand = [k for k in ("march_emit", "integrate") if k in kernels]
+    cand = [k for k in ("march_emit", "tile_scatter", "integrate") if k in kernels]
     if cand:
         dom = max(cand, key=lambda k: kernels[k]["avg_us"])
         achieved = alg_bytes[dom] / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+        # HBM bytes per launch from the rocprofv3 PMC passes of the same command (profiles/), if recorded
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh).get(f"{dom}:{args.integrate}:{args.scatter}")
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[dom],
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes[dom],
                     "avg_launch_us": kernels[dom]["avg_us"]}
+        if "integrate" in kernels and dom != "integrate":
+            # the HBM-stream kernel of the update (SURVEY.md §8d holds THIS one to the bandwidth roofline)
+            ia = alg_bytes["integrate"] / (kernels["integrate"]["avg_us"] * 1e-6) / 1e9
+            roofline["integrate"] = {"achieved": ia, "frac": ia / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes["integrate"],
+                                     "avg_launch_us": kernels["integrate"]["avg_us"]}
         t_update_us = sum(kernels[k]["avg_us"] for k in kernels if k != "reg_iteration")
         b_update = 12 * n + 4 * V + 4 * T + 16 * streamed_vox
         roofline["update_total"] = {"bytes": b_update, "device_us": t_update_us,
