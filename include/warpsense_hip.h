@@ -85,6 +85,13 @@ int ws_map_upload(ws_map *map, int which, const int32_t size[3], const int32_t p
 int ws_map_set_params(ws_map *map, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3]);
 /* DeviceMapMemWrapper::to_host — device_map_wrapper.cu:85-92 (synchronises) */
 int ws_map_download(ws_map *map, int which, int32_t size[3], int32_t pos[3], int32_t offset[3], uint32_t *host_data);
+/* Device side of TSDFMapping::map_shift (src/warpsense/tsdf_mapping.cpp:97-136 + HDF5LocalMap::shift,
+ * src/map/hdf5_local_map.cpp:53-118): instead of moving the WHOLE map through the host, only the slabs that leave
+ * or enter the window are packed / unpacked.  Boxes are inclusive world-voxel ranges inside the current window;
+ * the host buffer is dense, x major, z fastest.  The caller updates pos/offset with ws_map_set_params in between
+ * (exactly the three steps of HDF5LocalMap::shift: save, move window, load).  Both synchronise. */
+int ws_map_extract_box(ws_map *map, int which, const int32_t lo[3], const int32_t hi[3], uint32_t *host_out);
+int ws_map_insert_box(ws_map *map, int which, const int32_t lo[3], const int32_t hi[3], const uint32_t *host_in);
 /* device pointer of the voxel array (uint32 per voxel, z fastest) — what DeviceMap::data_ is on the device */
 void *ws_map_device_data(ws_map *map, int which);
 int64_t ws_map_n_voxels(const ws_map *map);

@@ -1,0 +1,78 @@
+"""Device-side map shift against the host mirror of HDF5LocalMap::shift, which is itself pinned
+by the reference's map_raw test (tests/test_oracle_pins.py::test_kat_ring_buffer_shift)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps(size, tau=1000, seed=0):
+    import warpsense_amd as W
+    rng = np.random.default_rng(seed)
+    dev_lm = W.LocalMap(*size, tau, 0)
+    n = dev_lm.data.size
+    dev_lm.data[:] = W.pack_entry(rng.integers(-tau, tau + 1, n), rng.integers(-64, 641, n))
+    host_lm = W.LocalMap(*size, tau, 0)
+    host_lm.data[:] = dev_lm.data
+    params = W.Params(W.MapParams(resolution=50, max_distance=tau / 1000.0, max_weight=10, size=tuple(s * 0.05 for s in size)))
+    tm = W.TSDFMapping(params, dev_lm)
+    # make new_map the default map again (TSDFCuda copies the host map into both device maps)
+    blank = W.LocalMap(*size, tau, 0)
+    tm.tsdf().new_map().to_device(blank.device_map())
+    return W, tm, dev_lm, host_lm
+
+
+def _download(W, tm, lm, which=0):
+    host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+    (tm.tsdf().avg_map() if which == 0 else tm.tsdf().new_map()).to_host(host)
+    return host
+
+
+def test_shift_sequence_matches_host_mirror():
+    W, tm, dev_lm, host_lm = _maps((21, 17, 13))
+    for new_pos in [(3, 0, 0), (3, -4, 2), (10, -4, 2), (10, 5, -3), (-2, 5, -3), (0, 0, 0)]:
+        tm.shift_map(new_pos)
+        host_lm.shift(new_pos)
+        got = _download(W, tm, dev_lm)
+        assert list(got.pos_) == list(host_lm.pos) and list(got.offset_) == list(host_lm.offset)
+        assert np.array_equal(got.data_, host_lm.data), new_pos
+    # coming back to the origin restores every voxel (nothing was lost in the global store)
+    W2, tm2, dev2, ref = _maps((21, 17, 13))
+    assert np.array_equal(_download(W, tm, dev_lm).data_, ref.data)
+
+
+def test_box_roundtrip_and_bounds():
+    W, tm, dev_lm, host_lm = _maps((15, 15, 15), seed=3)
+    avg = tm.tsdf().avg_map()
+    lo, hi = (-7, -2, 3), (1, 4, 7)
+    box = avg.extract_box(lo, hi)
+    want = np.array([host_lm.data[host_lm.get_index(x, y, z)] for x in range(lo[0], hi[0] + 1) for y in range(lo[1], hi[1] + 1)
+                     for z in range(lo[2], hi[2] + 1)], dtype=np.uint32)
+    assert np.array_equal(box, want)
+    avg.insert_box(lo, hi, box[::-1].copy())
+    assert np.array_equal(avg.extract_box(lo, hi), box[::-1])
+    with pytest.raises(W.WsError):
+        avg.extract_box((-8, 0, 0), (0, 0, 0))  # outside the window
+
+
+def test_update_after_shift_matches_oracle():
+    """a TSDF update on the shifted window == oracle on a map with the same pos/offset."""
+    import torch
+    import warpsense_amd as W
+    tau, res, mw, size = 1000, 50, 640, (64, 64, 32)
+    lm = W.LocalMap(*size, tau, 0)
+    params = W.Params(W.MapParams(resolution=res, max_distance=1.0, max_weight=10, size=tuple(s * res / 1000.0 for s in size)))
+    tm = W.TSDFMapping(params, lm)
+    tm.shift_map((5, -3, 2))
+    sensor = (5 * res + 10, -3 * res + 7, 2 * res + 3)
+    pts = S.os1_128_scan(sensor_mm=sensor, rings=16, azimuths=128, half_extents_mm=(1400.0, 1300.0, 700.0), seed=4)
+    pos = [int(np.floor(np.float32(s) / np.float32(res))) for s in sensor]
+    tm.update_tsdf(torch.from_numpy(pts).cuda(), pos_rm=pos, up_rm=(0, 0, 32768))
+    got = _download(W, tm, lm)
+    oa = O.OracleMap(size, tau, 0, pos=lm.pos, offset=lm.offset)
+    on = oa.copy()
+    O.update_tsdf(oa, on, pts, pos, (0, 0, 32768), tau, mw, res)
+    assert np.array_equal(got.data_, oa.data)

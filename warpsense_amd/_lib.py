@@ -23,7 +23,7 @@ WS_SCATTER_TILES, WS_SCATTER_GLOBAL = 0, 1
 EXPORTS = [
     "ws_last_error", "ws_version", "ws_ctx_create", "ws_ctx_destroy", "ws_ctx_set_stream", "ws_sync",
     "ws_device_reset", "ws_map_create", "ws_map_destroy", "ws_map_upload", "ws_map_set_params", "ws_map_download",
-    "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
+    "ws_map_extract_box", "ws_map_insert_box", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
     "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_scatter", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
     "ws_reg_solve_dev", "ws_reg_poll", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
@@ -64,6 +64,8 @@ def load() -> C.CDLL:
     L.ws_map_upload.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.ws_map_set_params.argtypes = [vp, C.c_int, vp, vp, vp]
     L.ws_map_download.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.ws_map_extract_box.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ws_map_insert_box.argtypes = [vp, C.c_int, vp, vp, vp]
     L.ws_map_device_data.argtypes = [vp, C.c_int]
     L.ws_map_device_data.restype = vp
     L.ws_map_n_voxels.argtypes = [vp]

@@ -158,6 +158,36 @@ class GlobalMap:
             self.chunks[key] = c
         return c
 
+    def _box(self, lo, hi, buf, save: bool):
+        """Move a dense world-voxel box (inclusive, x major / z fastest) between `buf` and the chunks."""
+        cs = self.CHUNK_SIZE
+        lo, hi = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+        ext = hi - lo + 1
+        box = buf.reshape(int(ext[0]), int(ext[1]), int(ext[2]))
+        c0, c1 = np.floor_divide(lo, cs), np.floor_divide(hi, cs)
+        for cx in range(c0[0], c1[0] + 1):
+            for cy in range(c0[1], c1[1] + 1):
+                for cz in range(c0[2], c1[2] + 1):
+                    chunk = self.activate_chunk(cx, cy, cz).reshape(cs, cs, cs)
+                    base = np.array([cx, cy, cz], dtype=np.int64) * cs
+                    a = np.maximum(lo, base)
+                    b = np.minimum(hi, base + cs - 1)
+                    sl_c = tuple(slice(int(a[k] - base[k]), int(b[k] - base[k]) + 1) for k in range(3))
+                    sl_b = tuple(slice(int(a[k] - lo[k]), int(b[k] - lo[k]) + 1) for k in range(3))
+                    if save:
+                        chunk[sl_c] = box[sl_b]
+                    else:
+                        box[sl_b] = chunk[sl_c]
+
+    def save_box(self, lo, hi, buf):
+        self._box(lo, hi, buf, True)
+
+    def load_box(self, lo, hi) -> np.ndarray:
+        ext = np.asarray(hi, dtype=np.int64) - np.asarray(lo, dtype=np.int64) + 1
+        buf = np.empty(int(np.prod(ext)), dtype=np.uint32)
+        self._box(lo, hi, buf, False)
+        return buf
+
 
 class LocalMap:
     """HDF5LocalMap without the file (src/map/hdf5_local_map.cpp): a 3-D ring buffer of TSDF entries around `pos`.
@@ -275,6 +305,21 @@ class DeviceMapMemWrapper:
         existing_map.size_[:] = size
         existing_map.pos_[:] = pos
         existing_map.offset_[:] = off
+
+    def extract_box(self, lo, hi) -> np.ndarray:
+        """Voxels of the inclusive world-voxel box [lo, hi] (x major, z fastest) — ws_map_extract_box."""
+        t = self._t
+        lo, hi = _i3(lo), _i3(hi)
+        out = np.empty(int(np.prod((hi - lo + 1).astype(np.int64))), dtype=np.uint32)
+        check(t._L.ws_map_extract_box(t.handle, self._which, _ptr(lo), _ptr(hi), _ptr(out)), "ws_map_extract_box")
+        return out
+
+    def insert_box(self, lo, hi, data):
+        t = self._t
+        lo, hi = _i3(lo), _i3(hi)
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        assert data.size == int(np.prod((hi - lo + 1).astype(np.int64)))
+        check(t._L.ws_map_insert_box(t.handle, self._which, _ptr(lo), _ptr(hi), _ptr(data)), "ws_map_insert_box")
 
     def dev(self):
         return self._t.handle
@@ -475,6 +520,40 @@ class TSDFMapping:
 
     def tsdf(self) -> TSDFCuda:
         return self.tsdf_
+
+    def shift_map(self, new_pos):
+        """TSDFMapping::map_shift (tsdf_mapping.cpp:109-126) with the window moved ON THE DEVICE: per axis, the slab
+        that leaves is packed and saved to the global map, pos/offset move, the slab that enters is loaded and
+        unpacked (the three steps of HDF5LocalMap::shift, hdf5_local_map.cpp:53-118).  The reference copies the whole
+        map device -> host -> device instead.  The host LocalMap only follows pos/offset; its voxel array is stale
+        until avg_map().to_host() is called."""
+        lm, avg, new = self.local_map_, self.tsdf_.avg_map(), self.tsdf_.new_map()
+        new_pos = np.asarray(new_pos, dtype=np.int64)
+        with self.mutex_:
+            diff = new_pos - lm.pos
+            assert np.all(np.abs(diff) <= lm.size)
+            for axis in range(3):
+                d = int(diff[axis])
+                if d == 0:
+                    continue
+                half = lm.size.astype(np.int64) // 2
+                start, end = lm.pos.astype(np.int64) - half, lm.pos.astype(np.int64) + half
+                if d > 0:
+                    end[axis] = start[axis] + d - 1
+                else:
+                    start[axis] = end[axis] + d + 1
+                lm.map_.save_box(start, end, avg.extract_box(start, end))
+                lm.pos[axis] += d
+                lm.offset[axis] = (lm.offset[axis] + d + lm.size[axis]) % lm.size[axis]
+                view = lm.device_map()
+                avg.update_params(view)
+                new.update_params(view)  # new_map is (tau, 0) everywhere: only its window moves
+                start, end = lm.pos.astype(np.int64) - half, lm.pos.astype(np.int64) + half
+                if d > 0:
+                    start[axis] = end[axis] - (d - 1)
+                else:
+                    end[axis] = start[axis] - d - 1
+                avg.insert_box(start, end, lm.map_.load_box(start, end))
 
 
 class TSDFRegistration(TSDFMapping):

@@ -168,7 +168,7 @@ static int map_free(ws_map *m)
   (void)hipStreamSynchronize(m->ctx->stream);
   void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->vstate, m->az_hist, m->az_off, m->ray_order, m->dirty_list, m->rays, m->scan_dev,
                   m->counters, m->arena, m->contested_per_wave, m->tile_count, m->tile_offset, m->tile_cursor, m->tile_records,
-                  m->tile_work, m->tile_state};
+                  m->tile_work, m->tile_state, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -315,6 +315,62 @@ int ws_map_download(ws_map *m, int which, int32_t size[3], int32_t pos[3], int32
     WS_HIP(hipMemcpyAsync(host_data, m->data[which], (size_t)m->n_vox * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
   }
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return WS_OK;
+}
+
+// ---- box transfers: the device side of the map shift (only the slabs that leave / enter move)
+static int box_check(ws_map *m, int which, const int32_t lo[3], const int32_t hi[3], int32_t ext[3], size_t *n)
+{
+  if (!m || !lo || !hi || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("box transfer: bad argument");
+  const MapParams &p = m->par[which];
+  size_t cnt = 1;
+  for (int k = 0; k < 3; ++k)
+  {
+    if (hi[k] < lo[k]) return invalid("box transfer: hi < lo");
+    if (std::abs(lo[k] - p.pos[k]) > p.size[k] / 2 || std::abs(hi[k] - p.pos[k]) > p.size[k] / 2)
+      return invalid("box transfer: box outside the local map window");
+    ext[k] = hi[k] - lo[k] + 1;
+    cnt *= (size_t)ext[k];
+  }
+  *n = cnt;
+  if (cnt > m->box_stage_cap)
+  {
+    WS_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->box_stage) WS_HIP(hipFree(m->box_stage));
+    m->box_stage = nullptr;
+    m->box_stage_cap = 0;
+    WS_HIP(hipMalloc((void **)&m->box_stage, cnt * sizeof(uint32_t)));
+    m->box_stage_cap = cnt;
+  }
+  return WS_OK;
+}
+
+int ws_map_extract_box(ws_map *m, int which, const int32_t lo[3], const int32_t hi[3], uint32_t *host_out)
+{
+  if (!host_out) return invalid("ws_map_extract_box: host_out is NULL");
+  int32_t ext[3];
+  size_t n = 0;
+  int rc = box_check(m, which, lo, hi, ext, &n);
+  if (rc != WS_OK) return rc;
+  rc = launch_box_copy(m, which, lo, ext, m->box_stage, true);
+  if (rc != WS_OK) return rc;
+  WS_HIP(hipMemcpyAsync(host_out, m->box_stage, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return WS_OK;
+}
+
+int ws_map_insert_box(ws_map *m, int which, const int32_t lo[3], const int32_t hi[3], const uint32_t *host_in)
+{
+  if (!host_in) return invalid("ws_map_insert_box: host_in is NULL");
+  int32_t ext[3];
+  size_t n = 0;
+  int rc = box_check(m, which, lo, hi, ext, &n);
+  if (rc != WS_OK) return rc;
+  WS_HIP(hipMemcpyAsync(m->box_stage, host_in, n * sizeof(uint32_t), hipMemcpyHostToDevice, m->ctx->stream));
+  rc = launch_box_copy(m, which, lo, ext, m->box_stage, false);
+  if (rc != WS_OK) return rc;
+  WS_HIP(hipStreamSynchronize(m->ctx->stream)); // the host buffer may be reused by the caller
+  if (which == WS_MAP_NEW) m->new_is_default = false;
   return WS_OK;
 }
 

@@ -675,6 +675,43 @@ __global__ __launch_bounds__(256) void fill_u64_kernel(uint64_t *dst, uint64_t v
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
 }
 
+// ---- slabs of the ring buffer <-> a dense box (device side of the map shift) ----
+// box-local order: x major, z fastest, like the maps; lo/ext in world voxel coordinates, box inside the window
+template <bool PACK>
+__global__ __launch_bounds__(256) void box_copy_kernel(uint32_t *map_data, MapParams mp, int32_t lox, int32_t loy, int32_t loz, int32_t ex,
+                                                       int32_t ey, int32_t ez, uint32_t *box)
+{
+  const int64_t n = (int64_t)ex * ey * ez;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+  {
+    const int32_t z = (int32_t)(i % ez);
+    const int32_t y = (int32_t)((i / ez) % ey);
+    const int32_t x = (int32_t)(i / ((int64_t)ez * ey));
+    const int64_t idx = get_index(mp, lox + x, loy + y, loz + z);
+    if (PACK)
+      box[i] = map_data[idx];
+    else
+      map_data[idx] = box[i];
+  }
+}
+
+int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack)
+{
+  const int64_t n = (int64_t)ext[0] * ext[1] * ext[2];
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (pack)
+    hipLaunchKernelGGL((box_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, m->ctx->stream, m->data[which], m->par[which], lo[0],
+                       lo[1], lo[2], ext[0], ext[1], ext[2], box_dev);
+  else
+    hipLaunchKernelGGL((box_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, m->ctx->stream, m->data[which], m->par[which], lo[0],
+                       lo[1], lo[2], ext[0], ext[1], ext[2], box_dev);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
 {
   if (n <= 0) return WS_OK;

@@ -126,6 +126,8 @@ struct ws_map
   void *tile_work = nullptr; // uint4 per work item
   uint32_t tile_work_cap = 0;
   void *tile_state = nullptr;
+  uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
+  size_t box_stage_cap = 0;
   ws::TsdfCounters *counters_host = nullptr; // pinned
 };
 
@@ -163,6 +165,7 @@ void prof_end(ws_context *ctx, int cls);
 // launchers implemented in the .hip files
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 int launch_tsdf_integrate(ws_map *m);
+int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
 int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n);
 int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
