@@ -21,11 +21,14 @@
 namespace ws
 {
 constexpr int REG_BLOCKS = 256;  // one workgroup per CU
-constexpr int REG_THREADS = 256; // 4 waves
+#ifndef WS_REG_THREADS
+#define WS_REG_THREADS 256
+#endif
+constexpr int REG_THREADS = WS_REG_THREADS; // 4 or 8 waves
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
-static_assert(REG_BLOCKS == REG_THREADS && REG_THREADS == 256, "sum_partials: 4 waves x 64 workgroups, 2 lanes per slot");
+static_assert(REG_BLOCKS % (REG_THREADS / 64 * 2) == 0, "sum_partials: every wave sums an equal share of the workgroups, 2 lanes per slot");
 
 // exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
 struct FastDiv
@@ -424,12 +427,14 @@ __device__ __forceinline__ void accumulate_points(const PointArgs &a, const floa
 // loads per lane (one memory latency), one shuffle, one LDS hop.
 __device__ __forceinline__ void sum_partials(const int64_t *pp, int64_t (*wave_part)[REG_SLOTS], int64_t *red)
 {
+  constexpr int WAVES = REG_THREADS / 64;
+  constexpr int PER_LANE = REG_BLOCKS / (WAVES * 2); // workgroups summed by one lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = lane >> 1;
-  const int64_t *base = pp + ((size_t)wave * 64 + (size_t)(lane & 1) * 32) * REG_SLOTS + slot;
+  const int64_t *base = pp + ((size_t)wave * (2 * PER_LANE) + (size_t)(lane & 1) * PER_LANE) * REG_SLOTS + slot;
   int64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) s = wadd64(s, base[(size_t)i * REG_SLOTS]);
+  for (int i = 0; i < PER_LANE; ++i) s = wadd64(s, base[(size_t)i * REG_SLOTS]);
   s = wadd64(s, shfl_xor_i64(s, 1));
   if ((lane & 1) == 0) wave_part[wave][slot] = s;
   __syncthreads();
@@ -437,7 +442,7 @@ __device__ __forceinline__ void sum_partials(const int64_t *pp, int64_t (*wave_p
   {
     int64_t t = 0;
 #pragma unroll
-    for (int w = 0; w < REG_THREADS / 64; ++w) t = wadd64(t, wave_part[w][threadIdx.x]);
+    for (int w = 0; w < WAVES; ++w) t = wadd64(t, wave_part[w][threadIdx.x]);
     red[threadIdx.x] = t;
   }
   __syncthreads();
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *par
 }
 
 // the solve alone, fed with externally (all-)reduced sums; updates state buffer 0
-__global__ void reg_solve_kernel(GnState *state, const int64_t *sums_dev)
+__global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int64_t *sums_dev)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0)
   {

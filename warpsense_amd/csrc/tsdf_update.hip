@@ -97,8 +97,8 @@ enum
 {
   MARCH_EMIT = 0,       // single pass: every candidate goes through the order keys (used when new_map is not default)
   MARCH_COLLECT = 1,    // candidate lists of contested voxels
-  MARCH_EMIT_KEYED = 2, // pass 1 of the split scatter: negative-weight and near-surface candidates -> order keys
-  MARCH_EMIT_FREE = 3   // pass 2: free-space candidates (tau, +64) -> one byte per voxel, no atomics
+  MARCH_EMIT_KEYED = 2, // pass 1 of the split scatter: the ray tails (fan and near-surface candidates) -> order keys
+  MARCH_EMIT_FREE = 3   // pass 2: the steps before the tails, all free space (tau, +64) -> one byte per voxel, no atomics
 };
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr int AZ_BINS = 1024;
@@ -251,7 +251,11 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   // (ray_order) at the same quarter of the tail, so its lanes hit voxels of the same vertical plane — z-neighbours,
   // i.e. the same cache lines — and one wave-wide atomic touches a handful of lines instead of 64.
   constexpr bool TAIL = (MODE == MARCH_EMIT_KEYED);
-  constexpr int LANES = TAIL ? 4 : 32;
+#ifndef WS_FULL_LANES
+#define WS_FULL_LANES 32
+#endif
+  constexpr int LANES = TAIL ? 4 : WS_FULL_LANES;
+  constexpr int RAYS_PER_BLOCK = 256 / WS_FULL_LANES;
   uint32_t ix;
   int32_t c;
   if (TAIL)
@@ -263,9 +267,9 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   }
   else
   {
-    ix = blockIdx.x * 8u + (threadIdx.x >> 5);
+    ix = blockIdx.x * (uint32_t)RAYS_PER_BLOCK + (threadIdx.x / (uint32_t)WS_FULL_LANES);
     if (ix >= a.n) return;
-    c = (int32_t)(threadIdx.x & 31u);
+    c = (int32_t)(threadIdx.x % (uint32_t)WS_FULL_LANES);
   }
   const RaySetup r = a.rays[ix];
   if (r.steps == 0) return;
@@ -280,11 +284,14 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   // |centre - proj| (1.5 voxels per axis for the double-width cell of trunc division + the fan offset).
   const int32_t keyed_len = min(a.keyed_len_neg, r.distance - tau - a.keyed_slack);
   const int32_t keyed_first = keyed_len > 1 ? max(0, (keyed_len - 1) / half - 1) : 0;
+  // pass 1 (keyed) owns the steps from keyed_first on, pass 2 (free) the steps before it
+  int32_t kend = r.steps;
   if (MODE == MARCH_EMIT_KEYED) kbeg = keyed_first;
-  if (kbeg >= r.steps) return;
-  const int32_t ch = (r.steps - kbeg + LANES - 1) / LANES;
+  if (MODE == MARCH_EMIT_FREE) kend = min(r.steps, keyed_first);
+  if (kbeg >= kend) return;
+  const int32_t ch = (kend - kbeg + LANES - 1) / LANES;
   const int32_t k0 = kbeg + c * ch;
-  const int32_t k1 = min(k0 + ch, r.steps);
+  const int32_t k1 = min(k0 + ch, kend);
   if (k0 >= k1) return;
 
   const MarchFrame f = make_march_frame(a.scanner_pos, res, tau, a.map);
@@ -299,34 +306,32 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
       const int32_t a0 = entry_value(s0) < 0 ? -entry_value(s0) : entry_value(s0);
       if (entry_weight(s0) > 0 || (value < 0 ? -value : value) > a0) return;
     }
-    if (MODE == MARCH_EMIT_KEYED || MODE == MARCH_EMIT_FREE)
+    if (MODE == MARCH_EMIT_FREE)
     {
-      const bool free_space = positive && value == tau;
-      if (MODE == MARCH_EMIT_FREE)
+      // every candidate of these steps is free space: on the ray, further than tau from the hit point
+      if (!(positive && value == tau))
       {
-        if (!free_space)
-        {
-          // must have been handled by the keyed pass: flag the (impossible) case instead of losing a candidate
-          if (k < keyed_first) atomicOr(&a.counters->error, 4u);
-          return;
-        }
-        const uint8_t b = a.vstate[idx];
-        if (b & VOX_KEYED)
-        {
-          // the voxel also has ordered candidates: this one takes part in the key order
-          const uint64_t key = make_kpos(t, value);
-          if (key < a.kpos[idx]) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
-        }
-        else if (b == 0)
-        {
-          // free space only (so far the common case): the result will be (tau, 64) whoever comes first
-          a.vstate[idx] = VOX_TOUCHED;
-          const int64_t tile = idx >> TILE_SHIFT;
-          if (a.dirty[tile] == 0) a.dirty[tile] = 1;
-        }
+        atomicOr(&a.counters->error, 4u); // impossible by the bound above; never lose a candidate silently
         return;
       }
-      if (free_space) return; // pass 2 takes it
+      const uint8_t b = a.vstate[idx];
+      if (b & VOX_KEYED)
+      {
+        // the voxel also has ordered candidates (from pass 1): this one takes part in the key order
+        const uint64_t key = make_kpos(t, value);
+        if (key < a.kpos[idx]) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
+      }
+      else if (b == 0)
+      {
+        // free space only (the common case): the result will be (tau, 64) whoever comes first
+        a.vstate[idx] = VOX_TOUCHED;
+        const int64_t tile = idx >> TILE_SHIFT;
+        if (a.dirty[tile] == 0) a.dirty[tile] = 1;
+      }
+      return;
+    }
+    if (MODE == MARCH_EMIT_KEYED)
+    {
       if (a.vstate[idx] != VOX_KEYED) a.vstate[idx] = VOX_KEYED;
     }
     if (MODE == MARCH_EMIT || MODE == MARCH_EMIT_KEYED)
@@ -765,7 +770,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.arena_cap = m->arena_cap;
   {
     // half of the arena is split evenly between the workgroups, the other half is the shared overflow area
-    const uint32_t blocks = (uint32_t)((n + 7) / 8); // workgroups of the collect pass
+    const uint32_t blocks = (uint32_t)((n + 256 / WS_FULL_LANES - 1) / (256 / WS_FULL_LANES)); // workgroups of the collect pass
     ma.arena_slice = (m->arena_cap / 2) / (blocks ? blocks : 1);
   }
   {
@@ -797,7 +802,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
-  const dim3 grid_rays((unsigned)((n + 7) / 8));
+  constexpr size_t rays_per_block = 256 / WS_FULL_LANES;
+  const dim3 grid_rays((unsigned)((n + rays_per_block - 1) / rays_per_block));
   const dim3 grid_tail((unsigned)((n + 63) / 64));
   const dim3 grid_list(LIST_GRID_BLOCKS);
   const bool s0 = !m->new_is_default;
