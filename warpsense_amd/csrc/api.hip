@@ -94,6 +94,7 @@ static void copy3(int32_t dst[3], const int32_t src[3])
 }
 
 size_t reg_partials_bytes();
+constexpr size_t AZ_ALLOC = 1024 * 64 + 8; // direction-bin histogram / offsets (tsdf_update.hip: AZ_BINS + 2 entries)
 } // namespace ws
 
 using namespace ws;
@@ -223,11 +224,11 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMemsetAsync(m->vstate, 0, (size_t)m->n_vox, s));
   TRY(hipMalloc((void **)&m->dirty_list, (size_t)m->n_tiles * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * 48));
-  TRY(hipMalloc((void **)&m->az_hist, 1032 * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->az_off, 1032 * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(m->az_hist, 0, 1032 * sizeof(uint32_t), s));
-  TRY(hipMemsetAsync(m->az_off, 0, 1032 * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->az_hist, 0, AZ_ALLOC * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->az_off, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
   TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));

@@ -101,7 +101,11 @@ enum
   MARCH_EMIT_FREE = 3   // pass 2: the steps before the tails, all free space (tau, +64) -> one byte per voxel, no atomics
 };
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
-constexpr int AZ_BINS = 1024;
+#ifndef WS_EL_BINS
+#define WS_EL_BINS 8
+#endif
+constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
+constexpr int AZ_BINS = AZ_ONLY_BINS * EL_BINS; // direction bins: azimuth major, elevation minor
 
 // update_tsdf.cu:52-63 for one ray per lane
 __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
@@ -186,8 +190,13 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
   if (r.steps > 0)
   {
     const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
-    int b = (int)((az + 3.14159265f) * ((float)AZ_BINS / 6.2831853f));
-    bin = (uint32_t)(b < 0 ? 0 : (b >= AZ_BINS ? AZ_BINS - 1 : b));
+    int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
+    b = b < 0 ? 0 : (b >= AZ_ONLY_BINS ? AZ_ONLY_BINS - 1 : b);
+    // elevation: sin(el) = dz / distance in [-1, 1]; LiDARs use the middle of that range, so bin tan-like: clamp +-0.5
+    float se = (float)r.dz / (float)r.distance;
+    int e = (int)((se + 0.5f) * (float)EL_BINS);
+    e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
+    bin = (uint32_t)(b * EL_BINS + e);
   }
   r.pad |= (int32_t)(bin << 1);
   atomicAdd(&a.az_hist[bin], 1u);
@@ -198,8 +207,12 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
 __global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t *off)
 {
   __shared__ uint32_t wave_sums[16];
+  constexpr int TOTAL = AZ_BINS + 1;
+  constexpr int PER = (TOTAL + 1023) / 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t v = hist[threadIdx.x];
+  const int lo = threadIdx.x * PER, hi = min(lo + PER, TOTAL);
+  uint32_t v = 0;
+  for (int i = lo; i < hi; ++i) v += hist[i];
   uint32_t x = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1)
@@ -209,17 +222,16 @@ __global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t
   }
   if (lane == 63) wave_sums[wave] = x;
   __syncthreads();
-  uint32_t before = 0;
-  for (int w = 0; w < wave; ++w) before += wave_sums[w];
-  off[threadIdx.x] = before + x - v;
-  hist[threadIdx.x] = 0;
-  if (threadIdx.x == 1023)
+  uint32_t run = x - v;
+  for (int w = 0; w < wave; ++w) run += wave_sums[w];
+  for (int i = lo; i < hi; ++i)
   {
-    const uint32_t last = hist[AZ_BINS]; // not yet reset: only lanes 0..1023 reset their own entry
-    off[AZ_BINS] = before + x;           // number of rays that contribute (start of the unused bin)
-    off[AZ_BINS + 1] = before + x + last;
-    hist[AZ_BINS] = 0;
+    const uint32_t c = hist[i];
+    off[i] = run;
+    hist[i] = 0;
+    run += c;
   }
+  if (hi == TOTAL && lo < hi) off[TOTAL] = run; // off[AZ_BINS] = rays that contribute, off[AZ_BINS + 1] = all rays
 }
 
 __global__ __launch_bounds__(256) void ray_scatter_kernel(MarchArgs a)
