@@ -43,7 +43,8 @@ typedef enum
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
   WS_ERR_CAPACITY = -4,    /* contested-voxel arena exhausted (see ws_tsdf_stats)       */
-  WS_ERR_RANGE = -5        /* ray too long for the order key            */
+  WS_ERR_RANGE = -5,       /* ray too long for the order key            */
+  WS_ERR_TIMEOUT = -6      /* the resident registration loop could not get the whole GPU */
 } ws_status;
 
 #define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
@@ -56,6 +57,11 @@ typedef enum
 /* registration flags */
 #define WS_REG_ALL_POINTS 0u
 #define WS_REG_COMPAT_REFERENCE_LAUNCH 1u /* reproduce the <<<128,512>>> / N%32 coverage of registration.cu:353-356 */
+
+/* how ws_register_cloud runs the Gauss-Newton loop, ws_reg_set_loop() */
+#define WS_REG_LOOP_RESIDENT 0 /* one launch for the whole loop, grid barrier between iterations (default;
+                                  falls back to LAUNCHES when the device cannot hold the grid at once) */
+#define WS_REG_LOOP_LAUNCHES 1 /* one launch per iteration */
 
 const char *ws_last_error(void);
 int ws_version(void);
@@ -141,6 +147,7 @@ int ws_reg_iterate(ws_reg *reg, const ws_map *map, const float T[16], int32_t ma
 int ws_register_cloud(ws_reg *reg, const ws_map *map, const float T_in[16], int32_t max_iterations,
                       float it_weight_gradient, float epsilon, int32_t map_resolution, uint32_t flags,
                       float T_out[16], int32_t *iterations);
+int ws_reg_set_loop(ws_reg *reg, int mode /* WS_REG_LOOP_* */);
 
 /* Building blocks of the same loop for point-sharded multi-GPU runs: every rank owns the
  * points [first, first+count) of the prepared cloud, accumulates its 44 int64 partial sums

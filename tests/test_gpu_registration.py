@@ -69,9 +69,13 @@ def test_hgec_ragged_sizes(n):
         assert np.array_equal(g, go) and np.array_equal(h, ho)
 
 
-def test_register_cloud_matches_oracle_pose():
-    """register_cloud: same iteration count, per-iteration sums and final pose (1e-4 m / 1e-4 rad)."""
+@pytest.mark.parametrize("loop", ["resident", "launches"])
+def test_register_cloud_matches_oracle_pose(loop):
+    """register_cloud: same iteration count, per-iteration sums and final pose (1e-4 m / 1e-4 rad),
+    with the loop as one resident launch (grid barrier) and as one launch per iteration."""
+    import warpsense_amd as W
     reg, oa, pts, res = build_scene(scans=2)
+    reg.reg_.set_loop(W.WS_REG_LOOP_RESIDENT if loop == "resident" else W.WS_REG_LOOP_LAUNCHES)
     Tp = S.perturbation(60, 40, 0, 3.0)
     q = S.transform_points_mm(pts, Tp)
     T_gpu = reg.register_cloud(q, np.eye(4, dtype=np.float32))
@@ -82,6 +86,24 @@ def test_register_cloud_matches_oracle_pose():
     # and it actually registers: closer to the inverse perturbation than the start
     inv = np.linalg.inv(Tp.astype(np.float64))
     assert pose_error(T_gpu, inv)[0] < pose_error(np.eye(4), inv)[0]
+
+
+def test_register_cloud_loop_modes_identical():
+    """resident loop == per-iteration launches, bit for bit (pose and iteration count), incl. max_iterations cut-offs."""
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    q = S.transform_points_mm(pts, S.perturbation(-45, 25, 5, -2.0))
+    reg.reg_.prepare_registration(q)
+    for max_it in (0, 1, 2, 7, 200):
+        out = []
+        for mode in (W.WS_REG_LOOP_RESIDENT, W.WS_REG_LOOP_LAUNCHES):
+            reg.reg_.set_loop(mode)
+            T, it = reg.reg_.register_cloud(reg.tsdf().device_map(), np.eye(4, dtype=np.float32), max_it, 0.1, 0.03, res)
+            out.append((T, it))
+        assert out[0][1] == out[1][1] and out[0][1] <= max_it
+        assert np.array_equal(out[0][0], out[1][0])
+        if max_it == 0:
+            assert np.array_equal(out[0][0], np.eye(4, dtype=np.float32))
 
 
 def test_register_cloud_empty_overlap():

@@ -7,6 +7,6 @@ from .api import (Context, DeviceMap, DeviceMapMemWrapper, GlobalMap, LocalMap, 
                   RegistrationParams, TSDFCuda, TSDFMapping, TSDFRegistration, cleanup, pack_entry, pause, to_int_mat,
                   to_map, unpack_entry)
 from ._lib import (WS_INTEGRATE_DENSE, WS_INTEGRATE_SPARSE, WS_MAP_AVG, WS_MAP_NEW, WS_REG_ALL_POINTS,  # noqa: F401
-                   WS_REG_COMPAT_REFERENCE_LAUNCH, WS_SCATTER_GLOBAL, WS_SCATTER_TILES, WsError)
+                   WS_REG_COMPAT_REFERENCE_LAUNCH, WS_REG_LOOP_LAUNCHES, WS_REG_LOOP_RESIDENT, WS_SCATTER_GLOBAL, WS_SCATTER_TILES, WsError)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

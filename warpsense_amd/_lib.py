@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
 WS_MAP_AVG, WS_MAP_NEW = 0, 1
 WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE = 0, 1
 WS_REG_ALL_POINTS, WS_REG_COMPAT_REFERENCE_LAUNCH = 0, 1
+WS_REG_LOOP_RESIDENT, WS_REG_LOOP_LAUNCHES = 0, 1
 (WS_K_MARCH_EMIT, WS_K_RESOLVE, WS_K_MARCH_COLLECT, WS_K_RESOLVE_LISTS, WS_K_INTEGRATE, WS_K_REG, WS_K_TILE_BIN,
  WS_K_TILE_SCATTER) = range(8)
 KERNEL_CLASSES = ["march_emit", "resolve", "march_collect", "resolve_lists", "integrate", "reg_iteration", "tile_bin",
@@ -26,7 +27,7 @@ EXPORTS = [
     "ws_map_extract_box", "ws_map_insert_box", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
     "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_scatter", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
-    "ws_reg_solve_dev", "ws_reg_poll", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
+    "ws_reg_solve_dev", "ws_reg_poll", "ws_reg_set_loop", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
 ]
 
 
@@ -84,6 +85,7 @@ def load() -> C.CDLL:
     L.ws_reg_iterate.argtypes = [vp, vp, vp, i32, u32, vp, vp, P(i32), P(i32)]
     L.ws_register_cloud.argtypes = [vp, vp, vp, i32, C.c_float, C.c_float, i32, u32, vp, P(i32)]
     L.ws_reg_begin.argtypes = [vp, vp, i32, C.c_float, C.c_float]
+    L.ws_reg_set_loop.argtypes = [vp, C.c_int]
     L.ws_reg_accumulate_dev.argtypes = [vp, vp, i32, u32, sz, sz, vp]
     L.ws_reg_solve_dev.argtypes = [vp, vp]
     L.ws_reg_poll.argtypes = [vp, P(i32), P(i32), vp]

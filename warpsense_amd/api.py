@@ -448,6 +448,10 @@ class RegistrationCuda:
               "ws_register_cloud")
         return out.reshape(4, 4).T.copy(), it.value
 
+    def set_loop(self, mode: int):
+        """WS_REG_LOOP_RESIDENT (one launch, grid barrier; default) or WS_REG_LOOP_LAUNCHES (one launch per iteration)."""
+        check(self._L.ws_reg_set_loop(self.handle, int(mode)), "ws_reg_set_loop")
+
     def close(self):
         if self.handle:
             self._L.ws_reg_destroy(self.handle)

@@ -497,6 +497,7 @@ int ws_reg_destroy(ws_reg *r)
   if (r->sums_dev) (void)hipFree(r->sums_dev);
   if (r->state_host) (void)hipHostFree(r->state_host);
   if (r->host_flag) (void)hipHostFree(r->host_flag);
+  if (r->grid_bar) (void)hipFree(r->grid_bar);
   delete r;
   return WS_OK;
 }
@@ -530,6 +531,8 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->host_flag, 64, hipHostMallocMapped);
   if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->host_flag_dev, r->host_flag, 0);
   if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, 2 * sizeof(GnState), ctx->stream);
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->grid_bar, reg_barrier_bytes());
+  if (rc == WS_OK && e == hipSuccess) r->loop_supported = reg_loop_supported(ctx->device);
   if (rc != WS_OK || e != hipSuccess)
   {
     if (e != hipSuccess) rc = hip_fail(e, "ws_reg_create allocation", __FILE__, __LINE__);
@@ -634,6 +637,23 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
   // The whole loop runs on the device: launch k applies update k (from the partial sums launch k-1 left
   // behind) and accumulates for iteration k.  The host just enqueues; the device raises a flag in
   // host-mapped memory on convergence so the host can stop early (launches already enqueued exit at once).
+  if (r->loop_mode == WS_REG_LOOP_RESIDENT && r->loop_supported)
+  {
+    // one launch: the 256 workgroups stay resident and meet at a grid barrier between iterations
+    rc = launch_reg_loop(r, m, res, flags);
+    if (rc != WS_OK) return rc;
+    r->latest = 0;
+    int fin = 0, iters = 0;
+    rc = ws_reg_poll(r, &fin, &iters, T_out);
+    if (rc != WS_OK) return rc;
+    if (r->state_host->core.error)
+    {
+      set_error("ws_register_cloud: grid barrier timed out (another kernel is holding compute units); use WS_REG_LOOP_LAUNCHES");
+      return WS_ERR_TIMEOUT;
+    }
+    if (iterations) *iterations = iters;
+    return WS_OK;
+  }
   const volatile int32_t *flag = r->host_flag;
   int launched = 0;
   for (int k = 0; k <= max_iterations; ++k)
@@ -648,6 +668,13 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
   rc = ws_reg_poll(r, &fin, &iters, T_out);
   if (rc != WS_OK) return rc;
   if (iterations) *iterations = iters;
+  return WS_OK;
+}
+
+int ws_reg_set_loop(ws_reg *r, int mode)
+{
+  if (!r || (mode != WS_REG_LOOP_RESIDENT && mode != WS_REG_LOOP_LAUNCHES)) return invalid("ws_reg_set_loop: bad argument");
+  r->loop_mode = mode;
   return WS_OK;
 }
 

@@ -125,99 +125,101 @@ __device__ __forceinline__ void expand_sums(const int64_t *terms, int64_t *sums)
   sums[43] = (int64_t)(int32_t)terms[28];
 }
 
-// ---- 6x6 solve, fully unrolled so every index is static (no scratch): LU with partial pivoting in
-// double, the same operation order as oracle/ws_oracle.c:wso_solve6 (Eigen hf.inverse()*g, tsdf_registration.cpp:69)
-__device__ __forceinline__ int solve6(double (&A)[6][6], double (&b)[6], double (&x)[6])
+// ---- 6x6 solve on one wave: LU with partial pivoting in double, the same operations in the same order as
+// oracle/ws_oracle.c:wso_solve6 (Eigen hf.inverse()*g, tsdf_registration.cpp:69), so the result is bit-identical
+// to a serial solve.  Lane 8*r + c holds element (r, c) of the augmented matrix [A | b] (c == 6 is b): the 5
+// divisions and the rank-1 update of an elimination step are one instruction each instead of 5 / 35, and no
+// element ever needs a dynamic register index (a serial version spills the matrix to scratch for the row swap:
+// 2.9 us per solve on one lane; this one ~1 us).  All 64 lanes of the wave must be active.
+__device__ __forceinline__ double lane_read(double v, int src_lane /* uniform */)
 {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_gather(double v, int src_lane /* per lane */)
+{
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// a: this lane's element of [A | b].  Returns 0 and x (identical in every lane), or -1 for a singular matrix.
+__device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
+{
+  const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
 #pragma unroll
   for (int k = 0; k < 6; ++k)
   {
+    // pivot: first row of maximal |A[i][k]|, i >= k
     int piv = k;
-    double best = fabs(A[k][k]);
+    double pv = lane_read(a, 8 * k + k);
+    double best = fabs(pv);
 #pragma unroll
     for (int i = k + 1; i < 6; ++i)
     {
-      const double c = fabs(A[i][k]);
-      if (c > best)
+      const double v = lane_read(a, 8 * i + k);
+      if (fabs(v) > best)
       {
-        best = c;
+        best = fabs(v);
+        pv = v;
         piv = i;
       }
     }
     if (best == 0.0) return -1;
+    if (k == 5) break;
+    // rows k and piv change places; fetch the swapped element, the pivot row and the k-th column in one go
+    const int rr = r == k ? piv : (r == piv ? k : r);
+    const double an = lane_gather(a, 8 * rr + c);
+    const double rowk = lane_gather(a, 8 * piv + c);
+    const double colk = lane_gather(a, 8 * rr + k);
+    const double f = colk / pv;
+    a = (r > k && c >= k) ? an - f * rowk : an;
+  }
+  double U[6][6], b[6];
 #pragma unroll
-    for (int i = k + 1; i < 6; ++i)
-    {
-      if (piv == i)
-      {
+  for (int i = 0; i < 6; ++i)
+  {
+    b[i] = lane_read(a, 8 * i + 6);
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-        {
-          const double t = A[k][j];
-          A[k][j] = A[i][j];
-          A[i][j] = t;
-        }
-        const double t = b[k];
-        b[k] = b[i];
-        b[i] = t;
-      }
-    }
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i)
-    {
-      const double f = A[i][k] / A[k][k];
-#pragma unroll
-      for (int j = k; j < 6; ++j) A[i][j] -= f * A[k][j];
-      b[i] -= f * b[k];
-    }
+    for (int j = i; j < 6; ++j) U[i][j] = lane_read(a, 8 * i + j);
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i)
   {
-    double s = b[i];
+    double t = b[i];
 #pragma unroll
-    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
-    x[i] = s / A[i][i];
+    for (int j = i + 1; j < 6; ++j) t -= U[i][j] * x[j];
+    x[i] = t / U[i][i];
   }
   return 0;
 }
 
-// One Gauss-Newton update (tsdf_registration.cpp:63-92, registration/util.h:5-39), single lane.
-__device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
+// One Gauss-Newton update (tsdf_registration.cpp:63-92, registration/util.h:5-39), executed by one whole wave;
+// every lane holds the same state and computes the same result.  H(r, c), G(r): the int64 sums.
+template <typename HF, typename GF>
+__device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int32_t c)
 {
   if (st.finished || st.iterations >= st.max_iterations) return;
-  const int32_t e = (int32_t)sums[42], c = (int32_t)sums[43];
   st.iterations += 1;
   if (c == 0)
   {
     st.finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
     return;
   }
-#ifdef WS_REG_TIMING
-  long long g0 = wall_clock64();
-#endif
-  double hf[6][6], gf[6], xi[6];
   const double w = (double)(st.alpha * (float)c);
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-  {
-    gf[r] = (double)sums[36 + r];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) hf[r][q] = (double)sums[q * 6 + r] + (r == q ? w : 0.0);
-  }
-#ifdef WS_REG_TIMING
-  long long g1 = wall_clock64();
-#endif
-  if (solve6(hf, gf, xi) != 0)
+  const int lane = threadIdx.x & 63, lr = lane >> 3, lc = lane & 7;
+  double a = 0.0;
+  if (lr < 6 && lc < 6) a = (double)H(lr, lc) + (lr == lc ? w : 0.0);
+  if (lr < 6 && lc == 6) a = (double)G(lr);
+  double xi[6];
+  if (solve6_wave(a, xi) != 0)
   {
     st.finished = 1;
     return;
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
-#ifdef WS_REG_TIMING
-  long long g2 = wall_clock64();
-#endif
 
   // xi_to_transform
   const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
@@ -254,9 +256,6 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
     const float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
     tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), (float)xi[3 + i]);
   }
-#ifdef WS_REG_TIMING
-  long long g3 = wall_clock64();
-#endif
   st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
   float out[16];
 #pragma unroll
@@ -278,10 +277,14 @@ __device__ __forceinline__ void gn_update(GnCore &st, const int64_t *sums)
   st.prev[1] = st.prev[2];
   st.prev[2] = st.prev[3];
   st.prev[3] = err;
-#ifdef WS_REG_TIMING
-  if (blockIdx.x == 7 && st.iterations == 21)
-    printf("gn_update ticks(10ns): build %lld solve %lld xi2T %lld rest %lld\n", g1 - g0, g2 - g1, g3 - g2, wall_clock64() - g3);
-#endif
+}
+
+// the update fed from the 29 reduced terms in LDS (e and c are `int` in the reference, registration.cu:16-21)
+__device__ __forceinline__ void gn_update_terms(GnCore &st, const int64_t *terms)
+{
+  gn_update(
+      st, [terms](int r, int c) { return terms[r <= c ? tri_index(r, c) : tri_index(c, r)]; }, [terms](int r) { return terms[21 + r]; },
+      (int32_t)terms[27], (int32_t)terms[28]);
 }
 
 struct PointArgs
@@ -425,6 +428,9 @@ __device__ __forceinline__ void accumulate_points(const PointArgs &a, const floa
 // Sum of the partials [REG_BLOCKS][REG_SLOTS] a previous launch left in HBM -> red[0..31] in LDS.
 // Lane l of wave w adds slot (l >> 1) over 32 of the wave's 64 workgroups: 32 independent, fully coalesced
 // loads per lane (one memory latency), one shuffle, one LDS hop.
+// COHERENT: the partials were written by other workgroups of the SAME launch -> agent-scope loads (sc1), which
+// cannot be served from a stale line of this XCD's L2.
+template <bool COHERENT = false>
 __device__ __forceinline__ void sum_partials(const int64_t *pp, int64_t (*wave_part)[REG_SLOTS], int64_t *red)
 {
   constexpr int WAVES = REG_THREADS / 64;
@@ -434,7 +440,12 @@ __device__ __forceinline__ void sum_partials(const int64_t *pp, int64_t (*wave_p
   const int64_t *base = pp + ((size_t)wave * (2 * PER_LANE) + (size_t)(lane & 1) * PER_LANE) * REG_SLOTS + slot;
   int64_t s = 0;
 #pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) s = wadd64(s, base[(size_t)i * REG_SLOTS]);
+  for (int i = 0; i < PER_LANE; ++i)
+  {
+    const int64_t v = COHERENT ? __hip_atomic_load(const_cast<int64_t *>(&base[(size_t)i * REG_SLOTS]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : base[(size_t)i * REG_SLOTS];
+    s = wadd64(s, v);
+  }
   s = wadd64(s, shfl_xor_i64(s, 1));
   if ((lane & 1) == 0) wave_part[wave][slot] = s;
   __syncthreads();
@@ -485,28 +496,32 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
     sum_partials(a.partials + (size_t)((a.k + 1) & 1) * REG_SLOTS * REG_BLOCKS, wave_part, red);
   }
   WS_STAMP(2);
-  if (threadIdx.x == 0)
+  if (threadIdx.x < 64)
   {
+    // the whole first wave: the 6x6 solve is lane-parallel, everything else is computed identically by every lane
     GnCore st = prev->core;
     if (need_update)
     {
-      int64_t sums[44];
-      expand_sums(red, sums);
-      gn_update(st, sums);
-      if (blockIdx.x == 0)
+      gn_update_terms(st, red);
+      if (blockIdx.x == 0 && threadIdx.x == 0)
       {
+        int64_t sums[44];
+        expand_sums(red, sums);
 #pragma unroll
         for (int i = 0; i < 44; ++i) cur->sums[i] = sums[i];
       }
     }
-    const int stop = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
-    stop_sh = stop;
-    if (blockIdx.x == 0)
+    if (threadIdx.x == 0)
     {
-      cur->core = st;
-      if (stop && a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int stop = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
+      stop_sh = stop;
+      if (blockIdx.x == 0)
+      {
+        cur->core = st;
+        if (stop && a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   __syncthreads();
@@ -531,6 +546,170 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
     printf("reg_iter k=%d ticks(100MHz): load %lld reduce %lld solve %lld accumulate %lld reduce %lld\n", a.k, ts[1] - ts[0], ts[2] - ts[1],
            ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4]);
 #endif
+}
+
+// ---- the whole Gauss-Newton loop in ONE launch -------------------------------------------------------
+// The launch boundary between two iterations above costs ~5.5 us (dispatch of 256 workgroups, end-of-kernel
+// cache write-back, the gap to the next launch) for ~10 us of work.  reg_loop_kernel keeps the 256
+// workgroups resident (one per CU, checked on the host before the launch) and replaces the boundary by a
+// grid barrier: a monotonic arrival counter in HBM, release/acquire at agent scope around it.  The
+// per-iteration structure (and every arithmetic step) is the one of reg_iter_kernel; the points of a
+// lane stay in registers for the whole loop.
+struct LoopArgs
+{
+  PointArgs pts;
+  GnState *state;    // in: state[0].core, out: state[0]
+  int64_t *partials; // [2][REG_BLOCKS][REG_SLOTS]
+  uint32_t *bar;     // REG_BAR_COUNTERS monotonic arrival counters + abort flag; zeroed before the launch
+  int32_t *host_flag;
+};
+
+// Grid barrier, measured with tools/barrier_bench.hip on MI355X (256 workgroups, 8 XCDs):
+//   * agent-scope release/acquire FENCES walk the XCD's L2 (buffer_wbl2 / buffer_inv): 16 us per barrier;
+//   * without them a barrier is 3.7 us, of which 2.6 us is 256 atomics queueing on one address.
+// So the data the workgroups exchange (the partials) is written and read with agent-scope atomic stores / loads
+// (write-through / L2-coherent `sc1` accesses, 8 bytes each, single-copy atomic), the arrival is ordered after
+// them by waiting for their completion (s_waitcnt vmcnt(0): gfx9 counts stores in vmcnt), and arrivals are
+// spread over 16 counters in different memory channels: 3.1 us per barrier INCLUDING every workgroup's read of
+// all 256 x 32 partials.  Nothing else is communicated inside the launch (the map is read-only here).
+constexpr int REG_BAR_COUNTERS = 16;
+constexpr int REG_BAR_STRIDE = 64; // uint32 words between counters (256 B)
+constexpr int REG_BAR_ABORT = REG_BAR_COUNTERS * REG_BAR_STRIDE;
+constexpr size_t REG_BAR_BYTES = (REG_BAR_ABORT + REG_BAR_STRIDE) * sizeof(uint32_t);
+static_assert(REG_BLOCKS % REG_BAR_COUNTERS == 0 && REG_BAR_COUNTERS <= 64, "arrival counters");
+constexpr long long REG_BARRIER_TIMEOUT_TICKS = 100000000ll; // 1 s of the 100 MHz wall clock
+
+__device__ __forceinline__ void grid_arrive(uint32_t *bar)
+{
+  // executed by wave 0, which also issued the partial stores
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // compiler ordering
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have been acknowledged
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(&bar[(blockIdx.x % REG_BAR_COUNTERS) * REG_BAR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0: wait until every counter has reached `target` (= iteration x workgroups per counter).
+// false: gave up (another kernel is holding CUs this grid needs) -- every workgroup then leaves the loop.
+__device__ __forceinline__ bool grid_wait(uint32_t *bar, uint32_t target)
+{
+  const int lane = threadIdx.x;
+  uint32_t spins = 0;
+  long long t0 = 0;
+  for (;;)
+  {
+    const bool ok = lane >= REG_BAR_COUNTERS ||
+                    __hip_atomic_load(&bar[(lane % REG_BAR_COUNTERS) * REG_BAR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+    if (__all(ok)) return true;
+    if ((++spins & 1023u) == 0)
+    {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      const bool give_up = now - t0 > REG_BARRIER_TIMEOUT_TICKS ||
+                           __hip_atomic_load(&bar[REG_BAR_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (__any(give_up))
+      {
+        if (lane == 0) __hip_atomic_store(&bar[REG_BAR_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  __shared__ float T_sh[16];
+  __shared__ int stop_sh;
+  __shared__ int abort_sh;
+
+  const Prefetched pref = prefetch_points(a.pts);
+  GnCore st; // first wave only, identical in all of its lanes
+  if (threadIdx.x < 64) st = a.state[0].core;
+#ifdef WS_REG_TIMING
+  long long ts[7], tot[6] = {0, 0, 0, 0, 0, 0};
+#define WS_LSTAMP(i) ts[i] = wall_clock64()
+#else
+#define WS_LSTAMP(i)
+#endif
+  uint32_t k = 0;
+  for (;; ++k)
+  {
+    bool aborted = false;
+    WS_LSTAMP(0);
+    WS_LSTAMP(1);
+    if (k > 0)
+    {
+      if (threadIdx.x < 64)
+      {
+        const bool ok = grid_wait(a.bar, k * (uint32_t)(REG_BLOCKS / REG_BAR_COUNTERS));
+        if (threadIdx.x == 0) abort_sh = ok ? 0 : 1;
+      }
+      __syncthreads();
+      WS_LSTAMP(1);
+      aborted = abort_sh != 0;
+      if (!aborted) sum_partials<true>(a.partials + (size_t)((k + 1) & 1) * REG_SLOTS * REG_BLOCKS, wave_part, red);
+    }
+    WS_LSTAMP(2);
+    if (threadIdx.x < 64)
+    {
+      if (aborted)
+      {
+        st.finished = 1;
+        st.error = 1; // reported by the host
+      }
+      else if (k > 0)
+        gn_update_terms(st, red);
+      if (threadIdx.x == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
+        stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    WS_LSTAMP(3);
+    if (stop_sh) break;
+
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+    int64_t acc[REG_SLOTS];
+#pragma unroll
+    for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+    accumulate_points(a.pts, T, pref, acc);
+    WS_LSTAMP(4);
+    block_reduce32(acc, wave_part, red);
+    WS_LSTAMP(5);
+    if (threadIdx.x < 64)
+    {
+      if (threadIdx.x < REG_SLOTS)
+        __hip_atomic_store(&a.partials[(size_t)(k & 1) * REG_SLOTS * REG_BLOCKS + (size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      grid_arrive(a.bar);
+    }
+#ifdef WS_REG_TIMING
+    WS_LSTAMP(6);
+    for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
+#endif
+  }
+#ifdef WS_REG_TIMING
+  if ((blockIdx.x % 37) == 0 && threadIdx.x == 0)
+    printf("reg_loop wg %d iterations %u, 10ns ticks per phase: wait %lld sum %lld solve %lld accumulate %lld reduce %lld arrive %lld\n", (int)blockIdx.x, k,
+           tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+#endif
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    a.state[0].core = st;
+    if (k > 0 && !st.error)
+    {
+      int64_t sums[44];
+      expand_sums(red, sums); // the totals the last update was made from
+#pragma unroll
+      for (int i = 0; i < 44; ++i) a.state[0].sums[i] = sums[i];
+    }
+    if (a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- the same pieces as separate kernels: perform_registration (host gets h,g,e,c) and the multi-GPU
@@ -577,18 +756,18 @@ __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *par
 // the solve alone, fed with externally (all-)reduced sums; updates state buffer 0
 __global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int64_t *sums_dev)
 {
-  if (threadIdx.x == 0 && blockIdx.x == 0)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  GnCore st = state->core;
+  gn_update(
+      st, [sums_dev](int r, int c) { return sums_dev[c * 6 + r]; }, [sums_dev](int r) { return sums_dev[36 + r]; }, (int32_t)sums_dev[42],
+      (int32_t)sums_dev[43]);
+  if (threadIdx.x == 0)
   {
-    int64_t sums[44];
-#pragma unroll
-    for (int k = 0; k < 44; ++k) sums[k] = sums_dev[k];
-    sums[42] = (int64_t)(int32_t)sums[42];
-    sums[43] = (int64_t)(int32_t)sums[43];
-    GnCore st = state->core;
-    gn_update(st, sums);
     state->core = st;
 #pragma unroll
-    for (int k = 0; k < 44; ++k) state->sums[k] = sums[k];
+    for (int k = 0; k < 42; ++k) state->sums[k] = sums_dev[k];
+    state->sums[42] = (int64_t)(int32_t)sums_dev[42];
+    state->sums[43] = (int64_t)(int32_t)sums_dev[43];
   }
 }
 
@@ -658,6 +837,34 @@ int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
+
+// 1 if the device can hold the whole grid of reg_loop_kernel at once (required by its grid barrier)
+int reg_loop_supported(int device)
+{
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reg_loop_kernel, REG_THREADS, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
+}
+
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags)
+{
+  ws_context *ctx = r->ctx;
+  LoopArgs a;
+  a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  a.state = r->state;
+  a.partials = r->partials;
+  a.bar = r->grid_bar;
+  a.host_flag = r->host_flag_dev;
+  WS_HIP(hipMemsetAsync(r->grid_bar, 0, REG_BAR_BYTES, ctx->stream));
+  prof_begin(ctx, WS_K_REG);
+  hipLaunchKernelGGL(reg_loop_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  prof_end(ctx, WS_K_REG);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+size_t reg_barrier_bytes() { return REG_BAR_BYTES; }
 
 size_t reg_partials_bytes() { return sizeof(int64_t) * 2 * REG_SLOTS * REG_BLOCKS; }
 

@@ -67,7 +67,7 @@ struct GnCore
   int32_t max_iterations;
   int32_t iterations;
   int32_t finished;
-  int32_t pad;
+  int32_t error; // 1: the grid barrier of reg_loop_kernel timed out
 };
 struct GnState
 {
@@ -144,6 +144,9 @@ struct ws_reg
   int latest = 0;                    // state buffer holding the newest state
   float *T_dev = nullptr;            // transform for ws_reg_iterate
   int64_t *sums_dev = nullptr;       // 44
+  uint32_t *grid_bar = nullptr;      // [2] arrival counter + abort flag of reg_loop_kernel
+  int loop_mode = 0;                 // WS_REG_LOOP_*
+  int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
 };
 
 namespace ws
@@ -174,4 +177,7 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
                           size_t first, size_t count, int64_t *sums_dev);
 int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags);
+int reg_loop_supported(int device);
+size_t reg_barrier_bytes();
 } // namespace ws
