@@ -98,19 +98,24 @@ def main():
 
     points = S.os1_128_scan()
     perturbed = S.transform_points_mm(points, S.perturbation())
+    if os.environ.get("WS_BENCH_POINT_ORDER") == "column":  # experiment: azimuth-major instead of ring-major cloud
+        perturbed = np.ascontiguousarray(perturbed.reshape(S.RINGS, S.AZIMUTHS, 3).transpose(1, 0, 2).reshape(-1, 3))
     d_points = torch.from_numpy(points).cuda()
     d_pert = torch.from_numpy(perturbed).cuda()
     n = points.shape[0]
     eye = np.eye(4, dtype=np.float32)
     backend = HipGnBackend(reg, tsdf, res)
     force_sharded = os.environ.get("WS_BENCH_FORCE_SHARDED") == "1"  # exercise the multi-rank driver on one rank
-    reg.prepare_registration(d_pert)  # resident in HBM before the timed region
+    reg.prepare_registration(d_pert)
     its = []
 
     def step():
         tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
         if args.no_registration:
             return
+        # TSDFRegistration::register_cloud starts with prepare_registration (tsdf_registration.cpp:50): the cloud is
+        # resident in HBM, so this is a device-to-device copy into the registration buffer, inside the timed region
+        reg.prepare_registration(d_pert)
         if world == 1 and not force_sharded:
             _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
         else:

@@ -69,24 +69,76 @@ __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask)
   return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// One stage of the transposing butterfly: lanes whose `BIT` is clear keep the lower HALF values and
-// receive the partner's lower half, the others keep/receive the upper half.
+// ---- transposing wave reduction of 32 int64 values, without the LDS crossbar -------------------------
+// Stage `BIT` pairs lane l with lane l ^ BIT: lanes whose BIT is clear keep the lower HALF of the values they
+// still carry and receive the partner's lower half, the others keep / receive the upper half, so every stage
+// halves the values per lane: 16+8+4+2+1+1 = 32 exchanges for 32 values instead of 32 x 6.
+//   BIT 32, 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange exactly those halves of two registers
+//               (no select, no address): one VALU instruction per 32-bit register pair;
+//   BIT 8 .. 1: DPP lane permutations (row_ror:8, row_half_mirror + quad_perm, quad_perm).
+__device__ __forceinline__ int64_t pack64(int lo, int hi) { return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); }
+
+template <int BIT>
+__device__ __forceinline__ void swap_add_stage(int64_t &a, const int64_t b)
+{
+  // a: the value kept by lanes with BIT clear, b: kept by lanes with BIT set; result in a (for every lane: its kept slot)
+  const int alo = (int)(uint32_t)((uint64_t)a & 0xffffffffull), ahi = (int)(uint32_t)((uint64_t)a >> 32);
+  const int blo = (int)(uint32_t)((uint64_t)b & 0xffffffffull), bhi = (int)(uint32_t)((uint64_t)b >> 32);
+  if constexpr (BIT == 32)
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = wadd64(pack64(lo[0], hi[0]), pack64(lo[1], hi[1]));
+  }
+  else
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = wadd64(pack64(lo[0], hi[0]), pack64(lo[1], hi[1]));
+  }
+}
+
+template <int BIT>
+__device__ __forceinline__ int dpp_xor(int v)
+{
+  if constexpr (BIT == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); // row_ror:8
+  if constexpr (BIT == 4)
+  {
+    const int m = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); // row_half_mirror: lane ^ 7
+    return __builtin_amdgcn_update_dpp(0, m, 0x1b, 0xf, 0xf, false);         // quad_perm [3,2,1,0]: lane ^ 3
+  }
+  if constexpr (BIT == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+  return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);                         // quad_perm [1,0,3,2]
+}
+template <int BIT>
+__device__ __forceinline__ int64_t dpp_xor_i64(int64_t v)
+{
+  return pack64(dpp_xor<BIT>((int)(uint32_t)((uint64_t)v & 0xffffffffull)), dpp_xor<BIT>((int)(uint32_t)((uint64_t)v >> 32)));
+}
+
 template <int HALF, int BIT>
 __device__ __forceinline__ void reduce_stage(int64_t (&v)[REG_SLOTS], int lane)
 {
-  const bool upper = (lane & BIT) != 0;
-#pragma unroll
-  for (int i = 0; i < HALF; ++i)
+  if constexpr (BIT >= 16)
   {
-    const int64_t send = upper ? v[i] : v[i + HALF];
-    const int64_t keep = upper ? v[i + HALF] : v[i];
-    v[i] = wadd64(keep, shfl_xor_i64(send, BIT));
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) swap_add_stage<BIT>(v[i], v[i + HALF]);
+  }
+  else
+  {
+    const bool upper = (lane & BIT) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i)
+    {
+      const int64_t send = upper ? v[i] : v[i + HALF];
+      const int64_t keep = upper ? v[i + HALF] : v[i];
+      v[i] = wadd64(keep, dpp_xor_i64<BIT>(send));
+    }
   }
 }
 
 // Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
-// trailing barrier). Every stage halves the values a lane still carries, so a wave needs
-// 16+8+4+2+1+1 = 32 exchanges for 32 values instead of 32 x 6.
+// trailing barrier).
 __device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS], int64_t *red)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -95,7 +147,7 @@ __device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t 
   reduce_stage<4, 8>(v, lane);
   reduce_stage<2, 4>(v, lane);
   reduce_stage<1, 2>(v, lane);
-  v[0] = wadd64(v[0], shfl_xor_i64(v[0], 1));
+  v[0] = wadd64(v[0], dpp_xor_i64<1>(v[0]));
   // lane l now holds the wave total of slot (l >> 1)
   if ((lane & 1) == 0) wave_part[wave][lane >> 1] = v[0];
   __syncthreads();
