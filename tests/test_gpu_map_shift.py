@@ -76,3 +76,53 @@ def test_update_after_shift_matches_oracle():
     on = oa.copy()
     O.update_tsdf(oa, on, pts, pos, (0, 0, 32768), tau, mw, res)
     assert np.array_equal(got.data_, oa.data)
+
+
+def test_write_back_exports_device_map_to_h5(tmp_path):
+    """TSDFMapping.write_back: chunks gathered from the device ring buffer and written to the .h5 file
+    == the host path of the reference (whole-map download, HDF5LocalMap::write_back voxel by voxel), after an update
+    on a shifted window so the ring-buffer offsets are non-trivial."""
+    import torch
+    from warpsense_amd import build
+    if build.find_hdf5() is None or build.build_h5() is None:
+        pytest.skip("no HDF5 C library on this box")
+    import warpsense_amd as W
+    tau, res, size = 1000, 50, (96, 80, 72)
+    path = str(tmp_path / "export.h5")
+    mp = W.MapParams(resolution=res, max_distance=1.0, max_weight=10, size=tuple(s * res / 1000.0 for s in size))
+    g = W.GlobalMap(tau, 0, filename=path, map_params=mp)
+    lm = W.LocalMap(*size, tau, 0, g)
+    tm = W.TSDFMapping(W.Params(mp), lm)
+    tm.shift_map((37, -50, 11))  # window straddles chunk borders in every axis, negative chunk ids in y
+    sensor = (37 * res + 10, -50 * res + 7, 11 * res + 3)
+    pts = S.os1_128_scan(sensor_mm=sensor, rings=32, azimuths=256, half_extents_mm=(2100.0, 1700.0, 1500.0), seed=9)
+    pos = [int(np.floor(np.float32(s) / np.float32(res))) for s in sensor]
+    tm.update_tsdf(torch.from_numpy(pts).cuda(), pos_rm=pos, up_rm=(0, 0, 32768))
+    tm.write_back()
+    g.write_pose(np.eye(4), 1000.0)
+    g.close()
+
+    # the reference's route: download the window, save it voxel-for-voxel into a (memory-only) global map
+    host = _download(W, tm, lm)
+    ref_g = W.GlobalMap(tau, 0)
+    ref_lm = W.LocalMap(*size, tau, 0, ref_g)
+    ref_lm.pos[:], ref_lm.offset[:] = host.pos_, host.offset_
+    ref_lm.data[:] = host.data_
+    ref_lm.write_back()
+    assert np.count_nonzero(W.unpack_entry(host.data_)[1]) > 10_000  # the scan is in there
+
+    g2 = W.GlobalMap(tau, 0, filename=path, open_existing=True)
+    assert len(ref_g.chunks) >= 8
+    for key, want in ref_g.chunks.items():
+        assert np.array_equal(g2.activate_chunk(*key), want), key
+    # the file also holds the chunks the (still blank) slabs went to when the window was shifted: default entries only
+    import ctypes as C
+    n = C.c_int64(0)
+    g2._H.ws_h5_num_chunks(g2._file, C.byref(n))
+    pos_list = np.zeros((n.value, 3), dtype=np.int32)
+    g2._H.ws_h5_list_chunks(g2._file, pos_list.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    in_file = {tuple(int(v) for v in p) for p in pos_list}
+    assert set(ref_g.chunks) <= in_file
+    for key in in_file - set(ref_g.chunks):
+        assert np.all(g2.activate_chunk(*key) == W.pack_entry(tau, 0)), key
+    g2.close()

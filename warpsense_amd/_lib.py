@@ -35,6 +35,50 @@ class WsError(RuntimeError):
     pass
 
 
+H5_LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_h5.so")
+H5_EXPORTS = ["ws_h5_last_error", "ws_h5_create", "ws_h5_open", "ws_h5_close", "ws_h5_flush", "ws_h5_write_meta", "ws_h5_read_meta",
+              "ws_h5_write_chunk", "ws_h5_read_chunk", "ws_h5_num_chunks", "ws_h5_list_chunks", "ws_h5_write_pose", "ws_h5_num_poses",
+              "ws_h5_read_pose"]
+_h5 = None
+
+
+def h5_available() -> bool:
+    return os.path.exists(H5_LIB_PATH)
+
+
+def load_h5() -> C.CDLL:
+    """Load libwarpsense_h5.so (include/warpsense_h5.h); raises if it was not built (no HDF5 C library on the box)."""
+    global _h5
+    if _h5 is not None:
+        return _h5
+    if not os.path.exists(H5_LIB_PATH):
+        raise WsError(f"{H5_LIB_PATH} is missing: `python -m warpsense_amd.build` builds it where the HDF5 C library is installed")
+    L = C.CDLL(H5_LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    P = C.POINTER
+    L.ws_h5_last_error.restype = C.c_char_p
+    L.ws_h5_create.argtypes = [C.c_char_p, P(vp)]
+    L.ws_h5_open.argtypes = [C.c_char_p, C.c_int, P(vp)]
+    L.ws_h5_close.argtypes = [vp]
+    L.ws_h5_flush.argtypes = [vp]
+    L.ws_h5_write_meta.argtypes = [vp, i32, vp, C.c_float, i32, i32]
+    L.ws_h5_read_meta.argtypes = [vp, P(i32), vp, P(C.c_float), P(i32), P(i32)]
+    L.ws_h5_write_chunk.argtypes = [vp, i32, i32, i32, vp]
+    L.ws_h5_read_chunk.argtypes = [vp, i32, i32, i32, vp, P(i32)]
+    L.ws_h5_num_chunks.argtypes = [vp, P(i64)]
+    L.ws_h5_list_chunks.argtypes = [vp, vp, i64, P(i64)]
+    L.ws_h5_write_pose.argtypes = [vp, vp]
+    L.ws_h5_num_poses.argtypes = [vp, P(i64)]
+    L.ws_h5_read_pose.argtypes = [vp, i64, vp]
+    _h5 = L
+    return L
+
+
+def check_h5(rc: int, what: str):
+    if rc != 0:
+        raise WsError(f"{what}: {load_h5().ws_h5_last_error().decode(errors='replace')}")
+
+
 class TsdfStats(C.Structure):
     _fields_ = [("contested_voxels", C.c_int64), ("contested_records", C.c_int64), ("dirty_tiles", C.c_int64),
                 ("error_flags", C.c_int32), ("pad", C.c_int32), ("tile_records", C.c_int64), ("tile_work_items", C.c_int64)]

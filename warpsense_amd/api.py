@@ -139,24 +139,145 @@ class DeviceMap:
         return int(np.prod(self.size_.astype(np.int64)))
 
 
+def pose_to_values(pose, scale: float) -> np.ndarray:
+    """The 7 floats HDF5GlobalMap::write_pose stores (hdf5_global_map.cpp:187-197): translation / scale and the
+    rotation as a quaternion (x, y, z, w), each rounded to 3 decimals.  The quaternion follows Eigen's
+    Quaternionf(Matrix3f) (trace branch / largest diagonal branch) in float32."""
+    P = np.asarray(pose, dtype=np.float64).reshape(4, 4)
+    out = np.zeros(7, dtype=np.float32)
+    for k in range(3):
+        # (double / float) * 1000.0f, std::round (half away from zero), / 1000.0f, stored as float
+        v = P[k, 3] / float(np.float32(scale)) * 1000.0
+        out[k] = np.float32(np.trunc(v + np.copysign(0.5, v)) / 1000.0)
+    m = P[:3, :3].astype(np.float32)
+    f = np.float32
+    q = np.zeros(4, dtype=np.float32)  # x y z w
+    t = f(m[0, 0] + m[1, 1] + m[2, 2])
+    if t > 0:
+        t = f(np.sqrt(f(t + f(1))))
+        q[3] = f(f(0.5) * t)
+        t = f(f(0.5) / t)
+        q[0] = f(f(m[2, 1] - m[1, 2]) * t)
+        q[1] = f(f(m[0, 2] - m[2, 0]) * t)
+        q[2] = f(f(m[1, 0] - m[0, 1]) * t)
+    else:
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = f(np.sqrt(f(f(f(m[i, i] - m[j, j]) - m[k, k]) + f(1))))
+        q[i] = f(f(0.5) * t)
+        t = f(f(0.5) / t)
+        q[3] = f(f(m[k, j] - m[j, k]) * t)
+        q[j] = f(f(m[j, i] + m[i, j]) * t)
+        q[k] = f(f(m[k, i] + m[i, k]) * t)
+    for n in range(4):
+        v = f(q[n] * f(1000.0))
+        out[3 + n] = f(f(np.trunc(v + np.copysign(f(0.5), v))) / f(1000.0))
+    return out
+
+
 class GlobalMap:
-    """In-memory stand-in for HDF5GlobalMap's chunk store (src/map/hdf5_global_map.cpp:59-173): the world is cut
-    into 64^3-voxel chunks of raw uint32 entries, index x*4096 + y*64 + z inside a chunk (:53-57), unseen chunks
-    are filled with the default entry.  (Writing the chunks to an .h5 file is a "next" row)"""
+    """HDF5GlobalMap (src/map/hdf5_global_map.cpp): the world is cut into 64^3-voxel chunks of raw uint32
+    entries, index x*4096 + y*64 + z inside a chunk (:53-57); chunks never seen hold the default entry.
+
+    Without `filename` every chunk stays in memory.  With `filename` the map is the reference's .h5 file
+    (layout in include/warpsense_h5.h, written through libwarpsense_h5.so): at most NUM_CHUNKS = 64 chunks are
+    active, the least recently used one is written to the file when a 65th is needed (:59-135), write_back()
+    flushes the active ones (:160-176), write_pose()/write_meta() as :178-221."""
 
     CHUNK_SIZE = 64
+    NUM_CHUNKS = 64  # hdf5_global_map.h:78
 
-    def __init__(self, default_value, default_weight=0):
+    def __init__(self, default_value, default_weight=0, filename: str | None = None, map_params=None, open_existing: bool = False):
+        from collections import OrderedDict
         self.default_raw = int(pack_entry(default_value, default_weight))
-        self.chunks: dict[tuple[int, int, int], np.ndarray] = {}
+        self.chunks: "OrderedDict[tuple[int, int, int], np.ndarray]" = OrderedDict()
+        self._file = None
+        self._filename = filename
+        if filename is not None:
+            self._H = _lib.load_h5()
+            h = C.c_void_p()
+            if open_existing:
+                _lib.check_h5(self._H.ws_h5_open(filename.encode(), 1, C.byref(h)), "ws_h5_open")
+            else:
+                _lib.check_h5(self._H.ws_h5_create(filename.encode(), C.byref(h)), "ws_h5_create")
+            self._file = h
+            if map_params is not None and not open_existing:
+                self.write_meta(map_params)
+
+    def filename(self):
+        return self._filename
+
+    # -- chunk cache --------------------------------------------------------------------------------
+    def _write_chunk(self, key, data):
+        _lib.check_h5(self._H.ws_h5_write_chunk(self._file, key[0], key[1], key[2], _ptr(data)), "ws_h5_write_chunk")
 
     def activate_chunk(self, cx, cy, cz) -> np.ndarray:
         key = (int(cx), int(cy), int(cz))
         c = self.chunks.get(key)
-        if c is None:
-            c = np.full(self.CHUNK_SIZE ** 3, self.default_raw, dtype=np.uint32)
-            self.chunks[key] = c
+        if c is not None:
+            if self._file is not None:
+                self.chunks.move_to_end(key)  # age 0
+            return c
+        c = np.empty(self.CHUNK_SIZE ** 3, dtype=np.uint32)
+        found = C.c_int32(0)
+        if self._file is not None:
+            _lib.check_h5(self._H.ws_h5_read_chunk(self._file, key[0], key[1], key[2], _ptr(c), C.byref(found)), "ws_h5_read_chunk")
+        if not found.value:
+            c.fill(self.default_raw)
+        if self._file is not None and len(self.chunks) >= self.NUM_CHUNKS:
+            old_key, old = self.chunks.popitem(last=False)  # the oldest chunk goes to the file
+            self._write_chunk(old_key, old)
+        self.chunks[key] = c
         return c
+
+    def get_value(self, x, y, z):
+        cs = self.CHUNK_SIZE
+        cx, cy, cz = int(x) // cs, int(y) // cs, int(z) // cs  # floor_divide, also for negative coordinates
+        c = self.activate_chunk(cx, cy, cz)
+        v, w = unpack_entry(c[(int(x) - cx * cs) * cs * cs + (int(y) - cy * cs) * cs + (int(z) - cz * cs)])
+        return int(v), int(w)
+
+    def set_value(self, x, y, z, value, weight):
+        cs = self.CHUNK_SIZE
+        cx, cy, cz = int(x) // cs, int(y) // cs, int(z) // cs
+        c = self.activate_chunk(cx, cy, cz)
+        c[(int(x) - cx * cs) * cs * cs + (int(y) - cy * cs) * cs + (int(z) - cz * cs)] = pack_entry(value, weight)
+
+    def write_back(self):
+        if self._file is None:
+            return
+        for key, data in self.chunks.items():
+            self._write_chunk(key, data)
+        _lib.check_h5(self._H.ws_h5_flush(self._file), "ws_h5_flush")
+
+    def write_pose(self, pose, scale: float):
+        if self._file is None:
+            raise WsError("write_pose: this GlobalMap has no file")
+        vals = pose_to_values(pose, scale)
+        _lib.check_h5(self._H.ws_h5_write_pose(self._file, _ptr(vals)), "ws_h5_write_pose")
+        return vals
+
+    def write_meta(self, p):
+        """p: MapParams (tau, size in voxels, max_distance, resolution, max_weight scaled like map_params.h:88-90)."""
+        size = np.asarray(p.size_voxels(), dtype=np.int32)
+        _lib.check_h5(self._H.ws_h5_write_meta(self._file, int(p.tau), _ptr(size), C.c_float(p.max_distance), int(p.resolution),
+                                               int(p.max_weight)), "ws_h5_write_meta")
+
+    def close(self):
+        if self._file is not None:
+            self.write_back()
+            self._H.ws_h5_close(self._file)
+            self._file = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _box(self, lo, hi, buf, save: bool):
         """Move a dense world-voxel box (inclusive, x major / z fastest) between `buf` and the chunks."""
@@ -480,11 +601,15 @@ class MapParams:
 
     def __init__(self, resolution=64, max_distance=1.0, max_weight=10, size=(40.0, 40.0, 25.0), shift=10.0, initial_weight=0):
         self.resolution = int(resolution)
+        self.max_distance = float(max_distance)
         self.tau = int(max_distance * 1000)
         self.max_weight = int(max_weight * WEIGHT_RESOLUTION)
         self.size = tuple(int(s * 1000 / self.resolution) for s in size)
         self.shift = float(shift)
         self.initial_weight = int(initial_weight)
+
+    def size_voxels(self):
+        return self.size
 
 
 class RegistrationParams:
@@ -558,6 +683,26 @@ class TSDFMapping:
                 else:
                     end[axis] = start[axis] - d - 1
                 avg.insert_box(start, end, lm.map_.load_box(start, end))
+
+
+    def write_back(self):
+        """HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:220) from the
+        DEVICE map: every 64^3 chunk the window overlaps is gathered out of the ring buffer by the GPU
+        (ws_map_extract_box: chunk layout, x major / z fastest), merged into the global map's chunk and written to
+        its file.  The reference downloads the whole window and copies voxel by voxel on the host."""
+        lm, avg = self.local_map_, self.tsdf_.avg_map()
+        cs = GlobalMap.CHUNK_SIZE
+        with self.mutex_:
+            half = lm.size.astype(np.int64) // 2
+            lo, hi = lm.pos.astype(np.int64) - half, lm.pos.astype(np.int64) + half
+            c0, c1 = np.floor_divide(lo, cs), np.floor_divide(hi, cs)
+            for cx in range(c0[0], c1[0] + 1):
+                for cy in range(c0[1], c1[1] + 1):
+                    for cz in range(c0[2], c1[2] + 1):
+                        base = np.array([cx, cy, cz], dtype=np.int64) * cs
+                        a, b = np.maximum(lo, base), np.minimum(hi, base + cs - 1)
+                        lm.map_.save_box(a, b, avg.extract_box(a, b))
+            lm.map_.write_back()
 
 
 class TSDFRegistration(TSDFMapping):

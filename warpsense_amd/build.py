@@ -16,6 +16,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
+H5_LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_h5.so")  # optional: global-map file (needs the HDF5 C library)
 SOURCES = ["api.hip", "tsdf_update.hip", "tsdf_tiles.hip", "registration.hip"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_device.h"), os.path.join(CSRC, "ws_march.h"),
            os.path.join(CSRC, "ws_tiles.h"),
@@ -71,5 +72,44 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def find_hdf5() -> tuple[str, str] | None:
+    """(include dir, lib dir) of an installed HDF5 C library, or None."""
+    roots = [os.environ.get("HDF5_ROOT"), "/opt/conda", "/usr", "/usr/local"]
+    layouts = [("include", "lib"), ("include/hdf5/serial", "lib/x86_64-linux-gnu/hdf5/serial"), ("include", "lib/x86_64-linux-gnu"),
+               ("include", "lib64")]
+    for root in roots:
+        if not root:
+            continue
+        for inc, lib in layouts:
+            i, l = os.path.join(root, inc), os.path.join(root, lib)
+            if os.path.exists(os.path.join(i, "hdf5.h")) and os.path.exists(os.path.join(l, "libhdf5.so")):
+                return i, l
+    return None
+
+
+def build_h5(force: bool = False, verbose: bool = False) -> str | None:
+    """libwarpsense_h5.so (include/warpsense_h5.h) with the host C++ compiler; None when HDF5 is not installed."""
+    src = os.path.join(CSRC, "ws_h5.cpp")
+    hdr = os.path.join(ROOT, "include", "warpsense_h5.h")
+    found = find_hdf5()
+    if found is None:
+        return None
+    if not force and os.path.exists(H5_LIB_PATH) and os.path.getmtime(H5_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return H5_LIB_PATH
+    inc, lib = found
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        return None
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", f"-I{os.path.join(ROOT, 'include')}", f"-I{inc}", src, "-o", H5_LIB_PATH,
+           f"-L{lib}", "-lhdf5", f"-Wl,-rpath,{lib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("building libwarpsense_h5.so failed:\n" + r.stdout.decode(errors="replace"))
+    return H5_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    print(build_h5(force="--force" in sys.argv, verbose=True) or "libwarpsense_h5.so: skipped (no HDF5 C library found)")

@@ -55,6 +55,7 @@ struct MarchArgs
   uint32_t arena_cap;
   uint32_t arena_slice;    // records reserved per workgroup of the collect pass
   int32_t collect_min_len; // COLLECT: steps below this length cannot reach a contested voxel
+  int32_t tag_in_vstate;   // COLLECT: contested voxels are marked VOX_CONTESTED in vstate (split scatter), else by kpos
 };
 
 // Bump allocation for the lanes that reach this point together: one atomic per wave, not per lane.
@@ -100,7 +101,7 @@ enum
   MARCH_EMIT_KEYED = 2, // pass 1 of the split scatter: the ray tails (fan and near-surface candidates) -> order keys
   MARCH_EMIT_FREE = 3   // pass 2: the steps before the tails, all free space (tau, +64) -> one byte per voxel, no atomics
 };
-constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
+constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_CONTESTED = 4; // CONTESTED: between resolve and resolve_lists only
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
@@ -369,7 +370,9 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
     }
     else
     {
-      if (a.kpos[idx] == KEY_CONTESTED_TAG)
+      // one byte per candidate where the split scatter keeps them (128 voxels per line instead of 16)
+      const bool tagged = a.tag_in_vstate ? a.vstate[idx] == VOX_CONTESTED : a.kpos[idx] == KEY_CONTESTED_TAG;
+      if (tagged)
       {
         const uint32_t rec = block_alloc(&record_cursor, blockIdx.x * a.arena_slice, a.arena_slice, &a.counters->records,
                                          gridDim.x * a.arena_slice);
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
       // contested: tag the voxel; its kneg word becomes the (empty) head of the candidate list
       a.kpos[idx] = KEY_CONTESTED_TAG;
       a.kneg[idx] = 0xffffffffull;
+      if (a.split) a.vstate[idx] = VOX_CONTESTED;
       n_contested += 1;
     }
   }
@@ -546,7 +550,13 @@ __global__ __launch_bounds__(256) void resolve_lists_kernel(ResolveArgs a)
   {
     const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
     if (idx >= a.n_vox) continue;
-    if (a.kpos[idx] != KEY_CONTESTED_TAG) continue;
+    if (a.split)
+    {
+      if (a.vstate[idx] != VOX_CONTESTED) continue;
+      a.vstate[idx] = 0;
+    }
+    else if (a.kpos[idx] != KEY_CONTESTED_TAG)
+      continue;
     const uint32_t head = (uint32_t)(a.kneg[idx] & 0xffffffffull);
     const uint32_t state = HAS_S0 ? a.new_data[idx] : pack_entry(a.tau, 0);
     int32_t sv = entry_value(state), sw = entry_weight(state);
@@ -808,6 +818,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.counters = m->counters;
   ra.vstate = m->vstate;
   ra.split = (m->scatter_mode != WS_SCATTER_TILES && m->new_is_default) ? 1 : 0;
+  ma.tag_in_vstate = ra.split;
   ra.contested_per_wave = m->contested_per_wave;
   ra.arena = m->arena;
   ra.arena_cap = m->arena_cap;
