@@ -34,6 +34,7 @@ extern "C" {
 
 typedef struct ws_context ws_context; /* one per (process, GPU): device id + stream                          */
 typedef struct ws_map ws_map;         /* cuda::TSDFCuda: avg_map_ + new_map_ + scan buffer (update_tsdf.h:9-34) */
+typedef struct ws_scan ws_scan;       /* scan pre-processing buffers: App::preprocess (src/warpsense/app.cpp:119-148)   */
 typedef struct ws_reg ws_reg;         /* cuda::RegistrationCuda (registration.h:10-45)                          */
 
 typedef enum
@@ -158,6 +159,23 @@ int ws_reg_accumulate_dev(ws_reg *reg, const ws_map *map, int32_t map_resolution
                           size_t count, int64_t *sums_dev /* 44 */);
 int ws_reg_solve_dev(ws_reg *reg, const int64_t *sums_dev /* 44 */);
 int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out[16]); /* synchronises */
+
+/* ------------------------------------------------------------------ scan pre-processing ---- */
+/* App::preprocess — src/warpsense/app.cpp:119-148, on the device: sensor points in float metres
+ * (x y z first, `stride_floats` floats per point, e.g. 3, or 4 for PointXYZI) are dropped if x, y and z are all
+ * < 0.3, scaled to mm, snapped to the centre of their `map_resolution` voxel, transformed by to_int_mat(pose)
+ * (pose: 4x4 column-major, translation in mm) and de-duplicated.  Output: int32 mm points in the order of their
+ * first occurrence in the input (the reference's unordered_set order is unspecified), resident on the device
+ * until the next call: feed ws_scan_points_dev() to ws_tsdf_update_dev / ws_reg_prepare_dev.  Synchronises
+ * (the count comes back to the host).  WS_ERR_RANGE: a transformed coordinate beyond +-2^20 mm. */
+int ws_scan_create(ws_context *ctx, size_t max_points, ws_scan **out);
+int ws_scan_destroy(ws_scan *scan);
+int ws_scan_preprocess(ws_scan *scan, const float *xyz_host, size_t n, size_t stride_floats, const float pose[16],
+                       int32_t map_resolution, size_t *n_out);
+int ws_scan_preprocess_dev(ws_scan *scan, const float *xyz_dev, size_t n, size_t stride_floats, const float pose[16],
+                           int32_t map_resolution, size_t *n_out);
+const int32_t *ws_scan_points_dev(const ws_scan *scan); /* n_out x 3 int32, device memory */
+int ws_scan_download(ws_scan *scan, int32_t *xyz_host, size_t capacity_points, size_t *n_out);
 
 /* ------------------------------------------------------------------ measurement ---- */
 /* Kernel classes for hipEvent timing (bench.py's roofline leg). */

@@ -545,3 +545,65 @@ int wso_register_cloud(const wso_map *map, const int32_t *xyz, size_t n, const f
   memcpy(T_out, st.T, 16 * sizeof(float));
   return st.iterations;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * App::preprocess — src/warpsense/app.cpp:119-148.
+ *   :129-132  skip the point if x < 0.3 && y < 0.3 && z < 0.3 (floats compared with the double literal)
+ *   :134      Pointf(x * 1000.f, y * 1000.f, z * 1000.f)
+ *   :135-140  voxel centre = (int)(std::floor(p / res) * res + res / 2): float / int, float * int, int / int
+ *   :142      transform_point(voxel_center, to_int_mat(pose_)) — util/util.h:20-34, int arithmetic, / 32768
+ *   :123,142-146  unordered_set<Pointi>: every distinct point once; iteration order is the implementation's,
+ *             so the restatement fixes it: order of first occurrence.
+ * Non-finite coordinates (undefined behaviour in the reference: float -> int of NaN) are skipped.
+ */
+static int pre_cmp(const void *a, const void *b)
+{
+  const int64_t *x = (const int64_t *)a, *y = (const int64_t *)b;
+  for (int k = 0; k < 3; ++k)
+    if (x[k] != y[k]) return x[k] < y[k] ? -1 : 1;
+  return x[3] < y[3] ? -1 : (x[3] > y[3] ? 1 : 0); /* ties: input index, so the first occurrence sorts first */
+}
+
+size_t wso_preprocess(const float *xyz, size_t n, size_t stride, const float pose[16], int32_t res, int32_t *out)
+{
+  int32_t M[16];
+  wso_to_int_mat(pose, M);
+  /* (x, y, z, index) of every surviving point, sorted to find duplicates, then put back in input order */
+  int64_t *rec = (int64_t *)malloc((n ? n : 1) * 4 * sizeof(int64_t));
+  unsigned char *keep = (unsigned char *)calloc(n ? n : 1, 1);
+  int32_t *pts = (int32_t *)malloc((n ? n : 1) * 3 * sizeof(int32_t));
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+  {
+    const float x = xyz[i * stride + 0], y = xyz[i * stride + 1], z = xyz[i * stride + 2];
+    if (!isfinite(x) || !isfinite(y) || !isfinite(z)) continue;
+    if (x < 0.3 && y < 0.3 && z < 0.3) continue;
+    const float px = x * 1000.f, py = y * 1000.f, pz = z * 1000.f;
+    int32_t c[3], q[3];
+    c[0] = (int32_t)(floorf(px / (float)res) * (float)res + (float)(res / 2));
+    c[1] = (int32_t)(floorf(py / (float)res) * (float)res + (float)(res / 2));
+    c[2] = (int32_t)(floorf(pz / (float)res) * (float)res + (float)(res / 2));
+    wso_transform_point(c, M, q);
+    for (int k = 0; k < 3; ++k) pts[3 * i + k] = q[k];
+    rec[4 * m + 0] = q[0];
+    rec[4 * m + 1] = q[1];
+    rec[4 * m + 2] = q[2];
+    rec[4 * m + 3] = (int64_t)i;
+    ++m;
+  }
+  qsort(rec, m, 4 * sizeof(int64_t), pre_cmp);
+  for (size_t j = 0; j < m; ++j)
+    if (j == 0 || rec[4 * j + 0] != rec[4 * (j - 1) + 0] || rec[4 * j + 1] != rec[4 * (j - 1) + 1] || rec[4 * j + 2] != rec[4 * (j - 1) + 2])
+      keep[rec[4 * j + 3]] = 1;
+  size_t n_out = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (keep[i])
+    {
+      for (int k = 0; k < 3; ++k) out[3 * n_out + k] = pts[3 * i + k];
+      ++n_out;
+    }
+  free(rec);
+  free(keep);
+  free(pts);
+  return n_out;
+}

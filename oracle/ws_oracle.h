@@ -118,6 +118,12 @@ int wso_register_cloud(const wso_map *map, const int32_t *xyz, size_t n, const f
                        int32_t max_iterations, float it_weight_gradient, float epsilon, int32_t res,
                        uint32_t flags, float T_out[16], int64_t *trace, int32_t trace_cap);
 
+/* ---- scan pre-processing (App::preprocess, src/warpsense/app.cpp:119-148) ----
+ * xyz: n points in float metres, `stride` floats apart; pose: 4x4 column-major, translation in mm.
+ * out: at most n points (int32 mm), each distinct transformed voxel centre once, in the order of its first
+ * occurrence in the input (the reference's unordered_set leaves the order unspecified). Returns the count. */
+size_t wso_preprocess(const float *xyz, size_t n, size_t stride, const float pose[16], int32_t res, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

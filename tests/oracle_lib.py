@@ -74,6 +74,8 @@ def lib():
         L.wso_to_map.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.wso_xi_to_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.wso_solve6.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wso_preprocess.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]
+        L.wso_preprocess.restype = C.c_size_t
     return _lib
 
 
@@ -280,3 +282,14 @@ def ref_lib():
     L.ref_matrix4_layout.argtypes = [C.c_void_p]
     L.ref_matrix6_layout.argtypes = [C.c_void_p]
     return L
+
+
+def preprocess(xyz_f32, pose_rowmajor, res):
+    """App::preprocess (app.cpp:119-148): (n, k>=3) float32 metres -> (m, 3) int32 mm, first-occurrence order."""
+    L = lib()
+    a = np.ascontiguousarray(xyz_f32, dtype=np.float32)
+    n, stride = a.shape
+    T = np.ascontiguousarray(np.asarray(pose_rowmajor, dtype=np.float32).reshape(4, 4).T).reshape(16)
+    out = np.zeros((max(n, 1), 3), dtype=np.int32)
+    m = L.wso_preprocess(a.ctypes.data_as(C.c_void_p), n, stride, T.ctypes.data_as(C.c_void_p), int(res), out.ctypes.data_as(C.c_void_p))
+    return out[:m].copy()

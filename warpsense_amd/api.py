@@ -585,6 +585,70 @@ class RegistrationCuda:
             pass
 
 
+class DevicePoints:
+    """(n, 3) int32 points resident on the device (what ScanPreprocessor returns); accepted wherever a CUDA
+    tensor of points is (TSDFCuda.update_tsdf, RegistrationCuda.prepare_registration)."""
+
+    is_cuda = True
+
+    def __init__(self, ptr: int, n: int, owner):
+        self._ptr, self.shape, self._owner = int(ptr), (int(n), 3), owner
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def __len__(self):
+        return self.shape[0]
+
+    def to_host(self) -> np.ndarray:
+        return self._owner.download()
+
+
+class ScanPreprocessor:
+    """App::preprocess on the device (src/warpsense/app.cpp:119-148): sensor cloud in float metres -> distinct
+    voxel-centre points in int mm, transformed by the pose, in first-occurrence order."""
+
+    def __init__(self, max_points: int = 128 * 1024, ctx: Context | None = None):
+        self.ctx = ctx or Context.default()
+        self._L = self.ctx._L
+        h = C.c_void_p()
+        check(self._L.ws_scan_create(self.ctx.handle, int(max_points), C.byref(h)), "ws_scan_create")
+        self.handle = h
+        self.n_out = 0
+
+    def preprocess(self, cloud, pose, map_resolution: int) -> DevicePoints:
+        """cloud: (n, k >= 3) float32, numpy or CUDA tensor (x y z first); pose: 4x4, translation in mm."""
+        n, stride = int(cloud.shape[0]), int(cloud.shape[1])
+        T = _colmajor(pose)
+        out = C.c_size_t(0)
+        if _is_device(cloud):
+            check(self._L.ws_scan_preprocess_dev(self.handle, _ptr(cloud), n, stride, _ptr(T), int(map_resolution), C.byref(out)),
+                  "ws_scan_preprocess_dev")
+        else:
+            a = np.ascontiguousarray(cloud, dtype=np.float32)
+            check(self._L.ws_scan_preprocess(self.handle, _ptr(a), n, stride, _ptr(T), int(map_resolution), C.byref(out)),
+                  "ws_scan_preprocess")
+        self.n_out = int(out.value)
+        return DevicePoints(self._L.ws_scan_points_dev(self.handle) or 0, self.n_out, self)
+
+    def download(self) -> np.ndarray:
+        pts = np.zeros((max(self.n_out, 1), 3), dtype=np.int32)
+        n = C.c_size_t(0)
+        check(self._L.ws_scan_download(self.handle, _ptr(pts), pts.shape[0], C.byref(n)), "ws_scan_download")
+        return pts[:int(n.value)].copy()
+
+    def close(self):
+        if self.handle:
+            self._L.ws_scan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def to_int_mat(mat):
     """(mat * MATRIX_RESOLUTION).cast<int>() — include/util/util.h:8-11."""
     return (np.asarray(mat, dtype=np.float32) * np.float32(MATRIX_RESOLUTION)).astype(np.int32)

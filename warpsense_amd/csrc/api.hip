@@ -678,6 +678,111 @@ int ws_reg_set_loop(ws_reg *r, int mode)
   return WS_OK;
 }
 
+// ------------------------------------------------------------------ scan pre-processing
+int ws_scan_destroy(ws_scan *sc)
+{
+  if (!sc) return WS_OK;
+  (void)hipStreamSynchronize(sc->ctx->stream);
+  void *dev[] = {sc->in_stage, sc->tmp, sc->slot_of, sc->keys, sc->first, sc->wg_count, sc->wg_off, sc->counters, sc->out};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  if (sc->host_count) (void)hipHostFree(sc->host_count);
+  delete sc;
+  return WS_OK;
+}
+
+int ws_scan_create(ws_context *ctx, size_t max_points, ws_scan **out)
+{
+  if (!ctx || !out) return invalid("ws_scan_create: NULL argument");
+  if (max_points == 0) max_points = 128 * 1024;
+  if (max_points > (1u << 30)) return invalid("ws_scan_create: too many points");
+  ws_scan *sc = new (std::nothrow) ws_scan();
+  if (!sc) return invalid("ws_scan_create: out of host memory");
+  sc->ctx = ctx;
+  sc->cap = max_points;
+  sc->table_slots = pre_table_slots(max_points);
+  const size_t blocks = (max_points + 255) / 256;
+  hipError_t e = hipMalloc((void **)&sc->tmp, max_points * 3 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->out, max_points * 3 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->slot_of, max_points * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->keys, sc->table_slots * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->first, sc->table_slots * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->wg_count, blocks * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->wg_off, blocks * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&sc->counters, 64);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&sc->host_count, 64, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&sc->host_count_dev, sc->host_count, 0);
+  if (e != hipSuccess)
+  {
+    const int rc = hip_fail(e, "ws_scan_create allocation", __FILE__, __LINE__);
+    ws_scan_destroy(sc);
+    return rc;
+  }
+  *out = sc;
+  return WS_OK;
+}
+
+static int scan_run(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const float pose[16], int32_t res, size_t *n_out)
+{
+  int32_t M[16];
+  for (int k = 0; k < 16; ++k) M[k] = (int32_t)(pose[k] * (float)MATRIX_RESOLUTION); // to_int_mat, util/util.h:8-11
+  int rc = launch_scan_preprocess(sc, xyz_dev, n, stride, M, res);
+  if (rc != WS_OK) return rc;
+  uint32_t counters[2] = {0, 0};
+  WS_HIP(hipMemcpyAsync(counters, sc->counters, sizeof counters, hipMemcpyDeviceToHost, sc->ctx->stream));
+  WS_HIP(hipStreamSynchronize(sc->ctx->stream));
+  sc->n_out = counters[0];
+  if (n_out) *n_out = sc->n_out;
+  if (counters[1] & 1u)
+  {
+    set_error("ws_scan_preprocess: a transformed coordinate is beyond +-2^20 mm");
+    return WS_ERR_RANGE;
+  }
+  return WS_OK;
+}
+
+int ws_scan_preprocess_dev(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const float pose[16], int32_t res, size_t *n_out)
+{
+  if (!sc || (!xyz_dev && n) || !pose) return invalid("ws_scan_preprocess_dev: NULL argument");
+  if (stride < 3) return invalid("ws_scan_preprocess_dev: a point needs at least 3 floats");
+  if (res < 1) return invalid("ws_scan_preprocess_dev: map_resolution must be positive");
+  if (n > sc->cap) return invalid("ws_scan_preprocess_dev: more points than ws_scan_create reserved");
+  return scan_run(sc, xyz_dev, n, stride, pose, res, n_out);
+}
+
+int ws_scan_preprocess(ws_scan *sc, const float *xyz_host, size_t n, size_t stride, const float pose[16], int32_t res, size_t *n_out)
+{
+  if (!sc || (!xyz_host && n) || !pose) return invalid("ws_scan_preprocess: NULL argument");
+  if (stride < 3) return invalid("ws_scan_preprocess: a point needs at least 3 floats");
+  if (res < 1) return invalid("ws_scan_preprocess: map_resolution must be positive");
+  if (n > sc->cap) return invalid("ws_scan_preprocess: more points than ws_scan_create reserved");
+  const size_t floats = n * stride;
+  if (floats > sc->in_stage_floats)
+  {
+    WS_HIP(hipStreamSynchronize(sc->ctx->stream));
+    if (sc->in_stage) WS_HIP(hipFree(sc->in_stage));
+    sc->in_stage = nullptr;
+    sc->in_stage_floats = 0;
+    WS_HIP(hipMalloc((void **)&sc->in_stage, floats * sizeof(float)));
+    sc->in_stage_floats = floats;
+  }
+  if (floats) WS_HIP(hipMemcpyAsync(sc->in_stage, xyz_host, floats * sizeof(float), hipMemcpyHostToDevice, sc->ctx->stream));
+  return scan_run(sc, sc->in_stage, n, stride, pose, res, n_out);
+}
+
+const int32_t *ws_scan_points_dev(const ws_scan *sc) { return sc ? sc->out : nullptr; }
+
+int ws_scan_download(ws_scan *sc, int32_t *xyz_host, size_t capacity_points, size_t *n_out)
+{
+  if (!sc || !n_out) return invalid("ws_scan_download: NULL argument");
+  *n_out = sc->n_out;
+  if (sc->n_out == 0) return WS_OK;
+  if (!xyz_host || capacity_points < sc->n_out) return invalid("ws_scan_download: buffer too small");
+  WS_HIP(hipMemcpyAsync(xyz_host, sc->out, sc->n_out * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, sc->ctx->stream));
+  WS_HIP(hipStreamSynchronize(sc->ctx->stream));
+  return WS_OK;
+}
+
 // ------------------------------------------------------------------ measurement
 int ws_prof_enable(ws_context *ctx, uint32_t class_mask)
 {

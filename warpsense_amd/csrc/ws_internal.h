@@ -149,6 +149,27 @@ struct ws_reg
   int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
 };
 
+// scan pre-processing buffers (App::preprocess on the device, scan_preprocess.hip)
+struct ws_scan
+{
+  ws_context *ctx = nullptr;
+  size_t cap = 0;         // points
+  size_t table_slots = 0; // power of two >= 2 * cap
+  float *in_stage = nullptr;
+  size_t in_stage_floats = 0;
+  int32_t *tmp = nullptr;
+  uint32_t *slot_of = nullptr;
+  uint64_t *keys = nullptr;
+  uint32_t *first = nullptr;
+  uint32_t *wg_count = nullptr;
+  uint32_t *wg_off = nullptr;
+  uint32_t *counters = nullptr;
+  int32_t *out = nullptr;
+  uint32_t *host_count = nullptr;     // pinned + mapped
+  uint32_t *host_count_dev = nullptr;
+  size_t n_out = 0;
+};
+
 namespace ws
 {
 void set_error(const std::string &msg);
@@ -177,6 +198,8 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
                           size_t first, size_t count, int64_t *sums_dev);
 int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
+int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
+size_t pre_table_slots(size_t max_points);
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags);
 int reg_loop_supported(int device);
 size_t reg_barrier_bytes();
