@@ -759,13 +759,12 @@ class TSDFMapping:
         with self.mutex_:
             half = lm.size.astype(np.int64) // 2
             lo, hi = lm.pos.astype(np.int64) - half, lm.pos.astype(np.int64) + half
-            c0, c1 = np.floor_divide(lo, cs), np.floor_divide(hi, cs)
-            for cx in range(c0[0], c1[0] + 1):
-                for cy in range(c0[1], c1[1] + 1):
-                    for cz in range(c0[2], c1[2] + 1):
-                        base = np.array([cx, cy, cz], dtype=np.int64) * cs
-                        a, b = np.maximum(lo, base), np.minimum(hi, base + cs - 1)
-                        lm.map_.save_box(a, b, avg.extract_box(a, b))
+            # one gather per 64-voxel-thick x slab of chunks (a few large device->host copies instead of one small one
+            # per chunk); save_box cuts the slab into its chunks
+            for cx in range(int(np.floor_divide(lo[0], cs)), int(np.floor_divide(hi[0], cs)) + 1):
+                a, b = lo.copy(), hi.copy()
+                a[0], b[0] = max(lo[0], cx * cs), min(hi[0], cx * cs + cs - 1)
+                lm.map_.save_box(a, b, avg.extract_box(a, b))
             lm.map_.write_back()
 
 
