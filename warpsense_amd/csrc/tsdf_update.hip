@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   // lists) do scattered 8-byte atomics near the surface: there a wave takes 64 rays of the same azimuth bin
   // (ray_order) at the same quarter of the tail, so its lanes hit voxels of the same vertical plane — z-neighbours,
   // i.e. the same cache lines — and one wave-wide atomic touches a handful of lines instead of 64.
-  constexpr bool TAIL = (MODE == MARCH_EMIT_KEYED);
+  constexpr bool TAIL = (MODE == MARCH_EMIT_KEYED); // (the collect pass is slower with this mapping: 308 vs 242 us)
 #ifndef WS_FULL_LANES
 #define WS_FULL_LANES 32
 #endif
@@ -345,9 +345,21 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
     }
     if (MODE == MARCH_EMIT_KEYED)
     {
-      if (a.vstate[idx] != VOX_KEYED) a.vstate[idx] = VOX_KEYED;
+      // Ray tails: three fire-and-forget operations per candidate, nothing the lane has to wait for.  Measured on
+      // MI355X (tools/keyed_exp.sh): reading vstate / the key first to skip redundant stores and atomics makes
+      // every step wait for a scattered load (610 us for the pass); unconditional stores + atomicMin 395 us, of
+      // which the 7.5 M scattered 64-bit atomics are 390 (~19 G atomics/s, the same at workgroup and agent scope)
+      // and the march arithmetic 153.  The tails are spread over the surfaces, so the byte stores do not pile up
+      // on one address the way they would near the sensor (the full-ray EMIT pass below keeps its pre-read).
+      a.vstate[idx] = VOX_KEYED;
+      a.dirty[idx >> TILE_SHIFT] = 1;
+      if (positive)
+        atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)make_kpos(t, value));
+      else
+        atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)make_kneg(t, value));
+      return;
     }
-    if (MODE == MARCH_EMIT || MODE == MARCH_EMIT_KEYED)
+    if (MODE == MARCH_EMIT)
     {
       // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
       // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
