@@ -174,12 +174,13 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
           r.div_m = fd.M;
           r.div_k = fd.k;
           // conditions of march_steps_fast (ws_march.h): no int32 wrap in d*len, pos + d, voxel centres,
-          // delta_z*iv and step*res*iv
+          // delta_z*iv and step*res*iv, nor in the squared distance to the hit point (|p - centre| <= len_end + 2 res)
           const int64_t dmax = max(max(llabs((long long)dx), llabs((long long)dy)), llabs((long long)dz));
           const int64_t pmax = max(max(llabs((long long)posx), llabs((long long)posy)), llabs((long long)posz));
           const int64_t ivmax = max(max(llabs(ivx), llabs(ivy)), llabs(ivz));
           const bool fast = dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
-                            (2 * max_delta_z + res) * ivmax < (1ll << 31);
+                            (2 * max_delta_z + res) * ivmax < (1ll << 31) &&
+                            (len_end + 2 * (int64_t)res) * (len_end + 2 * (int64_t)res) < (1ll << 31);
           r.pad = fast ? 1 : 0;
         }
       }
@@ -267,8 +268,12 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
 #ifndef WS_FULL_LANES
 #define WS_FULL_LANES 32
 #endif
-  constexpr int LANES = TAIL ? 4 : WS_FULL_LANES;
-  constexpr int RAYS_PER_BLOCK = 256 / WS_FULL_LANES;
+#ifndef WS_COLLECT_LANES
+#define WS_COLLECT_LANES 32
+#endif
+  constexpr int FULL_LANES = MODE == MARCH_COLLECT ? WS_COLLECT_LANES : WS_FULL_LANES;
+  constexpr int LANES = TAIL ? 4 : FULL_LANES;
+  constexpr int RAYS_PER_BLOCK = 256 / FULL_LANES;
   uint32_t ix;
   int32_t c;
   if (TAIL)
@@ -280,9 +285,9 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   }
   else
   {
-    ix = blockIdx.x * (uint32_t)RAYS_PER_BLOCK + (threadIdx.x / (uint32_t)WS_FULL_LANES);
+    ix = blockIdx.x * (uint32_t)RAYS_PER_BLOCK + (threadIdx.x / (uint32_t)FULL_LANES);
     if (ix >= a.n) return;
-    c = (int32_t)(threadIdx.x % (uint32_t)WS_FULL_LANES);
+    c = (int32_t)(threadIdx.x % (uint32_t)FULL_LANES);
   }
   const RaySetup r = a.rays[ix];
   if (r.steps == 0) return;
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
   if (k0 >= k1) return;
 
   const MarchFrame f = make_march_frame(a.scanner_pos, res, tau, a.map);
-  march_steps(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+  march_steps<MODE == MARCH_EMIT_FREE>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
     const int64_t idx = get_index(a.map, vx, vy, vz);
     const uint64_t t = order_key(ix, k, step);
     if (HAS_S0)
@@ -804,7 +809,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ma.arena_cap = m->arena_cap;
   {
     // half of the arena is split evenly between the workgroups, the other half is the shared overflow area
-    const uint32_t blocks = (uint32_t)((n + 256 / WS_FULL_LANES - 1) / (256 / WS_FULL_LANES)); // workgroups of the collect pass
+    const uint32_t blocks = (uint32_t)((n + 256 / WS_COLLECT_LANES - 1) / (256 / WS_COLLECT_LANES)); // workgroups of the collect pass
     ma.arena_slice = (m->arena_cap / 2) / (blocks ? blocks : 1);
   }
   {
@@ -840,6 +845,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   constexpr size_t rays_per_block = 256 / WS_FULL_LANES;
   const dim3 grid_rays((unsigned)((n + rays_per_block - 1) / rays_per_block));
   const dim3 grid_tail((unsigned)((n + 63) / 64));
+  constexpr size_t rays_per_collect_block = 256 / WS_COLLECT_LANES;
+  const dim3 grid_collect((unsigned)((n + rays_per_collect_block - 1) / rays_per_collect_block));
   const dim3 grid_list(LIST_GRID_BLOCKS);
   const bool s0 = !m->new_is_default;
 
@@ -900,9 +907,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   prof_begin(ctx, WS_K_MARCH_COLLECT);
   if (s0)
-    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, true>), grid_rays, block, 0, s, ma);
+    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, true>), grid_collect, block, 0, s, ma);
   else
-    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, false>), grid_rays, block, 0, s, ma);
+    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, false>), grid_collect, block, 0, s, ma);
   prof_end(ctx, WS_K_MARCH_COLLECT);
 
   prof_begin(ctx, WS_K_RESOLVE_LISTS);

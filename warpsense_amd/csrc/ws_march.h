@@ -142,7 +142,7 @@ __device__ __forceinline__ void march_steps_direct(const MarchFrame &f, const Ra
 //   * proj moves by less than one voxel per step, so floor(proj/res) and the remainder are carried too;
 //     trunc(x/res) = floor unless x < 0 with a non-zero remainder;
 //   * fan offsets are small: delta_z*iv and step*res*iv fit 32 bits, /32768 toward zero is a shift.
-// RaySetup.pad != 0 marks rays for which all of this holds without int32 wrap (always, inside the
+// RaySetup.pad bit 0 marks rays for which all of this holds without int32 wrap (always, inside the
 // reference's own no-overflow domain); other rays use march_steps_direct.
 struct AxisWalk
 {
@@ -233,7 +233,9 @@ __device__ __forceinline__ int32_t axis_index_offset(const AxisWalk &w, int32_t 
   return fi + ((w.proj + e < 0 && rem != 0) ? 1 : 0);
 }
 
-template <class Emit>
+// FREE_SPACE: the caller guarantees that every step of [k0, k1) lies more than tau (+ the centre/fan slack) in front
+// of the hit point, so value == tau and the weight is positive without computing them (no squares, no sqrt).
+template <bool FREE_SPACE, class Emit>
 __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
   const int32_t res = f.res, half = f.half, tau = f.tau;
@@ -269,10 +271,14 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
     const int32_t izz = axis_index(wz);
     if (!in_bounds(f.map, ixx, iyy, izz)) continue;
 
-    int32_t value = l2norm_i(axis_centre_delta(wx, px, res, half), axis_centre_delta(wy, py, res, half), axis_centre_delta(wz, pz, res, half));
-    value = value < tau ? value : tau;
-    if (len > r.distance) value = -value;
-    if (value < -f.weight_epsilon && tsdf_weight(value, tau, f.weight_epsilon) == 0) continue;
+    int32_t value = tau;
+    if (!FREE_SPACE)
+    {
+      value = l2norm_i(axis_centre_delta(wx, px, res, half), axis_centre_delta(wy, py, res, half), axis_centre_delta(wz, pz, res, half));
+      value = value < tau ? value : tau;
+      if (len > r.distance) value = -value;
+      if (value < -f.weight_epsilon && tsdf_weight(value, tau, f.weight_epsilon) == 0) continue;
+    }
 
     const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
     if (delta_z != last_dz)
@@ -308,11 +314,11 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
   }
 }
 
-template <class Emit>
+template <bool FREE_SPACE = false, class Emit>
 __device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
   if (r.pad & 1)
-    march_steps_fast(f, r, k0, k1, emit);
+    march_steps_fast<FREE_SPACE>(f, r, k0, k1, emit);
   else
     march_steps_direct(f, r, k0, k1, emit);
 }
