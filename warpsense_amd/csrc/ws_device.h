@@ -51,7 +51,9 @@ __device__ __forceinline__ int64_t get_index(const MapParams &m, int32_t x, int3
   int32_t xi = ring(x - m.pos[0] + m.offset[0] + m.size[0], m.size[0]);
   int32_t yi = ring(y - m.pos[1] + m.offset[1] + m.size[1], m.size[1]);
   int32_t zi = ring(z - m.pos[2] + m.offset[2] + m.size[2], m.size[2]);
-  return ((int64_t)xi * m.size[1] + yi) * (int64_t)m.size[2] + zi;
+  // size[0] * size[1] < 2^31 (checked by ws_map_create): one 32-bit multiply, then v_mad_i64_i32
+  const int32_t row = xi * m.size[1] + yi;
+  return (int64_t)row * (int64_t)m.size[2] + zi;
 }
 
 // DeviceMap::in_bounds — device_map.h:109-114

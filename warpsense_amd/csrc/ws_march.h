@@ -235,6 +235,23 @@ __device__ __forceinline__ int32_t axis_index_offset(const AxisWalk &w, int32_t 
 
 // FREE_SPACE: the caller guarantees that every step of [k0, k1) lies more than tau (+ the centre/fan slack) in front
 // of the hit point, so value == tau and the weight is positive without computing them (no squares, no sqrt).
+// the same for |e| < res (one wrap at most)
+__device__ __forceinline__ int32_t axis_index_offset_small(const AxisWalk &w, int32_t e, int32_t res)
+{
+  int32_t rem = w.rem + e, fi = w.fi;
+  if (rem >= res)
+  {
+    rem -= res;
+    fi += 1;
+  }
+  else if (rem < 0)
+  {
+    rem += res;
+    fi -= 1;
+  }
+  return fi + ((w.proj + e < 0 && rem != 0) ? 1 : 0);
+}
+
 template <bool FREE_SPACE, class Emit>
 __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
@@ -288,6 +305,15 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
       c0x = trunc_shift15(delta_z * r.ivx);
       c0y = trunc_shift15(delta_z * r.ivy);
       c0z = trunc_shift15(delta_z * r.ivz);
+    }
+    if (FREE_SPACE)
+    {
+      // no fan before len_neg (delta_z * 2 < res): one on-ray candidate, offset by less than half a voxel
+      const int32_t vx = axis_index_offset_small(wx, -c0x, res);
+      const int32_t vy = axis_index_offset_small(wy, -c0y, res);
+      const int32_t vz = axis_index_offset_small(wz, -c0z, res);
+      if (in_bounds(f.map, vx, vy, vz)) emit(k, 0, vx, vy, vz, value, true);
+      continue;
     }
     int32_t iter_steps = 1, mid = 0;
     if (delta_z * 2 >= res)
