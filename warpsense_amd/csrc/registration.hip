@@ -20,7 +20,10 @@
 
 namespace ws
 {
-constexpr int REG_BLOCKS = 256;  // one workgroup per CU
+#ifndef WS_REG_BLOCKS
+#define WS_REG_BLOCKS 256
+#endif
+constexpr int REG_BLOCKS = WS_REG_BLOCKS; // one workgroup per CU
 #ifndef WS_REG_THREADS
 #define WS_REG_THREADS 256
 #endif
