@@ -224,6 +224,17 @@ struct DeviceMapMemWrapper
   }
   // what kernels of the reference receive; here an opaque handle RegistrationCuda understands
   DeviceMap *dev() const { return reinterpret_cast<DeviceMap *>(map_); }
+  // additions: dense world-voxel boxes [lo, hi] (inclusive, x major / z fastest) out of / into the
+  // device ring buffer, so a map shift or an export moves only the slabs it needs (reference: whole-map to_host/to_device)
+  void extract_box(const rmagine::Pointi &lo, const rmagine::Pointi &hi, std::vector<TSDFEntry> &out) const
+  {
+    out.resize((size_t)(hi.x - lo.x + 1) * (size_t)(hi.y - lo.y + 1) * (size_t)(hi.z - lo.z + 1));
+    WS_CHECK(ws_map_extract_box(map_, which_, &lo.x, &hi.x, reinterpret_cast<uint32_t *>(out.data())));
+  }
+  void insert_box(const rmagine::Pointi &lo, const rmagine::Pointi &hi, const std::vector<TSDFEntry> &in)
+  {
+    WS_CHECK(ws_map_insert_box(map_, which_, &lo.x, &hi.x, reinterpret_cast<const uint32_t *>(in.data())));
+  }
 
   ws_map *map_ = nullptr;
   int which_ = WS_MAP_AVG;
@@ -268,6 +279,17 @@ public:
     avg_map_.to_host(result);
     new_map_.to_host(latest_map);
   }
+  // addition: scan already resident on the device (e.g. ScanPreprocessor::points_dev())
+  void update_tsdf_dev(const int32_t *xyz_dev, size_t n, const rmagine::Pointi &scanner_pos, const rmagine::Pointi &up)
+  {
+    int rc = ws_tsdf_update_dev(map_, xyz_dev, n, &scanner_pos.x, &up.x);
+    if (rc == WS_ERR_TOO_MANY_POINTS)
+    {
+      fprintf(stderr, "HIP Error: %s:%d - %s\n", __FILE__, __LINE__, ws_last_error());
+      return;
+    }
+    WS_CHECK(rc);
+  }
   DeviceMap *device_map() { return avg_map_.dev(); }
   const DeviceMap *device_map() const { return avg_map_.dev(); }
   const DeviceMapMemWrapper &avg_map() const { return avg_map_; }
@@ -294,6 +316,7 @@ public:
   {
     WS_CHECK(ws_reg_prepare(reg_, points.empty() ? nullptr : &points[0].x, points.size()));
   }
+  void prepare_registration_dev(const int32_t *xyz_dev, size_t n) { WS_CHECK(ws_reg_prepare_dev(reg_, xyz_dev, n)); }
   void perform_registration(const DeviceMap *map_dev, const rmagine::Matrix4x4f *pretransform, rmagine::Matrix6x6l &h,
                             rmagine::Point6l &g, int &e, int &c, int map_resolution)
   {
@@ -319,6 +342,36 @@ public:
 private:
   ws_reg *reg_ = nullptr;
   uint32_t flags_ = WS_REG_ALL_POINTS;
+};
+
+// App::preprocess on the device (src/warpsense/app.cpp:119-148): float metres -> distinct int mm voxel-centre points
+// transformed by the pose, in first-occurrence order; the result stays on the device until the next call.
+class ScanPreprocessor
+{
+public:
+  explicit ScanPreprocessor(size_t max_points = 128 * 1024) { WS_CHECK(ws_scan_create(detail::context(), max_points, &scan_)); }
+  ~ScanPreprocessor() { ws_scan_destroy(scan_); }
+  ScanPreprocessor(const ScanPreprocessor &) = delete;
+  ScanPreprocessor &operator=(const ScanPreprocessor &) = delete;
+
+  size_t preprocess(const float *cloud_xyz, size_t n, size_t stride_floats, const rmagine::Matrix4x4f &pose, int map_resolution)
+  {
+    WS_CHECK(ws_scan_preprocess(scan_, cloud_xyz, n, stride_floats, &pose.data[0][0], map_resolution, &n_out_));
+    return n_out_;
+  }
+  const int32_t *points_dev() const { return ws_scan_points_dev(scan_); }
+  size_t size() const { return n_out_; }
+  std::vector<rmagine::Pointi> download() const
+  {
+    std::vector<rmagine::Pointi> pts(n_out_);
+    size_t n = 0;
+    WS_CHECK(ws_scan_download(scan_, n_out_ ? &pts[0].x : nullptr, n_out_, &n));
+    return pts;
+  }
+
+private:
+  ws_scan *scan_ = nullptr;
+  size_t n_out_ = 0;
 };
 
 inline void pause() { WS_CHECK(ws_sync(detail::context())); }

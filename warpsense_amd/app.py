@@ -46,7 +46,15 @@ class App:
     def update_pose_estimate(self, transform):
         """app.cpp:172-176."""
         T = np.asarray(transform, dtype=np.float32)
-        self.pose_[:3, :3] = T[:3, :3] @ self.pose_[:3, :3]
+        f = np.float32
+        R = np.zeros((3, 3), dtype=np.float32)
+        for i in range(3):  # float32 products summed in index order (same as include/warpsense_hip/app.hpp)
+            for j in range(3):
+                acc = f(0)
+                for k in range(3):
+                    acc = f(acc + f(T[i, k] * self.pose_[k, j]))
+                R[i, j] = acc
+        self.pose_[:3, :3] = R
         self.pose_[:3, 3] += T[:3, 3]
 
     def map_shift(self):
