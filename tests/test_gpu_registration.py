@@ -113,3 +113,22 @@ def test_register_cloud_empty_overlap():
     T = reg.register_cloud(q[:100], np.eye(4, dtype=np.float32))
     assert np.all(np.isfinite(T))
     assert np.allclose(T, np.eye(4))
+
+
+@pytest.mark.parametrize("n", [0, 5, 200_000])
+def test_register_cloud_point_count_extremes(n):
+    """no points at all, fewer points than lanes in one wave, and more than two passes of the resident grid
+    (131 072 lanes x 2 points): same iteration count and pose as the oracle in both loop modes."""
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    rng = np.random.default_rng(7)
+    q = S.transform_points_mm(pts, S.perturbation(25, -18, 6, 1.2))
+    q = q[rng.integers(0, len(q), n)] if n else q[:0]
+    T_cpu, it_cpu, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+    for mode in (W.WS_REG_LOOP_RESIDENT, W.WS_REG_LOOP_LAUNCHES):
+        reg.reg_.set_loop(mode)
+        T = reg.register_cloud(q, np.eye(4, dtype=np.float32))
+        assert reg.last_iterations == it_cpu, (mode, reg.last_iterations, it_cpu)
+        assert np.all(np.isfinite(T))
+        dt, ang = pose_error(T, T_cpu)
+        assert dt < 1e-4 and ang < 1e-4, (mode, dt, ang)
