@@ -218,6 +218,83 @@ int run2(const char *name, uint32_t *bar, uint32_t *flags, int64_t *partials, in
   return 0;
 }
 
+// variant: the workgroups ADD their 32 values into one of NG group accumulators (agent-scope atomic add, no return;
+// the accumulators are never reset: a reader subtracts what it saw two iterations ago), then arrive; readers fetch
+// NG x 32 values instead of 256 x 32.
+template <int NG>
+__global__ __launch_bounds__(THREADS) void bar3_kernel(uint32_t *bar, int64_t *accum /* [2][NG][SLOTS] */, int iters, int64_t *sink)
+{
+  __shared__ int64_t prev[2][SLOTS];
+  __shared__ int64_t part[THREADS / 64][SLOTS];
+  if (threadIdx.x < 2 * SLOTS) prev[threadIdx.x / SLOTS][threadIdx.x % SLOTS] = 0;
+  __syncthreads();
+  int64_t bad = 0;
+  for (int k = 1; k <= iters; ++k)
+  {
+    if (threadIdx.x < 64)
+    {
+      if (threadIdx.x < SLOTS)
+        __hip_atomic_fetch_add(&accum[((size_t)(k & 1) * NG + (blockIdx.x % NG)) * SLOTS + threadIdx.x], (int64_t)(k + threadIdx.x), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(&bar[(blockIdx.x % 16) * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t target = (uint32_t)k * (BLOCKS / 16);
+      int guard = 0;
+      for (;;)
+      {
+        const bool ok = threadIdx.x >= 16 || __hip_atomic_load(&bar[(threadIdx.x % 16) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        if (__all(ok) || ++guard > 100000000) break;
+      }
+    }
+    __syncthreads();
+    // NG x 32 values: lane l of the workgroup reads group (l / 32) + 8 * j, slot l % 32
+    int64_t s = 0;
+    for (int g = threadIdx.x / SLOTS; g < NG; g += THREADS / SLOTS)
+      s += __hip_atomic_load(&accum[((size_t)(k & 1) * NG + g) * SLOTS + (threadIdx.x % SLOTS)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // combine the 8 lanes that hold the same slot: lanes l and l + 32 inside a wave, then across the 4 waves
+    s += __shfl_xor(s, 32, 64);
+    if ((threadIdx.x & 63) < SLOTS) part[threadIdx.x >> 6][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (threadIdx.x < SLOTS)
+    {
+      const int64_t now = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+      const int64_t total = now - prev[k & 1][threadIdx.x];
+      prev[k & 1][threadIdx.x] = now;
+      if (total != (int64_t)BLOCKS * (k + threadIdx.x)) bad += 1;
+    }
+    __syncthreads();
+  }
+  if (bad != 0) atomicAdd((unsigned long long *)&sink[1], (unsigned long long)bad);
+}
+
+template <int NG>
+int run3(const char *name, uint32_t *bar, int64_t *accum, int64_t *sink)
+{
+  const int iters = 2000;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep)
+  {
+    CK(hipMemset(bar, 0, 64 * 256));
+    CK(hipMemset(accum, 0, 2 * 64 * SLOTS * 8));
+    CK(hipMemset(sink, 0, 16));
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(bar3_kernel<NG>, dim3(BLOCKS), dim3(THREADS), 0, 0, bar, accum, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep == 1)
+    {
+      int64_t h[2] = {0, 0};
+      CK(hipMemcpy(h, sink, 16, hipMemcpyDeviceToHost));
+      printf("%-58s %8.3f us per barrier   (wrong totals: %lld)\n", name, ms * 1000.0 / iters, (long long)h[1]);
+    }
+  }
+  return 0;
+}
+
 int main()
 {
   uint32_t *bar, *flags;
@@ -242,5 +319,11 @@ int main()
   if (run2<16>("sc1 partials, 16 counters", bar, flags, partials, sink)) return 1;
   if (run2<64>("sc1 partials, 64 counters", bar, flags, partials, sink)) return 1;
   if (run2<0>("sc1 partials, 256 flags", bar, flags, partials, sink)) return 1;
+  int64_t *accum;
+  CK(hipMalloc((void **)&accum, 2 * 64 * SLOTS * 8));
+  if (run3<8>("atomic adds into 8 group accumulators, 16 counters", bar, accum, sink)) return 1;
+  if (run3<16>("atomic adds into 16 group accumulators, 16 counters", bar, accum, sink)) return 1;
+  if (run3<32>("atomic adds into 32 group accumulators, 16 counters", bar, accum, sink)) return 1;
+  if (run3<64>("atomic adds into 64 group accumulators, 16 counters", bar, accum, sink)) return 1;
   return 0;
 }

@@ -25,9 +25,9 @@ namespace ws
 #endif
 constexpr int REG_BLOCKS = WS_REG_BLOCKS; // one workgroup per CU
 #ifndef WS_REG_THREADS
-#define WS_REG_THREADS 256
+#define WS_REG_THREADS 512
 #endif
-constexpr int REG_THREADS = WS_REG_THREADS; // 4 or 8 waves
+constexpr int REG_THREADS = WS_REG_THREADS; // 8 waves: one point per lane for a 131 072-point scan (4 waves x 2 points: 10.7 vs 10.1 us)
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
@@ -252,6 +252,13 @@ __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
 
 // One Gauss-Newton update (tsdf_registration.cpp:63-92, registration/util.h:5-39), executed by one whole wave;
 // every lane holds the same state and computes the same result.  H(r, c), G(r): the int64 sums.
+#ifdef WS_REG_TIMING_GN
+__device__ long long g_gn_ticks[5];
+#define WS_GN_STAMP(i) const long long gn_t##i = wall_clock64()
+#else
+#define WS_GN_STAMP(i)
+#endif
+
 template <typename HF, typename GF>
 __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int32_t c)
 {
@@ -262,12 +269,14 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
     st.finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
     return;
   }
+  WS_GN_STAMP(0);
   const double w = (double)(st.alpha * (float)c);
   const int lane = threadIdx.x & 63, lr = lane >> 3, lc = lane & 7;
   double a = 0.0;
   if (lr < 6 && lc < 6) a = (double)H(lr, lc) + (lr == lc ? w : 0.0);
   if (lr < 6 && lc == 6) a = (double)G(lr);
   double xi[6];
+  WS_GN_STAMP(1);
   if (solve6_wave(a, xi) != 0)
   {
     st.finished = 1;
@@ -275,6 +284,7 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
+  WS_GN_STAMP(2);
 
   // xi_to_transform
   const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
@@ -311,6 +321,7 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
     const float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
     tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), (float)xi[3 + i]);
   }
+  WS_GN_STAMP(3);
   st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
   float out[16];
 #pragma unroll
@@ -332,6 +343,16 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
   st.prev[1] = st.prev[2];
   st.prev[2] = st.prev[3];
   st.prev[3] = err;
+#ifdef WS_REG_TIMING_GN
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    g_gn_ticks[0] += gn_t1 - gn_t0;
+    g_gn_ticks[1] += gn_t2 - gn_t1;
+    g_gn_ticks[2] += gn_t3 - gn_t2;
+    g_gn_ticks[3] += wall_clock64() - gn_t3;
+    g_gn_ticks[4] += 1;
+  }
+#endif
 }
 
 // the update fed from the 29 reduced terms in LDS (e and c are `int` in the reference, registration.cu:16-21)
@@ -380,8 +401,20 @@ struct Gathered
   bool ok;
 };
 
+// The voxel a point fell into at the previous iteration of the resident loop and the 7 entries read there.  Late in
+// the Gauss-Newton loop the pose moves by a fraction of a millimetre per iteration, almost every point stays in its
+// voxel, and a wave whose 128 points all stayed issues no load at all (the map does not change during the loop).
+struct VoxelCache
+{
+  int32_t bx, by, bz;
+  uint32_t cur, xn, xl, yn, yl, zn, zl;
+  bool filled;
+};
+
 // transform one point and issue its 7 gathers (nothing here waits for memory)
-__device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTransform &t, int32_t px, int32_t py, int32_t pz, bool valid)
+template <bool CACHED = false>
+__device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTransform &t, int32_t px, int32_t py, int32_t pz, bool valid,
+                                                 VoxelCache *cache = nullptr)
 {
   Gathered g;
   // cu_transform_point (cuda/util.h:11-22), int32 wrap like the reference
@@ -394,6 +427,33 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
   g.qz = wsub(qz, t.cz);
   g.ok = valid && in_bounds_buffer(a.map, bx, by, bz, -1); // in_bounds_with_buffer_neg(buf, 1), registration.cu:217
   g.cur = g.xn = g.xl = g.yn = g.yl = g.zn = g.zl = 0;
+  if (CACHED)
+  {
+    if (g.ok)
+    {
+      VoxelCache &c = *cache;
+#ifdef WS_REG_FORCE_CACHE
+      if (!c.filled) // timing experiment: never reload (wrong results)
+#else
+      if (!(c.filled && c.bx == bx && c.by == by && c.bz == bz))
+#endif
+      {
+        c.cur = a.map_data[get_index(a.map, bx, by, bz)];
+        c.xn = a.map_data[get_index(a.map, bx + 1, by, bz)];
+        c.xl = a.map_data[get_index(a.map, bx - 1, by, bz)];
+        c.yn = a.map_data[get_index(a.map, bx, by + 1, bz)];
+        c.yl = a.map_data[get_index(a.map, bx, by - 1, bz)];
+        c.zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
+        c.zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
+        c.bx = bx;
+        c.by = by;
+        c.bz = bz;
+        c.filled = true;
+      }
+      g.cur = c.cur; g.xn = c.xn; g.xl = c.xl; g.yn = c.yn; g.yl = c.yl; g.zn = c.zn; g.zl = c.zl;
+    }
+    return g;
+  }
   if (g.ok)
   {
     // the 6 neighbours are in bounds by the test above
@@ -464,14 +524,21 @@ __device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a)
   return f;
 }
 
-__device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, const Prefetched &f, int64_t (&acc)[REG_SLOTS])
+template <bool CACHED = false>
+__device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, const Prefetched &f, int64_t (&acc)[REG_SLOTS],
+                                                  VoxelCache *cache = nullptr)
 {
   const IntTransform t = make_int_transform(T);
   // the two prefetched points: 14 gathers in flight before the first is consumed
-  const Gathered g0 = gather_point(a, t, f.p[0][0], f.p[0][1], f.p[0][2], f.valid[0]);
-  const Gathered g1 = gather_point(a, t, f.p[1][0], f.p[1][1], f.p[1][2], f.valid[1]);
-  consume_point(g0, acc);
-  consume_point(g1, acc);
+  const Gathered g0 = gather_point<CACHED>(a, t, f.p[0][0], f.p[0][1], f.p[0][2], f.valid[0], CACHED ? &cache[0] : nullptr);
+  if (__ballot(f.valid[1]) != 0ull) // a whole wave without a second point (cloud <= one pass of the grid) skips its arithmetic
+  {
+    const Gathered g1 = gather_point<CACHED>(a, t, f.p[1][0], f.p[1][1], f.p[1][2], f.valid[1], CACHED ? &cache[1] : nullptr);
+    consume_point(g0, acc);
+    consume_point(g1, acc);
+  }
+  else
+    consume_point(g0, acc);
   // clouds larger than two passes of the grid (N > 131 072)
   for (uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x + 2 * REG_STRIDE; idx < a.end; idx += REG_STRIDE)
   {
@@ -681,6 +748,8 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   const Prefetched pref = prefetch_points(a.pts);
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.state[0].core;
+  VoxelCache cache[2];
+  cache[0].filled = cache[1].filled = false;
 #ifdef WS_REG_TIMING
   long long ts[7], tot[6] = {0, 0, 0, 0, 0, 0};
 #define WS_LSTAMP(i) ts[i] = wall_clock64()
@@ -732,7 +801,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     int64_t acc[REG_SLOTS];
 #pragma unroll
     for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-    accumulate_points(a.pts, T, pref, acc);
+    accumulate_points<true>(a.pts, T, pref, acc, cache);
     WS_LSTAMP(4);
     block_reduce32(acc, wave_part, red);
     WS_LSTAMP(5);
@@ -748,6 +817,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
 #endif
   }
+#ifdef WS_REG_TIMING_GN
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("gn_update x%lld, 10ns ticks: build %lld solve6 %lld xi_to_transform %lld pose+err %lld\n", g_gn_ticks[4], g_gn_ticks[0], g_gn_ticks[1],
+           g_gn_ticks[2], g_gn_ticks[3]);
+#endif
 #ifdef WS_REG_TIMING
   if ((blockIdx.x % 37) == 0 && threadIdx.x == 0)
     printf("reg_loop wg %d iterations %u, 10ns ticks per phase: wait %lld sum %lld solve %lld accumulate %lld reduce %lld arrive %lld\n", (int)blockIdx.x, k,
