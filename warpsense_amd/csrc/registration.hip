@@ -140,9 +140,8 @@ __device__ __forceinline__ void reduce_stage(int64_t (&v)[REG_SLOTS], int lane)
   }
 }
 
-// Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
-// trailing barrier).
-__device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS], int64_t *red)
+// wave totals of REG_SLOTS per-lane values -> wave_part[wave][0..31] (valid after the trailing barrier)
+__device__ __forceinline__ void wave_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS])
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   reduce_stage<16, 32>(v, lane);
@@ -154,6 +153,13 @@ __device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t 
   // lane l now holds the wave total of slot (l >> 1)
   if ((lane & 1) == 0) wave_part[wave][lane >> 1] = v[0];
   __syncthreads();
+}
+
+// Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
+// trailing barrier).
+__device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS], int64_t *red)
+{
+  wave_reduce32(v, wave_part);
   if (threadIdx.x < REG_SLOTS)
   {
     int64_t s = 0;
@@ -684,10 +690,16 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
 constexpr int REG_GROUPS = 32;
 static_assert(REG_THREADS % REG_SLOTS == 0 && REG_GROUPS % (REG_THREADS / REG_SLOTS) == 0 && REG_BLOCKS % REG_GROUPS == 0, "group exchange");
 
-__device__ __forceinline__ void group_publish(int64_t *accum /* [REG_GROUPS][REG_SLOTS] of this parity */, const int64_t *red)
+// first wave, after wave_reduce32: workgroup total of every slot straight into the group accumulator
+__device__ __forceinline__ void group_publish(int64_t *accum /* [REG_GROUPS][REG_SLOTS] of this parity */, int64_t (*wave_part)[REG_SLOTS])
 {
   if (threadIdx.x < REG_SLOTS)
-    __hip_atomic_fetch_add(&accum[(size_t)(blockIdx.x % REG_GROUPS) * REG_SLOTS + threadIdx.x], red[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    int64_t s = 0;
+#pragma unroll
+    for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, wave_part[w][threadIdx.x]);
+    __hip_atomic_fetch_add(&accum[(size_t)(blockIdx.x % REG_GROUPS) * REG_SLOTS + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // all lanes: totals of the iteration -> red[0..31] (valid after the trailing barrier); prev: this parity's last reading
@@ -842,11 +854,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
     accumulate_points<true>(a.pts, T, pref, acc, cache);
     WS_LSTAMP(4);
-    block_reduce32(acc, wave_part, red);
+    wave_reduce32(acc, wave_part);
     WS_LSTAMP(5);
     if (threadIdx.x < 64)
     {
-      group_publish(a.partials + (size_t)(k & 1) * REG_SLOTS * REG_GROUPS, red);
+      group_publish(a.partials + (size_t)(k & 1) * REG_SLOTS * REG_GROUPS, wave_part);
       grid_arrive(a.bar);
     }
 #ifdef WS_REG_TIMING
