@@ -160,6 +160,11 @@ int ws_reg_accumulate_dev(ws_reg *reg, const ws_map *map, int32_t map_resolution
 int ws_reg_solve_dev(ws_reg *reg, const int64_t *sums_dev /* 44 */);
 int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out[16]); /* synchronises */
 
+/* Test entry: the 6x6 solve of the Gauss-Newton update alone (LU with partial pivoting in double, one wavefront per
+ * system; stands for Eigen's hf.inverse() * g, tsdf_registration.cpp:69). n systems: A row-major n x 36, b n x 6 ->
+ * x n x 6, status n (0, or -1 for a singular matrix). Host pointers; synchronises. */
+int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status);
+
 /* ------------------------------------------------------------------ scan pre-processing ---- */
 /* App::preprocess — src/warpsense/app.cpp:119-148, on the device: sensor points in float metres
  * (x y z first, `stride_floats` floats per point, e.g. 3, or 4 for PointXYZI) are dropped if x, y and z are all

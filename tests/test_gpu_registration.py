@@ -132,3 +132,45 @@ def test_register_cloud_point_count_extremes(n):
         assert np.all(np.isfinite(T))
         dt, ang = pose_error(T, T_cpu)
         assert dt < 1e-4 and ang < 1e-4, (mode, dt, ang)
+
+
+def test_wave_solver_is_bit_identical_to_the_oracle_lu():
+    """solve6_wave (one matrix element per lane) == wso_solve6 (serial LU, the same operations in the same order), bit
+    for bit: normal equations as the registration produces them, matrices that need every pivot choice, badly scaled
+    and singular ones."""
+    import ctypes as C
+    import warpsense_amd as W
+    from warpsense_amd import _lib
+    rng = np.random.default_rng(17)
+    mats, rhs = [], []
+    for _ in range(400):  # J^T J of integer Jacobians + damping, like gn_update builds it
+        J = np.concatenate([rng.integers(-2_000_000, 2_000_000, size=(50, 3)), rng.integers(-600, 600, size=(50, 3))], axis=1).astype(np.float64)
+        mats.append(J.T @ J + np.eye(6) * float(rng.integers(0, 5000)))
+        rhs.append(J.T @ rng.integers(-1000, 1000, size=50).astype(np.float64))
+    for _ in range(400):  # general matrices: pivoting in every column
+        mats.append(rng.normal(size=(6, 6)) * 10.0 ** rng.integers(-8, 9, size=(6, 1)))
+        rhs.append(rng.normal(size=6))
+    for _ in range(100):  # exact ties in the pivot column and zeros on the diagonal
+        mats.append(rng.integers(-2, 3, size=(6, 6)).astype(np.float64))
+        rhs.append(rng.integers(-3, 4, size=6).astype(np.float64))
+    mats.append(np.zeros((6, 6)))
+    rhs.append(np.ones(6))
+    A = np.ascontiguousarray(np.stack(mats), dtype=np.float64)
+    b = np.ascontiguousarray(np.stack(rhs), dtype=np.float64)
+    n = len(A)
+    x = np.zeros((n, 6), dtype=np.float64)
+    st = np.zeros(n, dtype=np.int32)
+    ctx = W.Context.default()
+    _lib.check(ctx._L.ws_debug_solve6(ctx.handle, A.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), n, x.ctypes.data_as(C.c_void_p),
+                                     st.ctypes.data_as(C.c_void_p)), "ws_debug_solve6")
+    L = O.lib()
+    singular = 0
+    for i in range(n):
+        xo = np.zeros(6, dtype=np.float64)
+        rc = L.wso_solve6(A[i].ctypes.data_as(C.c_void_p), b[i].ctypes.data_as(C.c_void_p), xo.ctypes.data_as(C.c_void_p))
+        assert rc == st[i], i
+        if rc != 0:
+            singular += 1
+            continue
+        assert np.array_equal(x[i].view(np.uint64), xo.view(np.uint64)), (i, x[i], xo)
+    assert 1 <= singular < 60

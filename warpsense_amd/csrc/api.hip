@@ -679,6 +679,34 @@ int ws_reg_set_loop(ws_reg *r, int mode)
   return WS_OK;
 }
 
+int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status)
+{
+  if (!ctx || !A || !b || !x || !status) return invalid("ws_debug_solve6: NULL argument");
+  double *dA = nullptr, *db = nullptr, *dx = nullptr;
+  int32_t *ds = nullptr;
+  hipError_t e = hipMalloc((void **)&dA, (n ? n : 1) * 36 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&db, (n ? n : 1) * 6 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&dx, (n ? n : 1) * 6 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&ds, (n ? n : 1) * sizeof(int32_t));
+  int rc = WS_OK;
+  if (e == hipSuccess && n)
+  {
+    hipStream_t s = ctx->stream;
+    e = hipMemcpyAsync(dA, A, n * 36 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(db, b, n * 6 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = launch_solve6_test(ctx, dA, db, n, dx, ds);
+    if (e == hipSuccess && rc == WS_OK) e = hipMemcpyAsync(x, dx, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == WS_OK) e = hipMemcpyAsync(status, ds, n * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  if (dA) (void)hipFree(dA);
+  if (db) (void)hipFree(db);
+  if (dx) (void)hipFree(dx);
+  if (ds) (void)hipFree(ds);
+  if (e != hipSuccess) return hip_fail(e, "ws_debug_solve6", __FILE__, __LINE__);
+  return rc;
+}
+
 // ------------------------------------------------------------------ scan pre-processing
 int ws_scan_destroy(ws_scan *sc)
 {

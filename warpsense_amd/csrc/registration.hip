@@ -949,6 +949,31 @@ __global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int
   }
 }
 
+// test entry: the wave solver alone, one wave per system (A row-major 6x6, b) -> x, status
+__global__ __launch_bounds__(64) void solve6_test_kernel(const double *A, const double *b, double *x, int32_t *status)
+{
+  const int lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+  const double *Ai = A + (size_t)blockIdx.x * 36, *bi = b + (size_t)blockIdx.x * 6;
+  double a = 0.0;
+  if (r < 6 && c < 6) a = Ai[r * 6 + c];
+  if (r < 6 && c == 6) a = bi[r];
+  double xi[6] = {0, 0, 0, 0, 0, 0};
+  const int rc = solve6_wave(a, xi);
+  if (lane == 0)
+  {
+    status[blockIdx.x] = rc;
+    for (int k = 0; k < 6; ++k) x[(size_t)blockIdx.x * 6 + k] = xi[k];
+  }
+}
+
+int launch_solve6_test(ws_context *ctx, const double *A_dev, const double *b_dev, size_t n, double *x_dev, int32_t *status_dev)
+{
+  if (n == 0) return WS_OK;
+  hipLaunchKernelGGL(solve6_test_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, A_dev, b_dev, x_dev, status_dev);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
 static PointArgs make_point_args(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count)
 {
   size_t end = first + count;

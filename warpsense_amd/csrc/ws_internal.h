@@ -202,5 +202,6 @@ int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t s
 size_t pre_table_slots(size_t max_points);
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags);
 int reg_loop_supported(int device);
+int launch_solve6_test(ws_context *ctx, const double *A_dev, const double *b_dev, size_t n, double *x_dev, int32_t *status_dev);
 size_t reg_barrier_bytes();
 } // namespace ws
