@@ -4,18 +4,21 @@
 // (src/warpsense/cuda/registration.cu:14-257,310-368) and moves the Gauss-Newton update of
 // cuda::TSDFRegistration::register_cloud (src/warpsense/tsdf_registration.cpp:55-92) onto the device.
 //
-// One launch of reg_iter_kernel is one Gauss-Newton iteration:
-//   phase A  (k > 0) every workgroup sums the 256 x 29 int64 partials the previous launch left in HBM
-//            (exact integer sums -> order independent, bit-identical to the reference's tree), one lane
-//            runs the 6x6 solve, xi -> SE(3) and the convergence test exactly like the reference's host
-//            code (double LU, float pose).  Doing this redundantly per workgroup costs nothing extra
-//            (they all wait for the same ~60 KB from L2) and saves a kernel boundary and a launch.
+// One Gauss-Newton iteration, in every workgroup (256 x 512 lanes):
+//   phase A  (k > 0) total of the previous iteration's partial sums (exact integer sums -> order independent,
+//            bit-identical to the reference's tree); the first wave runs the 6x6 solve (lane-parallel LU in
+//            double), xi -> SE(3) and the convergence test exactly like the reference's host code.  Doing this
+//            redundantly per workgroup costs nothing extra and saves a broadcast.
 //   phase B  fixed-point transform, voxel + 6-neighbour gather, gradient, Jacobian, per-lane accumulation
 //            of the 21 unique terms of J J^T, the 6 of J v, |v| and the count in int64 registers
-//            (v_mad_i64_i32), a transposing wave64 reduction (32 values in 32 shuffles instead of 32 x 6),
-//            LDS across the 4 waves, one 29-word partial per workgroup.
+//            (v_mad_i64_i32), a transposing wave64 reduction (32 values in 32 exchanges instead of 32 x 6),
+//            LDS across the waves, one 29-word partial per workgroup.
 // No Jacobian / value / mask arrays ever reach HBM (the reference writes and re-reads 51 B per point).
-// State and partials are double buffered by launch parity, so no fences or atomics are needed.
+//
+// reg_loop_kernel (default) runs ALL iterations in one launch: resident workgroups, a grid barrier between the
+// iterations, partial sums exchanged through wrapping group accumulators, a per-lane voxel cache.
+// reg_iter_kernel is one launch per iteration (state and 256 x 32 partials double buffered by launch parity, so no
+// fences or atomics are needed); it is the fallback when the grid cannot be resident, and the A/B reference.
 #include "ws_device.h"
 
 namespace ws
@@ -32,38 +35,6 @@ constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
 static_assert(REG_BLOCKS % (REG_THREADS / 64 * 2) == 0, "sum_partials: every wave sums an equal share of the workgroups, 2 lanes per slot");
-
-// exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
-struct FastDiv
-{
-  uint64_t M;
-  int32_t k;
-  int32_t d;
-};
-
-__host__ FastDiv make_fastdiv(int32_t d)
-{
-  FastDiv f;
-  f.d = d;
-  int l = 0;
-  while ((1ll << l) < d) ++l;
-  f.k = 31 + l;
-  f.M = (uint64_t)(((unsigned __int128)1 << f.k) / (unsigned)d) + 1; // ceil for non powers of two; exact enough for powers of two too
-  if (((unsigned __int128)1 << f.k) % (unsigned)d == 0) f.M -= 1;
-  return f;
-}
-
-// C-style truncating division of any int32 by the prepared positive divisor
-__device__ __forceinline__ int32_t div_trunc(int32_t x, const FastDiv &f)
-{
-  const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
-  uint32_t q;
-  if (ax == 0x80000000u)
-    q = ax / (uint32_t)f.d; // |INT_MIN| is outside the multiply-shift range
-  else
-    q = (uint32_t)(((uint64_t)ax * f.M) >> f.k); // ax < 2^31, M <= 2^32: no overflow
-  return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
-}
 
 __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask)
 {
@@ -738,11 +709,11 @@ struct LoopArgs
 // Grid barrier, measured with tools/barrier_bench.hip on MI355X (256 workgroups, 8 XCDs):
 //   * agent-scope release/acquire FENCES walk the XCD's L2 (buffer_wbl2 / buffer_inv): 16 us per barrier;
 //   * without them a barrier is 3.7 us, of which 2.6 us is 256 atomics queueing on one address.
-// So the data the workgroups exchange (the partials) is written and read with agent-scope atomic stores / loads
-// (write-through / L2-coherent `sc1` accesses, 8 bytes each, single-copy atomic), the arrival is ordered after
-// them by waiting for their completion (s_waitcnt vmcnt(0): gfx9 counts stores in vmcnt), and arrivals are
-// spread over 16 counters in different memory channels: 3.1 us per barrier INCLUDING every workgroup's read of
-// all 256 x 32 partials.  Nothing else is communicated inside the launch (the map is read-only here).
+// So the data the workgroups exchange (group_publish / group_collect above) moves with agent-scope atomic adds and
+// loads (`sc1`: performed at the coherent level, 8 bytes each), the arrival is ordered after them by waiting for
+// their completion (s_waitcnt vmcnt(0): gfx9 counts stores and atomics in vmcnt), and arrivals are spread over 16
+// counters in different memory channels: 3.1 us per barrier INCLUDING the exchange.  Nothing else is communicated
+// inside the launch (the map is read-only here).
 constexpr int REG_BAR_COUNTERS = 16;
 constexpr int REG_BAR_STRIDE = 64; // uint32 words between counters (256 B)
 constexpr int REG_BAR_ABORT = REG_BAR_COUNTERS * REG_BAR_STRIDE;

@@ -19,37 +19,6 @@ struct RaySetup // 48 bytes
 };
 static_assert(sizeof(RaySetup) == 48, "ws_map::rays is sized for 48-byte records");
 
-// exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
-// (error e = M*d - 2^k < d <= 2^(k-31), so x*e < 2^k for every x < 2^31)
-struct FastDiv
-{
-  uint64_t M;
-  int32_t k;
-  int32_t d;
-};
-__host__ __device__ inline FastDiv make_fastdiv(int32_t d)
-{
-  FastDiv f;
-  f.d = d;
-  int l = 0;
-  while ((1ll << l) < d) ++l;
-  f.k = 31 + l;
-  const uint64_t p = 1ull << f.k; // k <= 62
-  f.M = p / (uint64_t)d + ((p % (uint64_t)d) ? 1 : 0);
-  return f;
-}
-// C-style truncating division of any int32 by the prepared positive divisor
-__device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, int32_t d)
-{
-  const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
-  uint32_t q;
-  if (ax == 0x80000000u)
-    q = ax / (uint32_t)d; // |INT_MIN| is outside the multiply-shift range
-  else
-    q = (uint32_t)(((uint64_t)ax * M) >> k); // ax < 2^31, M <= 2^32
-  return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
-}
-
 // scan-wide constants of the march
 struct MarchFrame
 {
