@@ -12,6 +12,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t x)
   return x;
 }
 
+// PATTERN 6/7: a lane stays on one random line for 4/8 successive operations (temporal, not spatial, locality).
 // PATTERN 0: every lane a random word; 1: a wave hits 64 consecutive words at a random place; 2: a wave hits 8 runs of
 // 8 consecutive words; 3: like 1 but 32-bit words; 4: like 1 with plain stores instead of atomics; 5: like 0, 32-bit
 template <int PATTERN>
@@ -23,7 +24,9 @@ __global__ __launch_bounds__(256) void k(uint64_t *a, uint32_t *a32, uint64_t n_
   {
     const uint64_t r = mix(wave * 1000003ull + i);
     uint64_t idx;
-    if (PATTERN == 0 || PATTERN == 5) idx = mix(r + lane * 7919ull) % n_words;
+    if (PATTERN == 6) idx = ((mix(mix(wave * 1000003ull + (i >> 2)) + lane * 7919ull) % (n_words / 16)) * 16) + (mix(r) & 15); // 4 successive ops of a lane on one line
+    else if (PATTERN == 7) idx = ((mix(mix(wave * 1000003ull + (i >> 3)) + lane * 7919ull) % (n_words / 16)) * 16) + (mix(r) & 15); // 8 successive
+    else if (PATTERN == 0 || PATTERN == 5) idx = mix(r + lane * 7919ull) % n_words;
     else if (PATTERN == 2) idx = (mix(r + (lane >> 3)) % (n_words - 8)) + (lane & 7);
     else idx = (r % (n_words - 64)) + lane;
     const uint64_t key = r + lane;
@@ -65,5 +68,7 @@ int main()
   if (run<5>("32-bit atomicMin, every lane a random word", a, n_words)) return 1;
   if (run<3>("32-bit atomicMin, 64 consecutive words per wave", a, n_words)) return 1;
   if (run<4>("64-bit plain store, 64 consecutive words per wave", a, n_words)) return 1;
+  if (run<6>("64-bit atomicMin, random line per lane, 4 successive ops on it", a, n_words)) return 1;
+  if (run<7>("64-bit atomicMin, random line per lane, 8 successive ops on it", a, n_words)) return 1;
   return 0;
 }
