@@ -96,6 +96,12 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise WsError(f"{LIB_PATH} is missing: build it with `python -m warpsense_amd.build` "
                       "(there is no CPU fallback for the hot path)")
+    # PyTorch-ROCm ships its own libamdhip64; two HIP runtimes in one process do not share the device (whichever
+    # initialises second reports "no ROCm-capable device").  Load torch's first, so that this library binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, sz, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t, C.c_int64
     P = C.POINTER
