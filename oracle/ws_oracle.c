@@ -194,6 +194,19 @@ int wso_ray_setup(const int32_t point[3], const int32_t pos[3], const int32_t up
   return 0;
 }
 
+/* debugging aid for the tests: record every candidate written to one watched voxel of the next wso_update_min call */
+static int64_t g_watch_idx = -1;
+static int32_t *g_watch_out = 0;
+static size_t g_watch_cap = 0, g_watch_n = 0;
+void wso_debug_watch(int64_t idx, int32_t *out /* rows of 6: point, len, step, value, weight, accepted */, size_t cap)
+{
+  g_watch_idx = idx;
+  g_watch_out = out;
+  g_watch_cap = cap;
+  g_watch_n = 0;
+}
+size_t wso_debug_watch_count(void) { return g_watch_n; }
+
 /* ---------- cu_min_tsdf_krnl, update_tsdf.cu:45-128, one "thread" after the other ---------- */
 void wso_update_min(wso_map *new_map, const int32_t *xyz, size_t n, const int32_t scanner_pos[3],
                     const int32_t up[3], int32_t tau, int32_t res, wso_update_stats *stats)
@@ -259,7 +272,14 @@ void wso_update_min(wso_map *new_map, const int32_t *xyz, size_t n, const int32_
         int16_t w = w16;
         if (step != mid) w = (int16_t)(w * -1);
         st.write_calls++;
-        st.accepted += wso_tsdf_min(new_map->data + wso_get_index(new_map, idx[0], idx[1], idx[2]), wso_pack(v16, w));
+        const int64_t lin = wso_get_index(new_map, idx[0], idx[1], idx[2]);
+        const int acc = wso_tsdf_min(new_map->data + lin, wso_pack(v16, w));
+        st.accepted += acc;
+        if (lin == g_watch_idx && g_watch_out && g_watch_n < g_watch_cap)
+        {
+          int32_t *o = g_watch_out + 6 * g_watch_n++;
+          o[0] = (int32_t)ix; o[1] = len; o[2] = step; o[3] = v16; o[4] = w; o[5] = acc;
+        }
       }
     }
   }

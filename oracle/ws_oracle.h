@@ -118,6 +118,10 @@ int wso_register_cloud(const wso_map *map, const int32_t *xyz, size_t n, const f
                        int32_t max_iterations, float it_weight_gradient, float epsilon, int32_t res,
                        uint32_t flags, float T_out[16], int64_t *trace, int32_t trace_cap);
 
+/* test aid: record the candidates of one voxel during the next wso_update_min (rows: point, len, step, value, weight, accepted) */
+void wso_debug_watch(int64_t idx, int32_t *out, size_t cap);
+size_t wso_debug_watch_count(void);
+
 /* ---- scan pre-processing (App::preprocess, src/warpsense/app.cpp:119-148) ----
  * xyz: n points in float metres, `stride` floats apart; pose: 4x4 column-major, translation in mm.
  * out: at most n points (int32 mm), each distinct transformed voxel centre once, in the order of its first

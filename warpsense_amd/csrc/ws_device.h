@@ -48,17 +48,19 @@ __device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, i
 }
 __device__ __forceinline__ int32_t div_trunc(int32_t x, const FastDiv &f) { return div_trunc(x, f.M, f.k, f.d); }
 
-// Vector3<int>::l2norm — include/warpsense/math/vector3.h:318-330: int(sqrtf(float(int sum)))
+// Vector3<int>::l2norm — include/warpsense/math/vector3.h:318-330: int(sqrtf(float(int sum))).
+// sqrtf, NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the latter is the 1-ulp hardware approximation, and the
+// truncation turns one ulp into a different integer (sqrt(19838114) -> 4453 instead of 4454: one ray in 65 536).
 __device__ __forceinline__ int32_t l2norm_i(int32_t x, int32_t y, int32_t z)
 {
   int32_t sq = wadd(wadd(wmul(x, x), wmul(y, y)), wmul(z, z));
-  return (int32_t)__fsqrt_rn((float)sq);
+  return (int32_t)sqrtf((float)sq);
 }
 // Vector3<long>::l2norm — same header, T = long
 __device__ __forceinline__ int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
 {
   int64_t sq = wadd64(wadd64(wmul64(x, x), wmul64(y, y)), wmul64(z, z));
-  return (int64_t)__fsqrt_rn((float)sq);
+  return (int64_t)sqrtf((float)sq);
 }
 
 // TSDFEntry — include/map/tsdf.h:16-23
