@@ -126,6 +126,15 @@ def test_nondefault_new_map_first_update():
     t.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
     assert np.array_equal(download(t, lm, 0), oa.data)
     assert np.all(download(t, lm, 1) == O.pack(tau, 0))
+    # and the registration of the benchmark against that map: same number of Gauss-Newton iterations, same pose
+    import warpsense_amd as W
+    pert = S.transform_points_mm(S.os1_128_scan(), S.perturbation())
+    reg = W.RegistrationCuda(None)
+    reg.prepare_registration(torch.from_numpy(pert).cuda())
+    T, it = reg.register_cloud(t.device_map(), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, res)
+    To, ito, _ = O.register_cloud(oa, pert, np.eye(4), 200, 0.1, 0.03, res)
+    assert it == ito and it > 50
+    assert np.linalg.norm(T[:3, 3] - To[:3, 3]) / 1000.0 < 1e-4 and np.abs(T[:3, :3] - To[:3, :3]).max() < 1e-4
 
 
 def test_too_many_points_is_a_noop(capsys):
@@ -201,3 +210,12 @@ def test_full_size_scan_matches_oracle():
         assert stats["error_flags"] == 0 and stats["contested_voxels"] > 100_000
     assert np.array_equal(download(t, lm, 0), oa.data)
     assert np.all(download(t, lm, 1) == O.pack(tau, 0))
+    # and the registration of the benchmark against that map: same number of Gauss-Newton iterations, same pose
+    import warpsense_amd as W
+    pert = S.transform_points_mm(S.os1_128_scan(), S.perturbation())
+    reg = W.RegistrationCuda(None)
+    reg.prepare_registration(torch.from_numpy(pert).cuda())
+    T, it = reg.register_cloud(t.device_map(), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, res)
+    To, ito, _ = O.register_cloud(oa, pert, np.eye(4), 200, 0.1, 0.03, res)
+    assert it == ito and it > 50
+    assert np.linalg.norm(T[:3, 3] - To[:3, 3]) / 1000.0 < 1e-4 and np.abs(T[:3, :3] - To[:3, :3]).max() < 1e-4
