@@ -208,6 +208,10 @@ def test_full_size_scan_matches_oracle():
     pert = S.transform_points_mm(S.os1_128_scan(), S.perturbation())
     reg = W.RegistrationCuda(None)
     reg.prepare_registration(torch.from_numpy(pert).cuda())
+    for Tk in (np.eye(4, dtype=np.float32), S.perturbation(-60, 45, 12, -3.0)):
+        h, g, e, c = reg.perform_registration(t.device_map(), Tk, res)
+        ho, go, eo, co = O.reg_iterate(oa, Tk, pert, res, 0)
+        assert (e, c) == (eo, co) and c > 50_000 and np.array_equal(g, go) and np.array_equal(h, ho)
     T, it = reg.register_cloud(t.device_map(), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, res)
     To, ito, _ = O.register_cloud(oa, pert, np.eye(4), 200, 0.1, 0.03, res)
     assert it == ito and it > 50
