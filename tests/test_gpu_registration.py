@@ -174,3 +174,17 @@ def test_wave_solver_is_bit_identical_to_the_oracle_lu():
             continue
         assert np.array_equal(x[i].view(np.uint64), xo.view(np.uint64)), (i, x[i], xo)
     assert 1 <= singular < 60
+
+
+def test_sharded_driver_on_one_rank_equals_the_resident_loop():
+    """warpsense_amd.dist.sharded_register_cloud (accumulate -> [all-reduce] -> solve per iteration, the multi-GPU
+    driver) on a single rank without a process group: identical pose and iteration count as ws_register_cloud."""
+    import warpsense_amd as W
+    from warpsense_amd.dist import HipGnBackend, sharded_register_cloud
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    q = S.transform_points_mm(pts, S.perturbation(30, -22, 7, 1.4))
+    reg.reg_.prepare_registration(q)
+    T1, it1 = reg.reg_.register_cloud(reg.tsdf().device_map(), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, res)
+    backend = HipGnBackend(reg.reg_, reg.tsdf(), res)
+    T2, it2 = sharded_register_cloud(backend, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03)
+    assert it1 == it2 and np.array_equal(T1, T2)
