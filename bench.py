@@ -108,6 +108,7 @@ def main():
     force_sharded = os.environ.get("WS_BENCH_FORCE_SHARDED") == "1"  # exercise the multi-rank driver on one rank
     reg.prepare_registration(d_pert)
     its = []
+    graph_cache = {}  # HIP graphs of the sharded Gauss-Newton batches, captured on first use
 
     def step():
         tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
@@ -119,7 +120,7 @@ def main():
         if world == 1 and not force_sharded:
             _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
         else:
-            _, it = sharded_register_cloud(backend, n, eye, *reg_params)
+            _, it = sharded_register_cloud(backend, n, eye, *reg_params, graphs=graph_cache)
         its.append(it)
 
     def fence():

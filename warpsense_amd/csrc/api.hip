@@ -144,8 +144,14 @@ int ws_ctx_destroy(ws_context *ctx)
 int ws_ctx_set_stream(ws_context *ctx, void *hip_stream)
 {
   if (!ctx) return invalid("ws_ctx_set_stream: ctx is NULL");
-  WS_HIP(hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  // work already enqueued on the old stream finishes before anything goes to the new one -- unless one of them is
+  // being captured into a graph (a synchronisation would invalidate the capture; the graph orders its own nodes)
+  hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(ctx->stream, &a);
+  (void)hipStreamIsCapturing(next, &b);
+  if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) WS_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = next;
   return WS_OK;
 }
 

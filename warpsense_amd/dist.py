@@ -54,23 +54,83 @@ class HipGnBackend:
         return bool(fin.value), int(it.value), out.reshape(4, 4).T.copy()
 
 
-def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it_weight_gradient: float, epsilon: float,
-                           group=None, batch: int = 16):
-    """cuda::TSDFRegistration::register_cloud (tsdf_registration.cpp:28-96) with the points sharded over the
-    ranks of `group`.  Returns (total_transform 4x4, iterations).  Every rank returns the same values."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    first, count = shard_range(n_points, rank, world)
-    backend.begin(T_in, max_iterations, it_weight_gradient, epsilon)
-    done, finished, iterations, T = 0, False, 0, np.asarray(T_in, dtype=np.float32)
-    while not finished and done < max_iterations:
-        todo = min(batch, max_iterations - done)
-        for _ in range(todo):
+class _GraphBatch:
+    """`batch` iterations of [accumulate -> all-reduce -> solve] captured once as a HIP graph and replayed: the host
+    launches one graph per batch instead of four operations per iteration (kernels that find the loop finished return
+    at once, so replaying past convergence is harmless).  Falls back to eager launches if capture is not possible."""
+
+    def __init__(self, backend, first, count, group, batch):
+        import torch
+        import torch.distributed as dist
+        self.graph = None
+        self.batch = batch
+        self._run = lambda: self._eager(backend, first, count, group, batch)
+        if not hasattr(backend, "reg"):
+            return  # CPU test backend
+        ctx = backend.reg.ctx
+        home = torch.cuda.current_stream().cuda_stream
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # one eager batch on the side stream (RCCL must be warm before a capture)
+                ctx.set_stream(side.cuda_stream)
+                self._eager(backend, first, count, group, 1)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                self._eager(backend, first, count, group, batch)
+            ctx.set_stream(home)
+            self.graph = g
+            self._run = g.replay
+        except Exception as exc:  # capture unsupported (old RCCL, a backend that synchronises): stay eager
+            import os
+            import sys
+            if os.environ.get("WS_DIST_DEBUG"):
+                print(f"[warpsense_amd.dist] graph capture failed, staying eager: {exc!r}", file=sys.stderr)
+            ctx.set_stream(home)
+            self.graph = None
+
+    @staticmethod
+    def _eager(backend, first, count, group, n):
+        import torch.distributed as dist
+        for _ in range(n):
             sums = backend.accumulate(first, count)
             if dist.is_initialized():
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
             backend.solve(sums)
-        done += todo
+
+    def run(self):
+        self._run()
+
+
+def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it_weight_gradient: float, epsilon: float,
+                           group=None, batch: int = 16, graphs: dict | None = None):
+    """cuda::TSDFRegistration::register_cloud (tsdf_registration.cpp:28-96) with the points sharded over the
+    ranks of `group`.  Returns (total_transform 4x4, iterations).  Every rank returns the same values.
+
+    `graphs`: a dict the caller keeps between calls; with it the per-batch work is captured once as a HIP graph
+    (keyed by shard and batch size) and replayed."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, count = shard_range(n_points, rank, world)
+    runner = None
+    if graphs is not None:
+        key = (first, count, batch)
+        runner = graphs.get(key)
+        if runner is None:
+            backend.begin(T_in, 1, it_weight_gradient, epsilon)  # a throw-away state for the warm-up / capture launches
+            runner = graphs[key] = _GraphBatch(backend, first, count, group, batch)
+    backend.begin(T_in, max_iterations, it_weight_gradient, epsilon)
+    done, finished, iterations, T = 0, False, 0, np.asarray(T_in, dtype=np.float32)
+    while not finished and done < max_iterations:
+        if runner is not None:
+            runner.run()  # whole batches: iterations beyond max_iterations / convergence are no-ops on the device
+            done += batch
+        else:
+            todo = min(batch, max_iterations - done)
+            _GraphBatch._eager(backend, first, count, group, todo)
+            done += todo
         finished, iterations, T = backend.poll()
     return T, iterations
