@@ -90,6 +90,14 @@ class _GraphBatch:
                 print(f"[warpsense_amd.dist] graph capture failed, staying eager: {exc!r}", file=sys.stderr)
             ctx.set_stream(home)
             self.graph = None
+        # every rank must take the same route (a graph replay and eager launches issue the same collectives, but
+        # agreeing keeps the ranks in lockstep if capture only failed somewhere)
+        if dist.is_initialized():
+            ok = torch.tensor([1 if self.graph is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0 and self.graph is not None:
+                self.graph = None
+                self._run = lambda: self._eager(backend, first, count, group, batch)
 
     @staticmethod
     def _eager(backend, first, count, group, n):
