@@ -216,3 +216,24 @@ def test_full_size_scan_matches_oracle():
     To, ito, _ = O.register_cloud(oa, pert, np.eye(4), 200, 0.1, 0.03, res)
     assert it == ito and it > 50
     assert np.linalg.norm(T[:3, 3] - To[:3, 3]) / 1000.0 < 1e-4 and np.abs(T[:3, :3] - To[:3, :3]).max() < 1e-4
+
+
+def test_full_size_tiles_equals_global():
+    """the experimental LDS-tile scatter on the benchmark scan: same 513^3 map as the default path, voxel for voxel"""
+    torch = _torch()
+    tau, res, mw, size = 1000, 50, 640, (512, 512, 512)
+    pts = torch.from_numpy(S.os1_128_scan()).cuda()
+    out = []
+    for mode in ("global", "tiles"):
+        import warpsense_amd as W
+        view = W.DeviceMap([513, 513, 513], [256, 256, 256], None, (0, 0, 0))
+        t = W.TSDFCuda(view, tau, mw, res)
+        t.set_scatter(W.WS_SCATTER_TILES if mode == "tiles" else W.WS_SCATTER_GLOBAL)
+        t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
+        assert t.stats()["error_flags"] == 0
+        host = W.DeviceMap(view.size_.copy(), view.offset_.copy(), np.empty(513 ** 3, dtype=np.uint32), view.pos_.copy())
+        t.avg_map().to_host(host)
+        out.append(host.data_)
+        t.close()
+    assert np.array_equal(out[0], out[1])
+    assert int((out[0] != O.pack(tau, 0)).sum()) > 10_000_000
