@@ -273,7 +273,9 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
     L[1][0] = (float)lz;  L[1][2] = (float)-lx;
     L[2][0] = (float)-ly; L[2][1] = (float)lx;
   }
-  const float s = (float)sin(theta), omc = (float)(1 - cos(theta));
+  double sin_t, cos_t;
+  sincos(theta, &sin_t, &cos_t); // one argument reduction for both
+  const float s = (float)sin_t, omc = (float)(1 - cos_t);
   float R[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
