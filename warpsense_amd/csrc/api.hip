@@ -504,6 +504,7 @@ int ws_reg_destroy(ws_reg *r)
   if (r->sums_dev) (void)hipFree(r->sums_dev);
   if (r->state_host) (void)hipHostFree(r->state_host);
   if (r->host_flag) (void)hipHostFree(r->host_flag);
+  if (r->result_host) (void)hipHostFree(r->result_host);
   if (r->grid_bar) (void)hipFree(r->grid_bar);
   delete r;
   return WS_OK;
@@ -537,6 +538,8 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->state_host, sizeof(GnState), hipHostMallocDefault);
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->host_flag, 64, hipHostMallocMapped);
   if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->host_flag_dev, r->host_flag, 0);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->result_host, sizeof(GnState), hipHostMallocMapped);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->result_host_dev, r->result_host, 0);
   if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, 2 * sizeof(GnState), ctx->stream);
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->grid_bar, reg_barrier_bytes());
   if (rc == WS_OK && e == hipSuccess) r->loop_supported = reg_loop_supported(ctx->device);
@@ -639,28 +642,37 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
 {
   if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud: NULL argument");
   if (res < 1) return invalid("ws_register_cloud: map_resolution must be positive");
-  int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
-  if (rc != WS_OK) return rc;
-  // The whole loop runs on the device: launch k applies update k (from the partial sums launch k-1 left
-  // behind) and accumulates for iteration k.  The host just enqueues; the device raises a flag in
-  // host-mapped memory on convergence so the host can stop early (launches already enqueued exit at once).
   if (r->loop_mode == WS_REG_LOOP_RESIDENT && r->loop_supported)
   {
-    // one launch: the 256 workgroups stay resident and meet at a grid barrier between iterations
-    rc = launch_reg_loop(r, m, res, flags);
+    // one launch: the 256 workgroups stay resident and meet at a grid barrier between iterations.  The initial state
+    // travels in the kernel arguments and the final state comes back through host-mapped memory, so the host neither
+    // waits for earlier work on the stream before enqueueing nor copies anything afterwards.
+    GnCore init;
+    std::memset(&init, 0, sizeof init);
+    std::memcpy(init.T, T_in, 16 * sizeof(float));
+    for (int k = 0; k < 3; ++k) init.center[k] = (int32_t)T_in[12 + k]; // tsdf_registration.cpp:33
+    init.it_weight_gradient = it_weight_gradient;
+    init.epsilon = epsilon;
+    init.max_iterations = max_iterations;
+    int rc = launch_reg_loop(r, m, res, flags, init);
     if (rc != WS_OK) return rc;
     r->latest = 0;
-    int fin = 0, iters = 0;
-    rc = ws_reg_poll(r, &fin, &iters, T_out);
-    if (rc != WS_OK) return rc;
-    if (r->state_host->core.error)
+    WS_HIP(hipStreamSynchronize(r->ctx->stream));
+    const GnCore *h = &r->result_host->core;
+    if (h->error)
     {
       set_error("ws_register_cloud: grid barrier timed out (another kernel is holding compute units); use WS_REG_LOOP_LAUNCHES");
       return WS_ERR_TIMEOUT;
     }
-    if (iterations) *iterations = iters;
+    std::memcpy(T_out, h->T, 16 * sizeof(float));
+    if (iterations) *iterations = h->iterations;
     return WS_OK;
   }
+  int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
+  if (rc != WS_OK) return rc;
+  // One launch per iteration: launch k applies update k (from the partial sums launch k-1 left behind) and
+  // accumulates for iteration k.  The host just enqueues; the device raises a flag in host-mapped memory on
+  // convergence so the host can stop early (launches already enqueued exit at once).
   const volatile int32_t *flag = r->host_flag;
   int launched = 0;
   for (int k = 0; k <= max_iterations; ++k)

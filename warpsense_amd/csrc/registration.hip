@@ -702,7 +702,9 @@ __device__ __forceinline__ void group_collect(int64_t *accum, int64_t (*wave_par
 struct LoopArgs
 {
   PointArgs pts;
-  GnState *state;    // in: state[0].core, out: state[0]
+  GnCore init;       // the state the loop starts from (by value: no staging copy, no host synchronisation before the launch)
+  GnState *state;    // out: state[0] (device copy for ws_reg_poll)
+  GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
   int64_t *partials; // [2][REG_GROUPS][REG_SLOTS] group accumulators, zeroed before the launch
   uint32_t *bar;     // REG_BAR_COUNTERS monotonic arrival counters + abort flag; zeroed before the launch
   int32_t *host_flag;
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 
   const Prefetched pref = prefetch_points(a.pts);
   GnCore st; // first wave only, identical in all of its lanes
-  if (threadIdx.x < 64) st = a.state[0].core;
+  if (threadIdx.x < 64) st = a.init;
   VoxelCache cache[2];
   cache[0].filled = cache[1].filled = false;
 #ifdef WS_REG_TIMING
@@ -852,12 +854,17 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     a.state[0].core = st;
+    a.result_host->core = st;
     if (k > 0 && !st.error)
     {
       int64_t sums[44];
       expand_sums(red, sums); // the totals the last update was made from
 #pragma unroll
-      for (int i = 0; i < 44; ++i) a.state[0].sums[i] = sums[i];
+      for (int i = 0; i < 44; ++i)
+      {
+        a.state[0].sums[i] = sums[i];
+        a.result_host->sums[i] = sums[i];
+      }
     }
     if (a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1023,17 +1030,21 @@ int reg_loop_supported(int device)
   return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
 }
 
-int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags)
+constexpr size_t REG_ACCUM_OFFSET = (REG_BAR_BYTES + 255) & ~(size_t)255; // group accumulators behind the counters: one memset
+constexpr size_t REG_ACCUM_BYTES = sizeof(int64_t) * 2 * REG_GROUPS * REG_SLOTS;
+
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const GnCore &init)
 {
   ws_context *ctx = r->ctx;
   LoopArgs a;
   a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  a.init = init;
   a.state = r->state;
-  a.partials = r->partials;
+  a.result_host = r->result_host_dev;
+  a.partials = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(r->grid_bar) + REG_ACCUM_OFFSET);
   a.bar = r->grid_bar;
   a.host_flag = r->host_flag_dev;
-  WS_HIP(hipMemsetAsync(r->grid_bar, 0, REG_BAR_BYTES, ctx->stream));
-  WS_HIP(hipMemsetAsync(r->partials, 0, sizeof(int64_t) * 2 * REG_GROUPS * REG_SLOTS, ctx->stream));
+  WS_HIP(hipMemsetAsync(r->grid_bar, 0, REG_ACCUM_OFFSET + REG_ACCUM_BYTES, ctx->stream));
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_loop_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
@@ -1041,7 +1052,7 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags)
   return WS_OK;
 }
 
-size_t reg_barrier_bytes() { return REG_BAR_BYTES; }
+size_t reg_barrier_bytes() { return REG_ACCUM_OFFSET + REG_ACCUM_BYTES; }
 
 size_t reg_partials_bytes() { return sizeof(int64_t) * 2 * REG_SLOTS * REG_BLOCKS; }
 

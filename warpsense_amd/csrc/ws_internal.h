@@ -139,6 +139,8 @@ struct ws_reg
   int64_t *partials = nullptr; // [2][32][REG_BLOCKS]
   ws::GnState *state = nullptr;      // [2] device, double buffered by launch parity
   ws::GnState *state_host = nullptr; // pinned staging
+  ws::GnState *result_host = nullptr;     // pinned + mapped: the resident loop writes its final state here
+  ws::GnState *result_host_dev = nullptr; // device view of result_host
   int32_t *host_flag = nullptr;      // pinned + mapped: the device sets it when the loop has finished
   int32_t *host_flag_dev = nullptr;  // device view of host_flag
   int latest = 0;                    // state buffer holding the newest state
@@ -200,7 +202,7 @@ int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
-int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags);
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init);
 int reg_loop_supported(int device);
 int launch_solve6_test(ws_context *ctx, const double *A_dev, const double *b_dev, size_t n, double *x_dev, int32_t *status_dev);
 size_t reg_barrier_bytes();
