@@ -4,6 +4,12 @@
     python -m warpsense_amd.build --force
 
 The library is written to warpsense_amd/libwarpsense_hip.so (git-ignored, travels with gpurun snapshots).
+
+WS_EXTRA_FLAGS adds compiler flags, e.g. the instrumentation switches of the kernels (they print per-phase clock
+ticks from a few workgroups; never used in the shipped build):
+    -DWS_REG_TIMING / -DWS_REG_TIMING_GN   phases of the resident registration loop / of the Gauss-Newton update
+    -DWS_TILE_TIMING                        phases of the experimental LDS-tile scatter
+    -DWS_REG_BLOCKS=.. -DWS_REG_THREADS=..  grid shape of the registration kernels (default 256 x 512)
 """
 from __future__ import annotations
 

@@ -411,11 +411,7 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
     if (g.ok)
     {
       VoxelCache &c = *cache;
-#ifdef WS_REG_FORCE_CACHE
-      if (!c.filled) // timing experiment: never reload (wrong results)
-#else
       if (!(c.filled && c.bx == bx && c.by == by && c.bz == bz))
-#endif
       {
         c.cur = a.map_data[get_index(a.map, bx, by, bz)];
         c.xn = a.map_data[get_index(a.map, bx + 1, by, bz)];

@@ -181,11 +181,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
           const bool fast = dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
                             (2 * max_delta_z + res) * ivmax < (1ll << 31) &&
                             (len_end + 2 * (int64_t)res) * (len_end + 2 * (int64_t)res) < (1ll << 31);
-#ifdef WS_NO_FAST_WALK
-          r.pad = 0;
-#else
           r.pad = fast ? 1 : 0;
-#endif
         }
       }
     }
