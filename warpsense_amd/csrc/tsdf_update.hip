@@ -480,6 +480,9 @@ __global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int6
 #define DENSE_UNROLL 4
 #endif
 constexpr int LIST_GRID_BLOCKS = 2048; // persistent grid over the touched-tile list: 8192 waves
+#ifndef SPARSE_UNROLL
+#define SPARSE_UNROLL 4
+#endif
 
 // One wave per touched 64-voxel tile (one lane per voxel), waves stride over the tile list.
 __global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
@@ -622,20 +625,42 @@ struct IntegrateArgs
 // cu_avg_tsdf_krnl (update_tsdf.cu:13-43) over the touched tiles only: one wave per tile.
 __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 {
+  // One tile per wave and trip was latency bound (a chain of three dependent loads per 256 B: tile id, new, avg):
+  // every wave works on SPARSE_UNROLL tiles at a time, all their loads are in flight before the first is used.
+  constexpr int U = SPARSE_UNROLL;
   const int lane = threadIdx.x & 63;
   const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t reset = pack_entry(a.tau, 0);
-  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
+  const uint32_t stride = gridDim.x * 4u;
+  for (uint32_t i0 = blockIdx.x * 4u + (threadIdx.x >> 6); i0 < n_dirty; i0 += stride * U)
   {
-    const uint32_t tile = a.dirty_list[i];
-    const int64_t idx = ((int64_t)tile << TILE_SHIFT) + lane;
-    if (idx >= a.n_vox) continue;
-    const uint32_t fresh = a.new_data[idx];
-    if (fresh == reset) continue;
-    const uint32_t existing = a.avg_data[idx];
-    const uint32_t updated = integrate_entry(existing, fresh, a.max_weight);
-    if (updated != existing) a.avg_data[idx] = updated;
-    a.new_data[idx] = reset;
+    int64_t idx[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      const uint32_t i = i0 + (uint32_t)u * stride;
+      ok[u] = i < n_dirty;
+      idx[u] = ok[u] ? (((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane) : 0;
+      ok[u] = ok[u] && idx[u] < a.n_vox;
+    }
+    uint32_t fresh[U], existing[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) fresh[u] = ok[u] ? a.new_data[idx[u]] : reset;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      ok[u] = ok[u] && fresh[u] != reset;
+      existing[u] = ok[u] ? a.avg_data[idx[u]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      if (!ok[u]) continue;
+      const uint32_t updated = integrate_entry(existing[u], fresh[u], a.max_weight);
+      if (updated != existing[u]) a.avg_data[idx[u]] = updated;
+      a.new_data[idx[u]] = reset;
+    }
   }
 }
 
