@@ -566,17 +566,31 @@ __global__ __launch_bounds__(256) void resolve_lists_kernel(ResolveArgs a)
   const int lane = threadIdx.x & 63;
   const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int32_t weight_epsilon = a.tau / 10;
-  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
+  constexpr int U = SPARSE_UNROLL; // tiles whose tags are fetched together (most tiles have no contested voxel)
+  const uint32_t stride = gridDim.x * 4u;
+  for (uint32_t i0 = blockIdx.x * 4u + (threadIdx.x >> 6); i0 < n_dirty; i0 += stride * U)
   {
-    const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
-    if (idx >= a.n_vox) continue;
-    if (a.split)
+    int64_t idxs[U];
+    bool tagged[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
     {
-      if (a.vstate[idx] != VOX_CONTESTED) continue;
-      a.vstate[idx] = 0;
+      const uint32_t i = i0 + (uint32_t)u * stride;
+      const bool ok = i < n_dirty;
+      idxs[u] = ok ? (((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane) : a.n_vox;
     }
-    else if (a.kpos[idx] != KEY_CONTESTED_TAG)
-      continue;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      tagged[u] = false;
+      if (idxs[u] < a.n_vox) tagged[u] = a.split ? (a.vstate[idxs[u]] == VOX_CONTESTED) : (a.kpos[idxs[u]] == KEY_CONTESTED_TAG);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+    if (!tagged[u]) continue;
+    const int64_t idx = idxs[u];
+    if (a.split) a.vstate[idx] = 0;
     const uint32_t head = (uint32_t)(a.kneg[idx] & 0xffffffffull);
     const uint32_t state = HAS_S0 ? a.new_data[idx] : pack_entry(a.tau, 0);
     int32_t sv = entry_value(state), sw = entry_weight(state);
@@ -608,6 +622,7 @@ __global__ __launch_bounds__(256) void resolve_lists_kernel(ResolveArgs a)
     a.new_data[idx] = pack_entry(sv, sw);
     a.kpos[idx] = KEY_INF;
     a.kneg[idx] = KEY_INF;
+    }
   }
 }
 
