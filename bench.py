@@ -157,6 +157,40 @@ def main():
     stats = tsdf.stats()
     ctx.prof_enable(0)
 
+    # dense-equivalent pass: the same steps with the reference-shaped integrate that streams EVERY voxel
+    # (16 B/voxel) -- the kernel the survey holds to the HBM roofline.  Separate from the timed region above.
+    dense_eq = None
+    if world == 1 and args.integrate == "sparse" and not force_sharded:
+        tsdf.set_integrate(W.WS_INTEGRATE_DENSE)
+        step()
+        fence()
+        ctx.prof_reset()
+        ctx.prof_enable(tsdf_mask)
+        n_dense = max(3, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(n_dense):
+            step()
+        fence()
+        dense_elapsed = time.perf_counter() - t1
+        dk = {}
+        for k in tsdf_classes:
+            ms, cnt = ctx.prof_read(k)
+            if cnt:
+                dk[_lib.KERNEL_CLASSES[k]] = 1000.0 * ms / cnt
+        ctx.prof_enable(0)
+        tsdf.set_integrate(W.WS_INTEGRATE_SPARSE)
+        step()  # leave the map in the state of the sparse run
+        fence()
+        n_vox_d = int(np.prod([s if s % 2 else s + 1 for s in size]))
+        b_int = 16 * n_vox_d
+        b_upd = 12 * n + 4 * 35_442_598 + 4 * 13_901_324 + b_int
+        t_upd = sum(dk.values())
+        dense_eq = {"value": n_dense / dense_elapsed, "unit": "scans/s", "integrate_us": dk.get("integrate"),
+                    "integrate_achieved_GBps": b_int / (dk["integrate"] * 1e-6) / 1e9 if dk.get("integrate") else None,
+                    "integrate_frac": b_int / (dk["integrate"] * 1e-6) / 1e9 / HBM_PEAK_GBS if dk.get("integrate") else None,
+                    "update_bytes": b_upd, "update_device_us": t_upd,
+                    "update_frac": b_upd / (t_upd * 1e-6) / 1e9 / HBM_PEAK_GBS if t_upd else None}
+
     # registration iteration timing in a separate pass (events per iteration would perturb the timed region)
     if not args.no_registration and world == 1:
         ctx.prof_reset()
@@ -231,6 +265,8 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    if roofline is not None and dense_eq is not None:
+        roofline["dense_equivalent"] = dense_eq
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(points, perturbed, size, tau, mw, res, reg_params)
     else:
