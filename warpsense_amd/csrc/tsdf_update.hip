@@ -474,10 +474,10 @@ __global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int6
 }
 
 #ifndef DENSE_GRID
-#define DENSE_GRID 2048
+#define DENSE_GRID 3072
 #endif
 #ifndef DENSE_UNROLL
-#define DENSE_UNROLL 4
+#define DENSE_UNROLL 8
 #endif
 constexpr int LIST_GRID_BLOCKS = 2048; // persistent grid over the touched-tile list: 8192 waves
 #ifndef SPARSE_UNROLL
