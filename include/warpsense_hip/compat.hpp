@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "warpsense_hip.h"
@@ -173,6 +174,15 @@ struct DeviceMap
       : size_(size), offset_(offset), data_(data), pos_(pos)
   {
   }
+  // device_map.h:42-48: view of a local map held by a shared_ptr (HDF5LocalMap::Ptr in the reference).  A template so
+  // that this header does not pull in the HDF5 map: any map type with get_size()/get_offset()/get_pos() returning
+  // something with .data() -> int[3] (Eigen::Vector3i there) and get_data() -> TSDFEntry* binds.
+  template <class LocalMapT>
+  DeviceMap(const std::shared_ptr<LocalMapT> &map)
+      : size_(reinterpret_cast<rmagine::Pointi *>(map->get_size().data())), offset_(reinterpret_cast<rmagine::Pointi *>(map->get_offset().data())),
+        data_(map->get_data()), pos_(reinterpret_cast<rmagine::Pointi *>(map->get_pos().data()))
+  {
+  }
   DeviceMap() = default;
   DeviceMap(const DeviceMap &) = delete;
   DeviceMap(DeviceMap &&) = delete;
@@ -195,6 +205,18 @@ struct DeviceMap
     return std::abs(x - pos_->x) <= size_->x / 2 && std::abs(y - pos_->y) <= size_->y / 2 && std::abs(z - pos_->z) <= size_->z / 2;
   }
   bool in_bounds(rmagine::Vector3i p) const { return in_bounds(p.x, p.y, p.z); }
+  // device_map.h:116-128: `buffer` is a size_t there, so both sides of the comparison are unsigned
+  // (a buffer larger than size/2 wraps and accepts everything, exactly like the reference)
+  bool in_bounds_with_buffer_neg(rmagine::Vector3i p, size_t buffer) const
+  {
+    const size_t ax = (size_t)std::abs(p.x - pos_->x), ay = (size_t)std::abs(p.y - pos_->y), az = (size_t)std::abs(p.z - pos_->z);
+    return ax <= ((size_t)(size_->x / 2) - buffer) && ay <= ((size_t)(size_->y / 2) - buffer) && az <= ((size_t)(size_->z / 2) - buffer);
+  }
+  bool in_bounds_with_buffer_pos(rmagine::Vector3i p, size_t buffer) const
+  {
+    const size_t ax = (size_t)std::abs(p.x - pos_->x), ay = (size_t)std::abs(p.y - pos_->y), az = (size_t)std::abs(p.z - pos_->z);
+    return ax <= ((size_t)(size_->x / 2) + buffer) && ay <= ((size_t)(size_->y / 2) + buffer) && az <= ((size_t)(size_->z / 2) + buffer);
+  }
   TSDFEntry &value_unchecked(int x, int y, int z) { return data_[get_index(rmagine::Vector3i(x, y, z))]; }
   const TSDFEntry &value_unchecked(int x, int y, int z) const { return data_[get_index(rmagine::Vector3i(x, y, z))]; }
   TSDFEntry &value_unchecked(const rmagine::Vector3i &p) { return data_[get_index(p)]; }

@@ -237,3 +237,79 @@ def test_full_size_tiles_equals_global():
         t.close()
     assert np.array_equal(out[0], out[1])
     assert int((out[0] != O.pack(tau, 0)).sum()) > 10_000_000
+
+
+def _pair_at(size, tau, res, mw, pos, offset, scatter="global"):
+    """device map + oracle maps for a window centred on `pos` with ring-buffer offset `offset` (as after shifts)."""
+    import warpsense_amd as W
+    size = [s if s % 2 == 1 else s + 1 for s in size]
+    n = int(np.prod(np.asarray(size, dtype=np.int64)))
+    view = W.DeviceMap(size, offset, np.full(n, O.pack(tau, 0), dtype=np.uint32), pos)
+    t = W.TSDFCuda(view, tau, mw, res)
+    t.set_scatter(W.WS_SCATTER_TILES if scatter == "tiles" else W.WS_SCATTER_GLOBAL)
+    oa = O.OracleMap(size, tau, 0, pos=pos, offset=offset)
+    return view, t, oa, oa.copy()
+
+
+def _download_view(t, view, which):
+    import warpsense_amd as W
+    host = W.DeviceMap(view.size_.copy(), view.offset_.copy(), np.empty_like(view.data_), view.pos_.copy())
+    (t.avg_map() if which == 0 else t.new_map()).to_host(host)
+    return host.data_
+
+
+@pytest.mark.parametrize("scatter", SCATTER_MODES)
+@pytest.mark.parametrize("sensor", [(0.0, 0.0, 0.0), (700_000.0, -350_000.0, 9_000.0)])
+def test_long_rays_take_the_wrapping_march(sensor, scatter):
+    """Ranges of 50-80 m: direction * len exceeds int32 and wraps in the reference's `int` arithmetic
+    (update_tsdf.cu:59,69).  Such rays leave the division-free walk (march_steps_fast) for march_steps_direct, which must
+    wrap exactly like the CUDA code / the oracle; the second case puts the sensor 780 m from the map origin."""
+    torch = _torch()
+    tau, res, mw = 1024, 256, 640
+    size = (480, 440, 48)
+    pos = tuple(int(np.floor(np.float32(s) / np.float32(res))) for s in sensor)
+    offset = (17, 401, 3)
+    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset, scatter)
+    # the room of os1_128_scan is centred on the map origin: move scan and room to the sensor
+    pts = S.os1_128_scan(rings=32, azimuths=256, seed=21, half_extents_mm=(58_000.0, 52_000.0, 5_500.0))
+    pts = (pts.astype(np.int64) + np.asarray(sensor, dtype=np.int64)).astype(np.int32)
+    d = np.linalg.norm(pts.astype(np.float64) - np.asarray(sensor), axis=1)
+    assert (d > 50_000).sum() > 1000 and float((np.abs(pts - np.asarray(sensor)).max(axis=1) * (d + tau)).max()) > 2.0 ** 31
+    st = O.update_min(on, pts, pos, (0, 0, 32768), tau, res)
+    assert st.rays_in_bounds > 4000 and st.write_calls > 500_000
+    t.scatter(torch.from_numpy(pts).cuda(), pos, (0, 0, 32768))
+    new = _download_view(t, view, 1)
+    assert t.stats()["error_flags"] == 0
+    mism = np.nonzero(new != on.data)[0]
+    assert mism.size == 0, f"{mism.size} voxels differ, first {mism[:5]}"
+    O.update_avg(on, oa, mw, tau)
+    t.integrate()
+    assert np.array_equal(_download_view(t, view, 0), oa.data)
+
+
+@pytest.mark.parametrize("scatter", SCATTER_MODES)
+def test_room_larger_than_the_window_with_ring_seam(scatter):
+    """Points beyond the window fail in_bounds_with_buffer_pos (update_tsdf.cu:55), accepted rays leave the window on
+    the way (in_bounds per step, :73,:113), and the ring-buffer seam of a shifted window runs through the fans."""
+    torch = _torch()
+    tau, res, mw = 600, 20, 640
+    size = (400, 400, 100)
+    pos = (37, -52, 9)
+    offset = (11, 250, 97)
+    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset, scatter)
+    sensor = (pos[0] * res + 7.0, pos[1] * res + 13.0, pos[2] * res + 4.0)
+    pts = S.os1_128_scan(rings=128, azimuths=512, seed=31, half_extents_mm=(6_000.0, 3_800.0, 1_150.0))
+    pts = (pts.astype(np.int64) + np.asarray(sensor, dtype=np.int64)).astype(np.int32)
+    st = O.update_min(on, pts, pos, (0, 0, 32768), tau, res)
+    assert 10_000 < st.rays_in_bounds < pts.shape[0] - 10_000  # some rays rejected, some kept
+    for k in range(2):
+        t.update_tsdf(torch.from_numpy(pts).cuda(), pos, (0, 0, 32768))
+        if k == 0:
+            O.update_avg(on, oa, mw, tau)
+        else:
+            O.update_tsdf(oa, on, pts, pos, (0, 0, 32768), tau, mw, res)
+        assert t.stats()["error_flags"] == 0
+        got = _download_view(t, view, 0)
+        mism = np.nonzero(got != oa.data)[0]
+        assert mism.size == 0, f"scan {k}: {mism.size} voxels differ, first {mism[:5]}"
+    assert int((W_entry_weight(oa.data) < 0).sum()) > 1000
