@@ -37,26 +37,69 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--map", type=int, default=512, help="map edge in voxels (the reference forces it odd: 513)")
     ap.add_argument("--resolution", type=int, default=50)
-    ap.add_argument("--integrate", choices=["sparse", "dense"], default="sparse")
-    ap.add_argument("--scatter", choices=["tiles", "global"], default="global")
+    ap.add_argument("--integrate", choices=["sparse", "dense", "separate"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-registration", action="store_true", help="time the TSDF update alone (diagnostics)")
     return ap.parse_args()
 
 
 def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
-    """The reference's CPU path (port, oracle/cpu_baseline.cpp) on this box's host cores: one scan."""
+    """The reference's CPU path (port, oracle/cpu_baseline.cpp) on this box's host cores, one scan of the same workload:
+    (i)  update_tsdf with thread_count = 1 (src/cpu/update_tsdf.cpp:397-564, what src/cpu/fastsense.cpp:172 calls),
+    (ii) the OpenMP overload (:566-724) at 8 threads and at all cores,
+    (iii) register_cloud (src/cpu/registration.cpp:14-177) at 8 threads and at all cores.
+    Median of the timed runs after one warm-up each; `value` uses the fastest update variant + the fastest registration."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    ncpu = os.cpu_count() or 1
+
+    def timed(fn, runs, warm=1):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    samples = {}
     m = O.OracleMap(size, tau, 0)
-    t0 = time.perf_counter()
-    threads = O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=0)
-    t1 = time.perf_counter()
-    _, it, _ = O.cpu_register_cloud(m, perturbed, np.eye(4), reg_params[0], reg_params[1], reg_params[2], res, threads=0)
-    t2 = time.perf_counter()
-    return {"value": 1.0 / (t2 - t0), "unit": "scans/s", "cores": int(threads), "kind": "port",
-            "sample": f"1 scan of the same workload: update_tsdf OpenMP overload (src/cpu/update_tsdf.cpp:566-724) "
-                      f"{t1 - t0:.2f} s + register_cloud (src/cpu/registration.cpp:14-177, {it} iterations) {t2 - t1:.2f} s"}
+
+    def upd(threads):
+        m.data[:] = O.pack(tau, 0)
+        return O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=threads)
+
+    variants = [("update_1_thread", 1, 3), ("update_8_threads", min(8, ncpu), 2)]
+    if ncpu > 8:
+        variants.append((f"update_{ncpu}_threads", ncpu, 1))
+    best_upd = None
+    for name, th, runs in variants:
+        med, ts = timed(lambda th=th: upd(th), runs, warm=1 if th == 1 else 0)
+        samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th}
+        if best_upd is None or med < best_upd[0]:
+            best_upd = (med, th, name)
+    upd(best_upd[1])  # the map the registration runs against
+    it_box = []
+
+    def reg(threads):
+        _, it, _ = O.cpu_register_cloud(m, perturbed, np.eye(4), reg_params[0], reg_params[1], reg_params[2], res, threads=threads)
+        it_box.append(it)
+
+    best_reg = None
+    reg_variants = [("register_8_threads", min(8, ncpu), 2)]
+    if ncpu > 8:
+        reg_variants.append((f"register_{ncpu}_threads", ncpu, 2))
+    for name, th, runs in reg_variants:
+        med, ts = timed(lambda th=th: reg(th), runs, warm=0)
+        samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th, "iterations": it_box[-1]}
+        if best_reg is None or med < best_reg[0]:
+            best_reg = (med, th, name)
+    return {"value": 1.0 / (best_upd[0] + best_reg[0]), "unit": "scans/s", "cores": int(max(best_upd[1], best_reg[1])), "kind": "port",
+            "sample": f"1 scan of the same workload ({points.shape[0]} points, {size[0] + 1 - size[0] % 2}^3 map): fastest update variant "
+                      f"{best_upd[2]} {best_upd[0]:.2f} s + fastest registration {best_reg[2]} {best_reg[0]:.2f} s; medians of all variants in `variants`",
+            "variants": samples,
+            "update_1_thread_scans_per_s": 1.0 / (samples["update_1_thread"]["median_s"] + best_reg[0])}
 
 
 def main():
@@ -91,8 +134,7 @@ def main():
     host_map = lm.device_map()
     host_map.data_ = None  # fresh map: let the library fill both device maps with (tau, 0)
     tsdf = W.TSDFCuda(host_map, tau, mw, res, ctx)
-    tsdf.set_integrate(W.WS_INTEGRATE_DENSE if args.integrate == "dense" else W.WS_INTEGRATE_SPARSE)
-    tsdf.set_scatter(W.WS_SCATTER_TILES if args.scatter == "tiles" else W.WS_SCATTER_GLOBAL)
+    tsdf.set_integrate({"dense": W.WS_INTEGRATE_DENSE, "sparse": W.WS_INTEGRATE_SPARSE, "separate": W.WS_INTEGRATE_SPARSE_SEPARATE}[args.integrate])
     reg = W.RegistrationCuda(None, ctx)
     del lm
 
@@ -133,11 +175,11 @@ def main():
         step()
     fence()
     its.clear()
-    tsdf_classes = (_lib.WS_K_MARCH_EMIT, _lib.WS_K_RESOLVE, _lib.WS_K_MARCH_COLLECT, _lib.WS_K_RESOLVE_LISTS, _lib.WS_K_INTEGRATE,
-                    _lib.WS_K_TILE_BIN, _lib.WS_K_TILE_SCATTER)
+    tsdf_classes = (_lib.WS_K_SETUP, _lib.WS_K_MARCH_TAILS, _lib.WS_K_MARCH_FREE, _lib.WS_K_TILE_BIN, _lib.WS_K_TILE_RESOLVE,
+                    _lib.WS_K_INTEGRATE)
     tsdf_mask = sum(1 << k for k in tsdf_classes)
     ctx.prof_reset()
-    ctx.prof_enable(tsdf_mask)  # hipEvents around the 5 TSDF kernels of every step, on the stream they run on
+    ctx.prof_enable(tsdf_mask)  # hipEvents around the TSDF kernel classes of every step, on the stream they run on
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,7 +202,7 @@ def main():
     # dense-equivalent pass: the same steps with the reference-shaped integrate that streams EVERY voxel
     # (16 B/voxel) -- the kernel the survey holds to the HBM roofline.  Separate from the timed region above.
     dense_eq = None
-    if world == 1 and args.integrate == "sparse" and not force_sharded:
+    if world == 1 and args.integrate != "dense" and not force_sharded:
         tsdf.set_integrate(W.WS_INTEGRATE_DENSE)
         step()
         fence()
@@ -178,7 +220,7 @@ def main():
             if cnt:
                 dk[_lib.KERNEL_CLASSES[k]] = 1000.0 * ms / cnt
         ctx.prof_enable(0)
-        tsdf.set_integrate(W.WS_INTEGRATE_SPARSE)
+        tsdf.set_integrate(W.WS_INTEGRATE_SPARSE_SEPARATE if args.integrate == "separate" else W.WS_INTEGRATE_SPARSE)
         step()  # leave the map in the state of the sparse run
         fence()
         n_vox_d = int(np.prod([s if s % 2 else s + 1 for s in size]))
@@ -209,33 +251,43 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant TSDF-update kernel (algorithmic bytes per launch) ----
+    # ---- roofline (algorithmic bytes per launch, SURVEY.md §8d: B_update = 12 N + 4 V + 4 T + 16 x voxels streamed) ----
     n_vox = int(np.prod([s if s % 2 else s + 1 for s in size]))
     V, T = 35_442_598, 13_901_324  # scatter targets / distinct voxels of this scan (reproduced by the oracle)
-    streamed_vox = n_vox if args.integrate == "dense" else int(stats["dirty_tiles"]) * 64
-    alg_bytes = {"march_emit": 12 * n + 4 * V + 4 * T, "tile_scatter": 12 * n + 4 * V + 4 * T, "integrate": 16 * streamed_vox}
+    streamed_vox = n_vox if args.integrate == "dense" else min(n_vox, int(stats["tiles"]) * 1024)
+    b_scatter = 12 * n + 4 * V + 4 * T
+    b_integrate = 16 * streamed_vox
+    scatter_classes = ("ray_setup", "march_tails", "march_free", "tile_bin", "tile_resolve")
     roofline = None
-    cand = [k for k in ("march_emit", "tile_scatter", "integrate") if k in kernels]
-    if cand:
-        dom = max(cand, key=lambda k: kernels[k]["avg_us"])
-        achieved = alg_bytes[dom] / (kernels[dom]["avg_us"] * 1e-6) / 1e9
-        # HBM bytes per launch from the rocprofv3 PMC passes of the same command (profiles/), if recorded
+    if any(k in kernels for k in scatter_classes):
+        t_scatter = sum(kernels[k]["avg_us"] for k in scatter_classes if k in kernels)
+        fused = "integrate" not in kernels  # the default route folds the integrate into the tile resolve
+        tsdf_kernels = [k for k in kernels if k in scatter_classes or k == "integrate"]
+        dom = max(tsdf_kernels, key=lambda k: kernels[k]["avg_us"])
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get(f"{dom}:{args.integrate}:{args.scatter}")
+                traffic = json.load(fh).get(f"{dom}:{args.integrate}")
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes[dom],
-                    "avg_launch_us": kernels[dom]["avg_us"]}
+        if dom == "integrate":
+            grp_bytes, grp_us, grp = b_integrate, kernels["integrate"]["avg_us"], ["integrate"]
+        else:
+            # the scatter's bytes belong to its kernels TOGETHER (set-up, both marches, binning, tile resolve)
+            grp_bytes, grp_us, grp = b_scatter + (b_integrate if fused else 0), t_scatter, [k for k in scatter_classes if k in kernels]
+        achieved = grp_bytes / (grp_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "kernel_group": grp, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": grp_bytes,
+                    "avg_launch_us": grp_us, "dominant_kernel_us": kernels[dom]["avg_us"],
+                    "note": "VALU-bound ray march (DESIGN.md §5); bytes = SURVEY §8d's scatter term" + (" + fused integrate" if fused else "")}
         if "integrate" in kernels and dom != "integrate":
-            # the HBM-stream kernel of the update (SURVEY.md §8d holds THIS one to the bandwidth roofline)
-            ia = alg_bytes["integrate"] / (kernels["integrate"]["avg_us"] * 1e-6) / 1e9
-            roofline["integrate"] = {"achieved": ia, "frac": ia / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes["integrate"],
-                                     "avg_launch_us": kernels["integrate"]["avg_us"]}
-        t_update_us = sum(kernels[k]["avg_us"] for k in kernels if k not in ("reg_iteration", "reg_loop"))
-        b_update = 12 * n + 4 * V + 4 * T + 16 * streamed_vox
+            ia = b_integrate / (kernels["integrate"]["avg_us"] * 1e-6) / 1e9
+            roofline["integrate"] = {"achieved": ia, "frac": ia / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_integrate,
+                                     "avg_launch_us": kernels["integrate"]["avg_us"],
+                                     "basis": "algorithmic (16 B x voxels of the touched tiles; untouched voxels of a tile are read, not written)"
+                                     if args.integrate != "dense" else "algorithmic == moved (PMC)"}
+        t_update_us = sum(kernels[k]["avg_us"] for k in tsdf_kernels)
+        b_update = b_scatter + b_integrate
         roofline["update_total"] = {"bytes": b_update, "device_us": t_update_us,
                                     "achieved": b_update / (t_update_us * 1e-6) / 1e9,
                                     "frac": b_update / (t_update_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
@@ -261,7 +313,8 @@ def main():
                     "iterations_per_scan": float(np.mean(its)) if its else None},
                    "parallelism": "single GPU" if world == 1 else f"map replicated, registration points sharded x{world}, "
                                                                    "RCCL all-reduce of 44 int64 per iteration",
-                   "contested_voxels": stats["contested_voxels"], "tiles_streamed": stats["dirty_tiles"]},
+                   "contested_voxels": stats["contested_voxels"], "tiles_streamed": stats["tiles"], "tail_records": stats["records"],
+                   "record_runs": stats["runs"]},
         "roofline": roofline,
         "kernels": kernels,
     }

@@ -43,17 +43,25 @@ typedef enum
   WS_ERR_INVALID = -1,     /* bad argument                                             */
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
-  WS_ERR_CAPACITY = -4,    /* contested-voxel arena exhausted (see ws_tsdf_stats)       */
-  WS_ERR_RANGE = -5,       /* ray too long for the order key            */
-  WS_ERR_TIMEOUT = -6      /* the resident registration loop could not get the whole GPU */
+  WS_ERR_CAPACITY = -4,    /* candidate-record buffers exhausted: a TSDF update is not exact (sticky, see below) */
+  WS_ERR_RANGE = -5,       /* ray too long for the order key; the ray was dropped (sticky)       */
+  WS_ERR_TIMEOUT = -6,     /* the resident registration loop could not get the whole GPU */
+  WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
 } ws_status;
+
+/* Sticky device-side errors.  ws_tsdf_update* only ENQUEUE work (like the reference, update_tsdf.cu:165), so a
+ * problem found by the kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact) cannot come back
+ * from that call.  It is kept in host-visible memory and returned ONCE by the first call on the same map that
+ * synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.  compat.hpp turns it into
+ * the reference's print-and-exit (common.cuh:10-21). */
 
 #define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
 #define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
 
 /* integrate pass selection, ws_tsdf_set_integrate() */
-#define WS_INTEGRATE_SPARSE 0 /* stream only 64-voxel tiles the scan touched (default)                 */
-#define WS_INTEGRATE_DENSE 1  /* stream every voxel like cu_avg_tsdf_krnl (update_tsdf.cu:13-43)       */
+#define WS_INTEGRATE_SPARSE 0 /* default: touched 8x8x16-voxel tiles only, folded into the scatter's tile resolve      */
+#define WS_INTEGRATE_DENSE 1  /* stream every voxel like cu_avg_tsdf_krnl (update_tsdf.cu:13-43)                      */
+#define WS_INTEGRATE_SPARSE_SEPARATE 2 /* touched tiles only, as a separate pass over new_map (the resolve writes new_map) */
 
 /* registration flags */
 #define WS_REG_ALL_POINTS 0u
@@ -115,21 +123,23 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* scatter implementation: the global-key path (default; always used when new_map is not (tau,0)) or the experimental
- * LDS-staged tile path (bit-identical results) */
-#define WS_SCATTER_TILES 0
-#define WS_SCATTER_GLOBAL 1
-int ws_tsdf_set_scatter(ws_map *map, int mode);
+/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers).  The default (32 Mi) holds a
+ * 131 072-point scan at 50 mm; the buffers grow by themselves before a scan when the PREVIOUS scan needed more, so only
+ * the first scan of a much larger kind can overflow (WS_ERR_CAPACITY, sticky).  Reserve up front to rule that out. */
+int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
 
 typedef struct
 {
-  int64_t contested_voxels;  /* voxels resolved by the exact ordered fallback in the last update */
-  int64_t contested_records; /* candidate records in the shared overflow area of the arena        */
-  int64_t dirty_tiles;       /* 64-voxel tiles streamed by the last sparse integrate              */
-  int32_t error_flags;       /* bit0 arena / record capacity exceeded, bit1 order-key range       */
+  int64_t contested_voxels; /* voxels of the last update decided by the exact ordered rounds (a negative-weight
+                               candidate could have blocked the earliest positive one)                         */
+  int64_t records;          /* scatter targets of the ray tails that went through the order keys                */
+  int64_t tiles;            /* touched 8x8x16-voxel tiles (resolved and integrated)                             */
+  int32_t error_flags;      /* device error bits since the last call: 1 capacity, 2 key range, 4 free-space bound, 8 internal */
   int32_t pad;
-  int64_t tile_records;      /* (ray, step-run) records binned by the LDS-tile path                */
-  int64_t tile_work_items;   /* workgroups-worth of tile work of the last update                   */
+  int64_t runs;             /* (workgroup, tile) runs of records                                                */
+  int64_t free_space_hits;  /* voxels where a free-space candidate met ordered candidates                       */
+  int64_t record_slots;     /* record slots reserved (upper bounds) out of ...                                  */
+  int64_t record_capacity;  /* ... this capacity                                                                */
 } ws_tsdf_stats_t;
 int ws_tsdf_stats(ws_map *map, ws_tsdf_stats_t *out); /* synchronises */
 
@@ -184,15 +194,14 @@ int ws_scan_download(ws_scan *scan, int32_t *xyz_host, size_t capacity_points, s
 
 /* ------------------------------------------------------------------ measurement ---- */
 /* Kernel classes for hipEvent timing (bench.py's roofline leg). */
-#define WS_K_MARCH_EMIT 0     /* ray-march, key emission (march_kernel<EMIT>)                 */
-#define WS_K_RESOLVE 1        /* key -> entry resolution over the touched tiles               */
-#define WS_K_MARCH_COLLECT 2  /* ray-march, candidate lists of contested voxels               */
-#define WS_K_RESOLVE_LISTS 3  /* ordered fold of those lists                                  */
-#define WS_K_INTEGRATE 4      /* dense or sparse weighted-average pass (cu_avg_tsdf_krnl)     */
-#define WS_K_REG 5            /* one Gauss-Newton iteration (accumulate + finish/solve)       */
-#define WS_K_TILE_BIN 6       /* LDS-tile path: count + scan + fill of the per-tile ray records */
-#define WS_K_TILE_SCATTER 7   /* LDS-tile path: march + resolve + integrate per tile           */
-#define WS_K_COUNT 8
+#define WS_K_SETUP 0         /* per-ray set-up + direction sort                                    */
+#define WS_K_MARCH_TAILS 1   /* ray tails -> records, sorted by tile per workgroup                 */
+#define WS_K_MARCH_FREE 2    /* free-space steps -> one byte per voxel                             */
+#define WS_K_TILE_BIN 3      /* runs per tile: count / scan / list / descriptor placement          */
+#define WS_K_TILE_RESOLVE 4  /* exact per-tile fold in LDS (+ fused integrate)                     */
+#define WS_K_INTEGRATE 5     /* separate sparse or dense weighted-average pass (cu_avg_tsdf_krnl)  */
+#define WS_K_REG 6           /* Gauss-Newton iterations (accumulate + solve)                       */
+#define WS_K_COUNT 7
 int ws_prof_enable(ws_context *ctx, uint32_t class_mask); /* 0 disables */
 /* sum of event-measured durations and number of launches per class since the last reset (synchronises) */
 int ws_prof_read(ws_context *ctx, int kernel_class, double *total_ms, int64_t *launches);

@@ -28,16 +28,21 @@ static inline int64_t wadd64(int64_t a, int64_t b) { return (int64_t)((uint64_t)
 static inline int64_t wsub64(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 static inline int32_t iabs32(int32_t a) { return a < 0 ? wsub(0, a) : a; }
 
-/* Vector3<int>::l2norm(): T(sqrtf(x*x+y*y+z*z)) with the sum in int (math/vector3.h:318-330) */
+/* Vector3<int>::l2norm(): T(sqrtf(x*x+y*y+z*z)) with the sum in int (math/vector3.h:318-330).
+ * Beyond ~46 m the int sum wraps and can be negative: sqrtf gives NaN, and the DEVICE float->int conversion of the
+ * reference's CUDA path (cvt.rzi.s32.f32) turns NaN into 0 (x86's cvttss2si would give INT_MIN; the oracle restates
+ * the CUDA kernel, and gfx950's v_cvt_i32_f32 agrees with it). */
 static inline int32_t l2norm_i(int32_t x, int32_t y, int32_t z)
 {
   int32_t sq = wadd(wadd(wmul(x, x), wmul(y, y)), wmul(z, z));
+  if (sq < 0) return 0;
   return (int32_t)sqrtf((float)sq);
 }
-/* Vector3<long>::l2norm(): long(sqrtf(float(long sum))) (math/vector3.h:318-330) */
+/* Vector3<long>::l2norm(): long(sqrtf(float(long sum))) (math/vector3.h:318-330); NaN -> 0 as above */
 static inline int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
 {
   int64_t sq = wadd64(wadd64(wmul64(x, x), wmul64(y, y)), wmul64(z, z));
+  if (sq < 0) return 0;
   return (int64_t)sqrtf((float)sq);
 }
 

@@ -13,16 +13,12 @@ def _torch():
     return torch
 
 
-SCATTER_MODES = ["tiles", "global"]
-
-
-def make_pair(size, tau, res, max_weight, default_weight=0, scatter="global"):
+def make_pair(size, tau, res, max_weight, default_weight=0):
     import warpsense_amd as W
     lm = W.LocalMap(size[0], size[1], size[2], tau, default_weight)
     om_avg = O.OracleMap(size, tau, default_weight)
     om_new = om_avg.copy()
     t = W.TSDFCuda(lm.device_map(), tau, max_weight, res)
-    t.set_scatter(W.WS_SCATTER_TILES if scatter == "tiles" else W.WS_SCATTER_GLOBAL)
     return lm, t, om_avg, om_new
 
 
@@ -33,11 +29,10 @@ def download(t, lm, which):
     return host.data_
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
-def test_kat_tsdf_write(scatter):
+def test_kat_tsdf_write():
     """test/map.cpp:9-90 / test/cuda.cpp:268-414: one point, res 1000, tau 3000, 21^3 map."""
     tau, res, mw = 3000, 1000, 640
-    lm, t, oa, on = make_pair((20, 20, 20), tau, res, mw, scatter=scatter)
+    lm, t, oa, on = make_pair((20, 20, 20), tau, res, mw)
     pts = np.array([[5500, 500, 500]], dtype=np.int32)
     t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
     avg = download(t, lm, 0)
@@ -49,14 +44,13 @@ def test_kat_tsdf_write(scatter):
     assert np.all(new == O.pack(tau, 0))
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
 @pytest.mark.parametrize("tau,res,size,rings,az", [(1000, 50, (128, 128, 64), 32, 256), (600, 64, (100, 100, 60), 16, 512),
                                                    (1000, 20, (160, 160, 80), 24, 128)])
-def test_scatter_matches_oracle(tau, res, size, rings, az, scatter):
+def test_scatter_matches_oracle(tau, res, size, rings, az):
     """new_map after the scatter == serial reference kernel (oracle wso_update_min), bit for bit."""
     torch = _torch()
     mw = 640
-    lm, t, oa, on = make_pair(size, tau, res, mw, scatter=scatter)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
     he = (size[0] * res * 0.4, size[1] * res * 0.35, size[2] * res * 0.3)
     pts = S.os1_128_scan(rings=rings, azimuths=az, half_extents_mm=he, seed=7)
     st = O.update_min(on, pts, (0, 0, 0), (0, 0, 32768), tau, res)
@@ -70,13 +64,12 @@ def test_scatter_matches_oracle(tau, res, size, rings, az, scatter):
     assert mism.size == 0, f"{mism.size} voxels differ, first {mism[:5]}, contested={stats}"
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
-def test_three_scans_avg_matches_oracle(scatter):
+def test_three_scans_avg_matches_oracle():
     """avg_map after 3 successive updates (moving sensor) is bit-exact; new_map is back to (tau,0)."""
     torch = _torch()
     tau, res, mw = 1000, 50, 640
     size = (128, 128, 64)
-    lm, t, oa, on = make_pair(size, tau, res, mw, scatter=scatter)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
     he = (2500.0, 2200.0, 900.0)
     for k, sensor in enumerate([(0, 0, 0), (120, -40, 10), (260, 30, -20)]):
         pts = S.os1_128_scan(sensor_mm=sensor, rings=32, azimuths=256, half_extents_mm=he, seed=11 + k)
@@ -95,14 +88,14 @@ def test_dense_equals_sparse():
     size = (96, 96, 48)
     he = (1800.0, 1500.0, 700.0)
     outs = []
-    for mode in (W.WS_INTEGRATE_SPARSE, W.WS_INTEGRATE_DENSE):
+    for mode in (W.WS_INTEGRATE_SPARSE, W.WS_INTEGRATE_DENSE, W.WS_INTEGRATE_SPARSE_SEPARATE):
         lm, t, _, _ = make_pair(size, tau, res, mw)
         t.set_integrate(mode)
         for k in range(2):
             pts = S.os1_128_scan(rings=16, azimuths=128, half_extents_mm=he, seed=3 + k)
             t.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
         outs.append(download(t, lm, 0))
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("tau,res,size,he,rings,az", [(1000, 50, (64, 64, 32), (1200.0, 1000.0, 500.0), 16, 128),
@@ -156,14 +149,13 @@ def _up_from_rpy(roll_deg, pitch_deg):
     return tuple(int(v) for v in (R[:, 2] * np.float32(32768)).astype(np.int32))
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
 @pytest.mark.parametrize("up", [(0, 0, 32768), _up_from_rpy(20.0, -15.0), (0, 23170, 23170), (32768, 0, 0)])
-def test_fans_and_contested_voxels_match_oracle(up, scatter):
+def test_fans_and_contested_voxels_match_oracle(up):
     """rays longer than len_neg (3277 mm at 20 mm voxels): off-ray fan candidates with negative weights, voxels whose
     winner depends on the canonical order (ordered fallback), for level and tilted interpolation vectors."""
     torch = _torch()
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
-    lm, t, oa, on = make_pair(size, tau, res, mw, scatter=scatter)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
     pts = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
     pos = (6, -4, 2)
     st = O.update_min(on, pts, pos, up, tau, res)
@@ -180,8 +172,7 @@ def test_fans_and_contested_voxels_match_oracle(up, scatter):
     t.integrate()
     assert np.array_equal(download(t, lm, 0), oa.data)
     stats = t.stats()  # the contested-voxel count is published by the integrate pass
-    if scatter == "global":
-        assert stats["contested_voxels"] > 10_000  # the ordered fallback did real work
+    assert stats["contested_voxels"] > 10_000  # the ordered rounds did real work
 
 
 def W_entry_weight(raw):
@@ -218,35 +209,38 @@ def test_full_size_scan_matches_oracle():
     assert np.linalg.norm(T[:3, 3] - To[:3, 3]) / 1000.0 < 1e-4 and np.abs(T[:3, :3] - To[:3, :3]).max() < 1e-4
 
 
-def test_full_size_tiles_equals_global():
-    """the experimental LDS-tile scatter on the benchmark scan: same 513^3 map as the default path, voxel for voxel"""
+def test_full_size_integrate_modes_agree():
+    """the benchmark scan through the three integrate routes (fused into the tile resolve, separate sparse pass,
+    reference-shaped dense pass): same 513^3 map voxel for voxel"""
     torch = _torch()
-    tau, res, mw, size = 1000, 50, 640, (512, 512, 512)
+    import warpsense_amd as W
+    tau, res, mw = 1000, 50, 640
     pts = torch.from_numpy(S.os1_128_scan()).cuda()
     out = []
-    for mode in ("global", "tiles"):
-        import warpsense_amd as W
+    for mode in (W.WS_INTEGRATE_SPARSE, W.WS_INTEGRATE_SPARSE_SEPARATE, W.WS_INTEGRATE_DENSE):
         view = W.DeviceMap([513, 513, 513], [256, 256, 256], None, (0, 0, 0))
         t = W.TSDFCuda(view, tau, mw, res)
-        t.set_scatter(W.WS_SCATTER_TILES if mode == "tiles" else W.WS_SCATTER_GLOBAL)
+        t.set_integrate(mode)
         t.update_tsdf(pts, (0, 0, 0), (0, 0, 32768))
         assert t.stats()["error_flags"] == 0
         host = W.DeviceMap(view.size_.copy(), view.offset_.copy(), np.empty(513 ** 3, dtype=np.uint32), view.pos_.copy())
         t.avg_map().to_host(host)
         out.append(host.data_)
+        new = W.DeviceMap(view.size_.copy(), view.offset_.copy(), np.empty(513 ** 3, dtype=np.uint32), view.pos_.copy())
+        t.new_map().to_host(new)
+        assert np.all(new.data_ == O.pack(tau, 0))
         t.close()
-    assert np.array_equal(out[0], out[1])
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
     assert int((out[0] != O.pack(tau, 0)).sum()) > 10_000_000
 
 
-def _pair_at(size, tau, res, mw, pos, offset, scatter="global"):
+def _pair_at(size, tau, res, mw, pos, offset):
     """device map + oracle maps for a window centred on `pos` with ring-buffer offset `offset` (as after shifts)."""
     import warpsense_amd as W
     size = [s if s % 2 == 1 else s + 1 for s in size]
     n = int(np.prod(np.asarray(size, dtype=np.int64)))
     view = W.DeviceMap(size, offset, np.full(n, O.pack(tau, 0), dtype=np.uint32), pos)
     t = W.TSDFCuda(view, tau, mw, res)
-    t.set_scatter(W.WS_SCATTER_TILES if scatter == "tiles" else W.WS_SCATTER_GLOBAL)
     oa = O.OracleMap(size, tau, 0, pos=pos, offset=offset)
     return view, t, oa, oa.copy()
 
@@ -258,9 +252,8 @@ def _download_view(t, view, which):
     return host.data_
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
 @pytest.mark.parametrize("sensor", [(0.0, 0.0, 0.0), (700_000.0, -350_000.0, 9_000.0)])
-def test_long_rays_take_the_wrapping_march(sensor, scatter):
+def test_long_rays_take_the_wrapping_march(sensor):
     """Ranges of 50-80 m: direction * len exceeds int32 and wraps in the reference's `int` arithmetic
     (update_tsdf.cu:59,69).  Such rays leave the division-free walk (march_steps_fast) for march_steps_direct, which must
     wrap exactly like the CUDA code / the oracle; the second case puts the sensor 780 m from the map origin."""
@@ -269,7 +262,7 @@ def test_long_rays_take_the_wrapping_march(sensor, scatter):
     size = (480, 440, 48)
     pos = tuple(int(np.floor(np.float32(s) / np.float32(res))) for s in sensor)
     offset = (17, 401, 3)
-    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset, scatter)
+    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset)
     # the room of os1_128_scan is centred on the map origin: move scan and room to the sensor
     pts = S.os1_128_scan(rings=32, azimuths=256, seed=21, half_extents_mm=(58_000.0, 52_000.0, 5_500.0))
     pts = (pts.astype(np.int64) + np.asarray(sensor, dtype=np.int64)).astype(np.int32)
@@ -287,8 +280,7 @@ def test_long_rays_take_the_wrapping_march(sensor, scatter):
     assert np.array_equal(_download_view(t, view, 0), oa.data)
 
 
-@pytest.mark.parametrize("scatter", SCATTER_MODES)
-def test_room_larger_than_the_window_with_ring_seam(scatter):
+def test_room_larger_than_the_window_with_ring_seam():
     """Points beyond the window fail in_bounds_with_buffer_pos (update_tsdf.cu:55), accepted rays leave the window on
     the way (in_bounds per step, :73,:113), and the ring-buffer seam of a shifted window runs through the fans."""
     torch = _torch()
@@ -296,7 +288,7 @@ def test_room_larger_than_the_window_with_ring_seam(scatter):
     size = (400, 400, 100)
     pos = (37, -52, 9)
     offset = (11, 250, 97)
-    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset, scatter)
+    view, t, oa, on = _pair_at(size, tau, res, mw, pos, offset)
     sensor = (pos[0] * res + 7.0, pos[1] * res + 13.0, pos[2] * res + 4.0)
     pts = S.os1_128_scan(rings=128, azimuths=512, seed=31, half_extents_mm=(6_000.0, 3_800.0, 1_150.0))
     pts = (pts.astype(np.int64) + np.asarray(sensor, dtype=np.int64)).astype(np.int32)
@@ -313,3 +305,46 @@ def test_room_larger_than_the_window_with_ring_seam(scatter):
         mism = np.nonzero(got != oa.data)[0]
         assert mism.size == 0, f"scan {k}: {mism.size} voxels differ, first {mism[:5]}"
     assert int((W_entry_weight(oa.data) < 0).sum()) > 1000
+
+
+def test_capacity_overflow_is_sticky_and_buffers_grow():
+    """A scan that needs more candidate records than the buffers hold cannot be exact.  update_tsdf only enqueues, so the
+    error comes back from the next call that synchronises (ws_sync here) — once — and the buffers have grown before the
+    next scan, which is exact again."""
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw, size = 600, 20, 640, (400, 400, 100)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    t.set_capacity(1 << 20)  # 1 Mi records; this scan reserves ~10 Mi
+    pts = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    d = torch.from_numpy(pts).cuda()
+    t.update_tsdf(d, (6, -4, 2), (0, 0, 32768))  # returns WS_OK: nothing is known yet
+    with pytest.raises(W.WsError, match="capacity"):
+        t.ctx.sync()
+    t.ctx.sync()  # reported once
+    st = t.stats()
+    assert st["status"] == 0 and st["record_capacity"] == 1 << 20
+    # start over on a fresh pair of maps: the library has seen what this kind of scan needs
+    blank = W.LocalMap(*size, tau, 0)
+    t.avg_map().to_device(blank.device_map())
+    t.new_map().to_device(blank.device_map())
+    t.update_tsdf(d, (6, -4, 2), (0, 0, 32768))
+    t.ctx.sync()
+    st = t.stats()
+    assert st["error_flags"] == 0 and st["record_capacity"] > st["record_slots"] > 1 << 20
+    O.update_tsdf(oa, on, pts, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+    assert np.array_equal(download(t, lm, 0), oa.data)
+
+
+def test_ray_beyond_the_key_range_is_reported():
+    """a ray of more than 65 536 steps cannot be ordered by the 16-bit step field of the key: it is dropped and the map's
+    next synchronising call says so (WS_ERR_RANGE), instead of returning a map that silently lacks it"""
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw = 32000, 2, 640  # 1 mm steps; distance 40 m + tau = 72 000 steps
+    view, t, oa, on = _pair_at((64, 64, 64), tau, res, mw, (0, 0, 0), (32, 32, 32))
+    pts = np.array([[60, 0, 0], [0, 61, 3]], dtype=np.int32)
+    t.update_tsdf(torch.from_numpy(pts).cuda(), (-20000, 0, 0), (0, 0, 32768))
+    with pytest.raises(W.WsError, match="65536 steps"):
+        t.ctx.sync()
+    assert np.all(_download_view(t, view, 0) == O.pack(tau, 0))

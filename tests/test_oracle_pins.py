@@ -169,8 +169,18 @@ def _check_against(get_index, in_bounds, in_pos, in_neg, l2i, l2l, cross, ray_se
     L.wso_l2norm_i.restype = C.c_int32
     L.wso_l2norm_l.restype = C.c_int64
     L.wso_l2norm_l.argtypes = [C.c_int64] * 3
-    assert np.array_equal(np.array([L.wso_l2norm_i(int(a), int(b), int(c)) for a, b, c in g["l2_in"]]), g["l2_i"])
-    assert np.array_equal(np.array([L.wso_l2norm_l(int(a), int(b), int(c)) for a, b, c in g["l2l_in"]]), g["l2_l"])
+    # Where the int sum of squares wraps to a negative number sqrtf gives NaN and float->int is undefined in C++: the
+    # host build of the reference header (the golden) shows x86's INT_MIN, the reference's CUDA device code gives 0
+    # (cvt.rzi of NaN), and so does gfx950.  The oracle restates the device: 0 there, the golden everywhere else.
+    got = np.array([L.wso_l2norm_i(int(a), int(b), int(c)) for a, b, c in g["l2_in"]])
+    v = g["l2_in"].astype(np.int64)
+    wrapped = (((v * v).sum(axis=1) + 2 ** 31) % 2 ** 32) - 2 ** 31
+    nan = wrapped < 0
+    assert nan.sum() > 0 and np.all(g["l2_i"][nan] == -2 ** 31) and np.all(got[nan] == 0)
+    assert np.array_equal(got[~nan], g["l2_i"][~nan])
+    got_l = np.array([L.wso_l2norm_l(int(a), int(b), int(c)) for a, b, c in g["l2l_in"]])
+    nan_l = g["l2_l"] == -2 ** 63
+    assert np.all(got_l[nan_l] == 0) and np.array_equal(got_l[~nan_l], g["l2_l"][~nan_l])
     out = np.zeros(3, dtype=np.int32)
     for a, b, want in zip(g["cross_a"], g["cross_b"], g["cross_out"]):
         L.wso_cross_i(O._p(np.ascontiguousarray(a)), O._p(np.ascontiguousarray(b)), O._p(out))

@@ -11,21 +11,18 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
 
 WS_MAP_AVG, WS_MAP_NEW = 0, 1
-WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE = 0, 1
+WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE, WS_INTEGRATE_SPARSE_SEPARATE = 0, 1, 2
 WS_REG_ALL_POINTS, WS_REG_COMPAT_REFERENCE_LAUNCH = 0, 1
 WS_REG_LOOP_RESIDENT, WS_REG_LOOP_LAUNCHES = 0, 1
-(WS_K_MARCH_EMIT, WS_K_RESOLVE, WS_K_MARCH_COLLECT, WS_K_RESOLVE_LISTS, WS_K_INTEGRATE, WS_K_REG, WS_K_TILE_BIN,
- WS_K_TILE_SCATTER) = range(8)
-KERNEL_CLASSES = ["march_emit", "resolve", "march_collect", "resolve_lists", "integrate", "reg_iteration", "tile_bin",
-                  "tile_scatter"]
-WS_SCATTER_TILES, WS_SCATTER_GLOBAL = 0, 1
+(WS_K_SETUP, WS_K_MARCH_TAILS, WS_K_MARCH_FREE, WS_K_TILE_BIN, WS_K_TILE_RESOLVE, WS_K_INTEGRATE, WS_K_REG) = range(7)
+KERNEL_CLASSES = ["ray_setup", "march_tails", "march_free", "tile_bin", "tile_resolve", "integrate", "reg_iteration"]
 
 # every symbol include/warpsense_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "ws_last_error", "ws_version", "ws_ctx_create", "ws_ctx_destroy", "ws_ctx_set_stream", "ws_sync",
     "ws_device_reset", "ws_map_create", "ws_map_destroy", "ws_map_upload", "ws_map_set_params", "ws_map_download",
     "ws_map_extract_box", "ws_map_insert_box", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
-    "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_scatter", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
+    "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
     "ws_reg_solve_dev", "ws_reg_poll", "ws_reg_set_loop", "ws_debug_solve6", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
     "ws_scan_preprocess_dev", "ws_scan_points_dev", "ws_scan_download", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
@@ -81,8 +78,9 @@ def check_h5(rc: int, what: str):
 
 
 class TsdfStats(C.Structure):
-    _fields_ = [("contested_voxels", C.c_int64), ("contested_records", C.c_int64), ("dirty_tiles", C.c_int64),
-                ("error_flags", C.c_int32), ("pad", C.c_int32), ("tile_records", C.c_int64), ("tile_work_items", C.c_int64)]
+    _fields_ = [("contested_voxels", C.c_int64), ("records", C.c_int64), ("tiles", C.c_int64),
+                ("error_flags", C.c_int32), ("pad", C.c_int32), ("runs", C.c_int64), ("free_space_hits", C.c_int64),
+                ("record_slots", C.c_int64), ("record_capacity", C.c_int64)]
 
 
 _lib = None
@@ -127,7 +125,7 @@ def load() -> C.CDLL:
     L.ws_tsdf_scatter_dev.argtypes = [vp, vp, sz, vp, vp]
     L.ws_tsdf_integrate.argtypes = [vp]
     L.ws_tsdf_set_integrate.argtypes = [vp, C.c_int]
-    L.ws_tsdf_set_scatter.argtypes = [vp, C.c_int]
+    L.ws_tsdf_set_capacity.argtypes = [vp, C.c_uint64]
     L.ws_tsdf_stats.argtypes = [vp, P(TsdfStats)]
     L.ws_reg_create.argtypes = [vp, sz, P(vp)]
     L.ws_reg_destroy.argtypes = [vp]

@@ -498,15 +498,18 @@ class TSDFCuda:
     def set_integrate(self, mode: int):
         check(self._L.ws_tsdf_set_integrate(self.handle, int(mode)), "ws_tsdf_set_integrate")
 
-    def set_scatter(self, mode: int):
-        check(self._L.ws_tsdf_set_scatter(self.handle, int(mode)), "ws_tsdf_set_scatter")
+    def set_capacity(self, records: int):
+        check(self._L.ws_tsdf_set_capacity(self.handle, int(records)), "ws_tsdf_set_capacity")
 
-    def stats(self) -> dict:
+    def stats(self, raise_on_error: bool = False) -> dict:
         st = _lib.TsdfStats()
-        check(self._L.ws_tsdf_stats(self.handle, C.byref(st)), "ws_tsdf_stats")
-        return {"contested_voxels": st.contested_voxels, "contested_records": st.contested_records,
-                "dirty_tiles": st.dirty_tiles, "error_flags": st.error_flags, "tile_records": st.tile_records,
-                "tile_work_items": st.tile_work_items}
+        rc = self._L.ws_tsdf_stats(self.handle, C.byref(st))
+        out = {"contested_voxels": st.contested_voxels, "records": st.records, "tiles": st.tiles, "error_flags": st.error_flags,
+               "runs": st.runs, "free_space_hits": st.free_space_hits, "record_slots": st.record_slots,
+               "record_capacity": st.record_capacity, "status": rc}
+        if rc != 0 and raise_on_error:
+            check(rc, "ws_tsdf_stats")
+        return out
 
     def device_map(self):
         return self.handle

@@ -8,7 +8,6 @@ The library is written to warpsense_amd/libwarpsense_hip.so (git-ignored, travel
 WS_EXTRA_FLAGS adds compiler flags, e.g. the instrumentation switches of the kernels (they print per-phase clock
 ticks from a few workgroups; never used in the shipped build):
     -DWS_REG_TIMING / -DWS_REG_TIMING_GN   phases of the resident registration loop / of the Gauss-Newton update
-    -DWS_TILE_TIMING                        phases of the experimental LDS-tile scatter
     -DWS_REG_BLOCKS=.. -DWS_REG_THREADS=..  grid shape of the registration kernels (default 256 x 512)
 """
 from __future__ import annotations
@@ -23,9 +22,8 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
 H5_LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_h5.so")  # optional: global-map file (needs the HDF5 C library)
-SOURCES = ["api.hip", "tsdf_update.hip", "tsdf_tiles.hip", "registration.hip", "scan_preprocess.hip"]
+SOURCES = ["api.hip", "tsdf_update.hip", "registration.hip", "scan_preprocess.hip"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_device.h"), os.path.join(CSRC, "ws_march.h"),
-           os.path.join(CSRC, "ws_tiles.h"),
            os.path.join(ROOT, "include", "warpsense_hip.h")]
 ARCH = "gfx950"
 

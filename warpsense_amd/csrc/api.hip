@@ -94,6 +94,10 @@ static void copy3(int32_t dst[3], const int32_t src[3])
 }
 
 size_t reg_partials_bytes();
+} // namespace ws
+static int ctx_take_errors(ws_context *ctx);
+namespace ws
+{
 constexpr size_t AZ_ALLOC = 1024 * 64 + 8; // direction-bin histogram / offsets (tsdf_update.hip: AZ_BINS + 2 entries)
 } // namespace ws
 
@@ -159,7 +163,7 @@ int ws_sync(ws_context *ctx)
 {
   if (!ctx) return invalid("ws_sync: ctx is NULL");
   WS_HIP(hipStreamSynchronize(ctx->stream));
-  return WS_OK;
+  return ctx_take_errors(ctx);
 }
 
 int ws_device_reset(void)
@@ -169,18 +173,97 @@ int ws_device_reset(void)
 }
 
 // ------------------------------------------------------------------ maps
+static void map_free_records(ws_map *m)
+{
+  void *ptrs[] = {m->rec_raw, m->rec_sorted, m->desc, m->sorted_desc};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  m->rec_raw = m->rec_sorted = nullptr;
+  m->desc = nullptr;
+  m->sorted_desc = nullptr;
+  m->rec_cap = m->desc_cap = 0;
+}
+
+// candidate-record buffers of the tail march: two record arrays (as emitted / sorted by tile) + run descriptors
+static int map_alloc_records(ws_map *m, uint64_t records)
+{
+  if (records < (1u << 20)) records = 1u << 20;
+  if (records > 0xfffffff0ull) records = 0xfffffff0ull;
+  map_free_records(m);
+  uint64_t descs = records / 8; // a run holds ~100 records on LiDAR scans; 8 leaves room for scattered clouds
+  if (descs < (1u << 18)) descs = 1u << 18;
+  WS_HIP(hipMalloc((void **)&m->rec_raw, (size_t)records * sizeof(CandRecord)));
+  WS_HIP(hipMalloc((void **)&m->rec_sorted, (size_t)records * sizeof(CandRecord)));
+  WS_HIP(hipMalloc((void **)&m->desc, (size_t)descs * sizeof(RunDesc)));
+  WS_HIP(hipMalloc((void **)&m->sorted_desc, (size_t)descs * 2 * sizeof(uint32_t)));
+  m->rec_cap = (uint32_t)records;
+  m->desc_cap = (uint32_t)descs;
+  return WS_OK;
+}
+
 static int map_free(ws_map *m)
 {
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
-  void *ptrs[] = {m->data[0], m->data[1], m->kpos,    m->kneg,  m->dirty, m->vstate, m->az_hist, m->az_off, m->ray_order, m->dirty_list, m->rays, m->scan_dev,
-                  m->counters, m->arena, m->contested_per_wave, m->tile_count, m->tile_offset, m->tile_cursor, m->tile_records,
-                  m->tile_work, m->tile_state, m->box_stage};
+  if (m->shift_stream) (void)hipStreamSynchronize(m->shift_stream);
+  for (size_t i = 0; i < m->ctx->maps.size(); ++i)
+    if (m->ctx->maps[i] == m)
+    {
+      m->ctx->maps.erase(m->ctx->maps.begin() + (long)i);
+      break;
+    }
+  map_free_records(m);
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_order, m->rays, m->scan_dev, m->counters, m->tile_nruns,
+                  m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->fk_vals, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
+  if (m->status_host) (void)hipHostFree(m->status_host);
+  if (m->shift_stream) (void)hipStreamDestroy(m->shift_stream);
   delete m;
   return WS_OK;
+}
+
+// Device-side error bits (record / descriptor / hash capacity exceeded, a ray outside the order-key range, internal
+// checks) are OR-ed into a host-mapped word by the kernels.  Every entry point that has just synchronised the stream
+// looks at it: an inexact map is reported ONCE, by the first such call after the update that produced it.
+static int map_take_error(ws_map *m)
+{
+  if (!m || !m->status_host) return WS_OK;
+  volatile uint32_t *st = m->status_host;
+  const uint32_t bits = st[0];
+  if (!bits) return WS_OK;
+  __atomic_fetch_and(m->status_host, ~bits, __ATOMIC_RELAXED);
+  m->last_error_bits |= bits;
+  if (bits & 8u)
+  {
+    set_error("TSDF update: internal consistency check failed on the device (record slice bound / free-space hash); the map is not exact");
+    return WS_ERR_INTERNAL;
+  }
+  if (bits & 4u)
+  {
+    set_error("TSDF update: a free-space step produced a candidate that is not free space; the map is not exact");
+    return WS_ERR_INTERNAL;
+  }
+  if (bits & 1u)
+  {
+    set_error("TSDF update: candidate-record capacity exceeded, a TSDF update since the last check is not exact "
+              "(the buffers grow before the next scan; ws_tsdf_set_capacity reserves them up front)");
+    return WS_ERR_CAPACITY;
+  }
+  set_error("TSDF update: a ray needs more than 65536 steps or 256 fan steps (outside the order-key range) and was dropped");
+  return WS_ERR_RANGE;
+}
+
+static int ctx_take_errors(ws_context *ctx)
+{
+  int rc = WS_OK;
+  for (ws_map *m : ctx->maps)
+  {
+    const int r = map_take_error(m);
+    if (rc == WS_OK) rc = r;
+  }
+  return rc;
 }
 
 int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], const int32_t offset[3],
@@ -201,12 +284,20 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     copy3(m->par[w].offset, offset);
   }
   m->n_vox = (int64_t)size[0] * size[1] * size[2];
-  m->n_tiles = (m->n_vox + (1 << TILE_SHIFT) - 1) >> TILE_SHIFT;
+  m->ntx = (size[0] + 7) >> TILE_XB;
+  m->nty = (size[1] + 7) >> TILE_YB;
+  m->ntz = (size[2] + 15) >> TILE_ZB;
+  m->n_tiles = (int64_t)m->ntx * m->nty * m->ntz;
+  if (m->n_tiles >= 0xffffffffll)
+  {
+    delete m;
+    return invalid("ws_map_create: more than 2^32 tiles");
+  }
+  m->scan_blocks = tile_scan_blocks(m->n_tiles);
   m->tau = tau;
   m->max_weight = max_weight;
   m->res = res;
-  // contested-voxel capacity: generous fixed pools (usage is reported by ws_tsdf_stats)
-  m->arena_cap = 1u << 24;     // 16 Mi records (256 MiB)
+  m->fk_slots = 1u << 20;
 
   hipStream_t s = ctx->stream;
   int rc = WS_OK;
@@ -224,13 +315,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   const size_t map_bytes = (size_t)m->n_vox * sizeof(uint32_t);
   TRY(hipMalloc((void **)&m->data[0], map_bytes));
   TRY(hipMalloc((void **)&m->data[1], map_bytes));
-  TRY(hipMalloc((void **)&m->kpos, (size_t)m->n_vox * sizeof(uint64_t)));
-  TRY(hipMalloc((void **)&m->kneg, (size_t)m->n_vox * sizeof(uint64_t)));
-  TRY(hipMalloc((void **)&m->dirty, (size_t)m->n_tiles));
   TRY(hipMalloc((void **)&m->vstate, (size_t)m->n_vox));
   TRY(hipMemsetAsync(m->vstate, 0, (size_t)m->n_vox, s));
-  TRY(hipMalloc((void **)&m->dirty_list, (size_t)m->n_tiles * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * 48));
+  TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
@@ -238,30 +325,31 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMemsetAsync(m->az_off, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
-  TRY(hipMalloc((void **)&m->arena, (size_t)m->arena_cap * sizeof(ContestedRecord)));
-  TRY(hipMalloc((void **)&m->contested_per_wave, 8192 * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(m->contested_per_wave, 0, 8192 * sizeof(uint32_t), s));
-  {
-    // LDS-tile scatter: 8 x 8 x 16 tiles of the ring buffer
-    const int64_t ntx = (size[0] + 7) >> 3, nty = (size[1] + 7) >> 3, ntz = (size[2] + 15) >> 4;
-    m->n_tiles3d = ntx * nty * ntz;
-    m->tile_records_cap = 64u << 20; // 64 Mi run records (512 MiB); a 131 072-point scan needs ~8 Mi
-    m->tile_work_cap = (uint32_t)(m->n_tiles3d + (m->tile_records_cap >> 11) + 1024);
-    TRY(hipMalloc((void **)&m->tile_count, (size_t)m->n_tiles3d * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&m->tile_offset, (size_t)m->n_tiles3d * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&m->tile_cursor, (size_t)m->n_tiles3d * sizeof(uint32_t)));
-    TRY(hipMalloc((void **)&m->tile_records, (size_t)m->tile_records_cap * sizeof(uint64_t)));
-    TRY(hipMalloc((void **)&m->tile_work, (size_t)m->tile_work_cap * 16));
-    TRY(hipMalloc((void **)&m->tile_state, 16));
-    TRY(hipMemsetAsync(m->tile_count, 0, (size_t)m->n_tiles3d * sizeof(uint32_t), s));
-    TRY(hipMemsetAsync(m->tile_cursor, 0, (size_t)m->n_tiles3d * sizeof(uint32_t), s));
-    TRY(hipMemsetAsync(m->tile_state, 0, 16, s));
-  }
-  TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
-  TRY(hipMemsetAsync(m->kpos, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
-  TRY(hipMemsetAsync(m->kneg, 0xff, (size_t)m->n_vox * sizeof(uint64_t), s));
-  TRY(hipMemsetAsync(m->dirty, 0, (size_t)m->n_tiles, s));
   TRY(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
+  // per-tile bookkeeping of the scatter: 9 bytes + one 16-byte list entry per 1024 voxels
+  TRY(hipMalloc((void **)&m->tile_nruns, (size_t)m->n_tiles * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->tile_begin, (size_t)m->n_tiles * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->tile_dirty, (size_t)m->n_tiles));
+  TRY(hipMalloc((void **)&m->tile_list, (size_t)m->n_tiles * sizeof(TileEntry)));
+  TRY(hipMalloc((void **)&m->block_sums, (size_t)m->scan_blocks * 4 * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->tile_dirty, 0, (size_t)m->n_tiles, s));
+  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * sizeof(unsigned long long)));
+  TRY(hipMalloc((void **)&m->fk_vals, (size_t)m->fk_slots * sizeof(unsigned long long)));
+  TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));
+  TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
+  TRY(hipHostMalloc((void **)&m->status_host, 64, hipHostMallocMapped));
+  std::memset(m->status_host, 0, 64);
+  TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
+  // records of the ray tails: 32 Mi by default (a 131 072-point OS1 scan at 50 mm reserves ~29 Mi slots);
+  // grows on demand from the previous scan's need, ws_tsdf_set_capacity() reserves up front
+  rc = map_alloc_records(m, 32ull << 20);
+  if (rc != WS_OK)
+  {
+    map_free(m);
+    return rc;
+  }
   const uint32_t def = ((uint32_t)tau & 0xffffu);
   if (host_data)
   {
@@ -283,6 +371,7 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     m->new_is_default = true;
   }
 #undef TRY
+  ctx->maps.push_back(m);
   *out = m;
   return WS_OK;
 }
@@ -323,7 +412,7 @@ int ws_map_download(ws_map *m, int which, int32_t size[3], int32_t pos[3], int32
     WS_HIP(hipMemcpyAsync(host_data, m->data[which], (size_t)m->n_vox * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
   }
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  return WS_OK;
+  return map_take_error(m);
 }
 
 // ---- box transfers: the device side of the map shift (only the slabs that leave / enter move)
@@ -360,7 +449,7 @@ int ws_map_extract_box(ws_map *m, int which, const int32_t lo[3], const int32_t 
   size_t n = 0;
   int rc = box_check(m, which, lo, hi, ext, &n);
   if (rc != WS_OK) return rc;
-  rc = launch_box_copy(m, which, lo, ext, m->box_stage, true);
+  rc = launch_box_copy(m, which, lo, ext, m->box_stage, true, m->ctx->stream);
   if (rc != WS_OK) return rc;
   WS_HIP(hipMemcpyAsync(host_out, m->box_stage, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -375,7 +464,7 @@ int ws_map_insert_box(ws_map *m, int which, const int32_t lo[3], const int32_t h
   int rc = box_check(m, which, lo, hi, ext, &n);
   if (rc != WS_OK) return rc;
   WS_HIP(hipMemcpyAsync(m->box_stage, host_in, n * sizeof(uint32_t), hipMemcpyHostToDevice, m->ctx->stream));
-  rc = launch_box_copy(m, which, lo, ext, m->box_stage, false);
+  rc = launch_box_copy(m, which, lo, ext, m->box_stage, false, m->ctx->stream);
   if (rc != WS_OK) return rc;
   WS_HIP(hipStreamSynchronize(m->ctx->stream)); // the host buffer may be reused by the caller
   if (which == WS_MAP_NEW) m->new_is_default = false;
@@ -393,30 +482,46 @@ int64_t ws_map_n_voxels(const ws_map *m) { return m ? m->n_vox : 0; }
 // ------------------------------------------------------------------ TSDF update
 int ws_tsdf_set_integrate(ws_map *m, int mode)
 {
-  if (!m || (mode != WS_INTEGRATE_SPARSE && mode != WS_INTEGRATE_DENSE)) return invalid("ws_tsdf_set_integrate: bad argument");
+  if (!m || (mode != WS_INTEGRATE_SPARSE && mode != WS_INTEGRATE_DENSE && mode != WS_INTEGRATE_SPARSE_SEPARATE))
+    return invalid("ws_tsdf_set_integrate: bad argument");
   m->integrate_mode = mode;
   return WS_OK;
 }
 
-int ws_tsdf_set_scatter(ws_map *m, int mode)
+int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
-  if (!m || (mode != WS_SCATTER_TILES && mode != WS_SCATTER_GLOBAL)) return invalid("ws_tsdf_set_scatter: bad argument");
-  m->scatter_mode = mode;
-  return WS_OK;
+  if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return map_alloc_records(m, records);
+}
+
+// the previous scan left the sum of its per-ray record upper bounds in host-mapped memory: grow the record buffers
+// before a scan that would not fit (a hint read without synchronisation; the first scan of a kind may still overflow,
+// which is reported as WS_ERR_CAPACITY by the next synchronising call)
+static int grow_for_next_scan(ws_map *m)
+{
+  const uint64_t need = *reinterpret_cast<volatile uint64_t *>(m->status_host + 2);
+  if (need + need / 4 <= m->rec_cap) return WS_OK;
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return map_alloc_records(m, need + need / 2);
+}
+
+static int too_many_points(size_t n)
+{
+  // update_tsdf.cu:146-150: message, no work
+  char buf[160];
+  snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
+  set_error(buf);
+  return WS_ERR_TOO_MANY_POINTS;
 }
 
 int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
-  if (n > MAX_SCAN_POINTS)
-  {
-    // update_tsdf.cu:146-150: message, no work
-    char buf[160];
-    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
-    set_error(buf);
-    return WS_ERR_TOO_MANY_POINTS;
-  }
-  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
+  if (n > MAX_SCAN_POINTS) return too_many_points(n);
+  int rc = grow_for_next_scan(m);
+  if (rc != WS_OK) return rc;
+  rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
   if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
   return rc;
 }
@@ -430,16 +535,12 @@ int ws_tsdf_integrate(ws_map *m)
 int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_update_dev: NULL argument");
-  if (n > MAX_SCAN_POINTS)
-  {
-    char buf[160];
-    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
-    set_error(buf);
-    return WS_ERR_TOO_MANY_POINTS;
-  }
-  // scatter with the map's current state flag, integrate with the same flag (dense if new_map was not default)
-  // with the sparse integrate the tile path folds cu_avg_tsdf_krnl into its write-back (new_map stays (tau, 0))
-  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
+  if (n > MAX_SCAN_POINTS) return too_many_points(n);
+  int rc = grow_for_next_scan(m);
+  if (rc != WS_OK) return rc;
+  // with the default (sparse) integrate the tile resolve folds cu_avg_tsdf_krnl into its write-back (new_map stays
+  // (tau, 0)); a non-default new_map is resolved on top of its entries and integrated by the dense pass
+  rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
   if (rc != WS_OK) return rc;
   return launch_tsdf_integrate(m);
 }
@@ -447,13 +548,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
 int ws_tsdf_update(ws_map *m, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
 {
   if (!m || (!xyz_host && n) || !scanner_pos || !up) return invalid("ws_tsdf_update: NULL argument");
-  if (n > MAX_SCAN_POINTS)
-  {
-    char buf[160];
-    snprintf(buf, sizeof buf, "TSDF update with %zu points, larger than the maximum of %zu", n, MAX_SCAN_POINTS);
-    set_error(buf);
-    return WS_ERR_TOO_MANY_POINTS;
-  }
+  if (n > MAX_SCAN_POINTS) return too_many_points(n);
   if (n)
   {
     // pageable source: hipMemcpyAsync stages the data before it returns, like the reference's cudaMemcpy (update_tsdf.cu:152)
@@ -467,29 +562,19 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   if (!m || !out) return invalid("ws_tsdf_stats: NULL argument");
   WS_HIP(hipMemcpyAsync(m->counters_host, m->counters, sizeof(TsdfCounters), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  out->contested_voxels = m->counters_host->last_contested;
-  {
-    uint32_t ts[4] = {0, 0, 0, 0};
-    WS_HIP(hipMemcpyAsync(ts, m->tile_state, sizeof ts, hipMemcpyDeviceToHost, m->ctx->stream));
-    WS_HIP(hipStreamSynchronize(m->ctx->stream));
-    out->contested_voxels += ts[2];
-    out->tile_records = ts[1];
-    out->tile_work_items = ts[0];
-  }
-  out->contested_records = m->counters_host->records;
-  out->dirty_tiles = m->counters_host->last_dirty_tiles;
-  out->error_flags = (int32_t)m->counters_host->error;
-  if (out->error_flags & 1)
-  {
-    set_error("contested-voxel arena exhausted: the last TSDF update is not exact");
-    return WS_ERR_CAPACITY;
-  }
-  if (out->error_flags & 2)
-  {
-    set_error("a ray needs more than 65536 steps or 256 fan steps: outside the supported range");
-    return WS_ERR_RANGE;
-  }
-  return WS_OK;
+  const TsdfCounters *c = m->counters_host;
+  out->contested_voxels = c->last_contested;
+  out->records = c->last_records;
+  out->tiles = c->last_listed;
+  out->runs = c->last_runs;
+  out->free_space_hits = c->last_free_keyed;
+  out->record_slots = c->raw_cursor;
+  out->record_capacity = m->rec_cap;
+  const int rc = map_take_error(m);
+  out->error_flags = (int32_t)m->last_error_bits;
+  out->pad = 0;
+  m->last_error_bits = 0;
+  return rc;
 }
 
 // ------------------------------------------------------------------ registration
@@ -589,7 +674,7 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
   std::memcpy(g, sums + 36, 6 * sizeof(int64_t));
   *e = (int32_t)sums[42];
   *c = (int32_t)sums[43];
-  return WS_OK;
+  return map_take_error(const_cast<ws_map *>(m));
 }
 
 int ws_reg_begin(ws_reg *r, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon)
@@ -666,7 +751,7 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
     }
     std::memcpy(T_out, h->T, 16 * sizeof(float));
     if (iterations) *iterations = h->iterations;
-    return WS_OK;
+    return map_take_error(const_cast<ws_map *>(m));
   }
   int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
   if (rc != WS_OK) return rc;
@@ -687,7 +772,7 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
   rc = ws_reg_poll(r, &fin, &iters, T_out);
   if (rc != WS_OK) return rc;
   if (iterations) *iterations = iters;
-  return WS_OK;
+  return map_take_error(const_cast<ws_map *>(m));
 }
 
 int ws_reg_set_loop(ws_reg *r, int mode)

@@ -5,31 +5,37 @@
 // The reference scatters with a racy CAS ("first positive-weight entry freezes the voxel",
 // include/warpsense/cuda/util.h:70-102), so its result depends on thread arrival order.  This
 // implementation computes the result of ONE fixed legal schedule — the serial one, ascending
-// (point, ray step, fan step) — deterministically:
+// (point, ray step, fan step) — deterministically, without a single global atomic per candidate:
 //
-//   march<EMIT>     every candidate carries an order key t; per voxel two 64-bit atomicMin words keep
-//                   kpos = earliest positive-weight candidate, kneg = smallest-|value| (latest on ties)
-//                   negative-weight candidate; a byte per 64-voxel tile marks touched tiles.
-//   resolve         voxels whose earliest positive candidate cannot have been blocked by any negative
-//                   one (|v_pos| <= min |v_neg|) — or that only saw negatives — are final: the entry
-//                   is written to new_map.  The rest are "contested" and get a list head.
-//   march<COLLECT>  (only if contested voxels exist) appends every candidate of a contested voxel to a
-//                   linked list in an arena.
-//   resolve_lists   folds each list in ascending key order with the reference's accept rule -> new_map.
-//   integrate       weighted average of new_map into avg_map and reset of new_map, either over the
-//                   touched tiles only (sparse) or over every voxel (dense, the reference's kernel).
+//   ray_setup/scan/scatter   per-ray constants (update_tsdf.cu:52-63), rays grouped by direction.
+//   march_tail_kernel        walks the ray TAILS once (near-surface and fan candidates: everything whose result
+//                            depends on the order).  Every scatter target becomes a 16-byte record
+//                            (order key, tile, voxel-in-tile) appended to the workgroup's private slice with
+//                            coalesced stores; the workgroup then sorts its own records by tile through an LDS hash
+//                            and publishes one run descriptor per (workgroup, tile).
+//   march_free_kernel        walks the steps before the tails: all free space (tau, +64) whoever comes first ->
+//                            one byte per voxel.  A free-space candidate landing on a voxel the tails marked goes
+//                            into a small (voxel -> earliest key) hash instead.
+//   tile_count/scan/list     runs per tile -> contiguous descriptor ranges + the list of touched tiles.
+//   desc_place_kernel        run descriptors grouped by tile.
+//   tile_resolve_kernel      ONE workgroup per touched 8x8x16-voxel tile: all candidates of the tile are present,
+//                            so the canonical accept rule is a local fold in LDS (earliest positive / smallest
+//                            negative keys, then exact rounds for the voxels where a negative-weight candidate
+//                            may have blocked the earliest positive one).  Writes new_map, or — fused — integrates
+//                            straight into avg_map (cu_avg_tsdf_krnl folded into the write-back).
+//   integrate_*_kernel       weighted average of new_map into avg_map and reset of new_map, over the touched
+//                            tiles only (sparse) or over every voxel (dense, the reference's kernel).
 //
-// new_map after resolve* is bit-identical to what the reference kernel leaves there when its threads
+// new_map after the resolve is bit-identical to what the reference kernel leaves there when its threads
 // run one after the other (oracle/ws_oracle.c: wso_update_min).
 #include <cstddef>
 
 #include "ws_march.h"
-#include "ws_tiles.h"
 
 namespace ws
 {
 
-struct MarchArgs
+struct ScatterArgs
 {
   const int32_t *xyz;
   uint32_t n;
@@ -38,90 +44,89 @@ struct MarchArgs
   MapParams map; // new_map's parameters (the reference indexes new_map in the scatter, update_tsdf.cu:55-125)
   int32_t tau;
   int32_t res;
-  FastDiv resdiv;
+  int32_t ntx, nty, ntz;
+  int32_t all_keyed;     // new_map is not (tau, 0): every candidate goes through the order keys, no free-space pass
+  int32_t keyed_len_neg; // smallest ray length with off-ray (negative-weight) candidates
+  int32_t keyed_slack;   // see ray_setup_kernel
   RaySetup *rays;
-  uint64_t *kpos;
-  uint64_t *kneg;
-  uint8_t *dirty;
-  uint8_t *vstate;          // one byte per voxel: VOX_KEYED / VOX_TOUCHED (split scatter)
-  uint32_t *az_hist;        // [AZ_BINS + 1] rays per azimuth bin (last bin: rays that contribute nothing)
-  uint32_t *az_off;         // [AZ_BINS + 2] exclusive scan of az_hist
-  uint32_t *ray_order;      // ray indices sorted by azimuth bin
-  int32_t keyed_len_neg;    // smallest ray length with off-ray (negative-weight) candidates
-  int32_t keyed_slack;      // see keyed_first_step()
-  const uint32_t *new_data; // only read when HAS_S0
+  uint32_t *az_hist;   // [AZ_BINS + 1] rays per direction bin (last bin: rays that contribute nothing)
+  uint32_t *az_off;    // [AZ_BINS + 2] exclusive scan of az_hist
+  uint32_t *ray_order; // ray indices sorted by direction bin
+  uint8_t *vstate;     // one byte per voxel: VOX_*
+  uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
+  uint32_t *tile_nruns;
+  CandRecord *rec_raw;
+  CandRecord *rec_sorted;
+  uint32_t rec_cap;
+  RunDesc *desc;
+  uint32_t desc_cap;
+  unsigned long long *fk_keys;
+  unsigned long long *fk_vals;
+  int32_t fk_shift; // 64 - log2(slots)
+  uint32_t fk_mask;
+  uint32_t *tail_stats; // records per workgroup of the tail march
   TsdfCounters *counters;
-  ContestedRecord *arena;
-  uint32_t arena_cap;
-  uint32_t arena_slice;    // records reserved per workgroup of the collect pass
-  int32_t collect_min_len; // COLLECT: steps below this length cannot reach a contested voxel
-  int32_t tag_in_vstate;   // COLLECT: contested voxels are marked VOX_CONTESTED in vstate (split scatter), else by kpos
+  uint32_t *status; // host-mapped: [0] sticky error bits
 };
 
-// Bump allocation for the lanes that reach this point together: one atomic per wave, not per lane.
-// (A single shared counter hit once per lane costs ~4 ns per hit on MI355X, i.e. milliseconds per pass.)
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter)
-{
-  const unsigned long long mask = __ballot(1);
-  const int lane = (int)(threadIdx.x & 63);
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
+constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_FREEHIT = 4;
+constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
-// Record allocation for the collect pass.  A shared bump counter costs ~10-20 ns per hit on MI355X even
-// when only wave leaders touch it, so every workgroup owns a fixed slice of the arena and allocates from it
-// with an LDS cursor; the shared counter (placed behind the slices) is only used when a slice overflows.
-__device__ __forceinline__ uint32_t block_alloc(uint32_t *lds_cursor, uint32_t slice_base, uint32_t slice_len, uint32_t *overflow_counter,
-                                                uint32_t overflow_base)
-{
-  const unsigned long long mask = __ballot(1);
-  const int lane = (int)(threadIdx.x & 63);
-  const int leader = __ffsll((long long)mask) - 1;
-  const uint32_t need = (uint32_t)__popcll(mask);
-  uint32_t base = 0;
-  if (lane == leader)
-  {
-    const uint32_t c = atomicAdd(lds_cursor, need); // LDS atomic
-    if (c + need <= slice_len)
-      base = slice_base + c;
-    else
-      base = overflow_base + atomicAdd(overflow_counter, need);
-  }
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-
-enum
-{
-  MARCH_EMIT = 0,       // single pass: every candidate goes through the order keys (used when new_map is not default)
-  MARCH_COLLECT = 1,    // candidate lists of contested voxels
-  MARCH_EMIT_KEYED = 2, // pass 1 of the split scatter: the ray tails (fan and near-surface candidates) -> order keys
-  MARCH_EMIT_FREE = 3   // pass 2: the steps before the tails, all free space (tau, +64) -> one byte per voxel, no atomics
-};
-constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_CONTESTED = 4; // CONTESTED: between resolve and resolve_lists only
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
 constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
 constexpr int AZ_BINS = AZ_ONLY_BINS * EL_BINS; // direction bins: azimuth major, elevation minor
 
-// update_tsdf.cu:52-63 for one ray per lane
-__global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
+size_t ray_setup_bytes() { return sizeof(RaySetup); }
+
+__device__ __forceinline__ void raise_error(TsdfCounters *c, uint32_t *status, uint32_t bits)
 {
+  atomicOr(&c->error, bits);
+  __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // sticky, host visible
+}
+
+// ring-buffer storage coordinates of a world voxel (device_map.h:93-101)
+__device__ __forceinline__ void storage_coords(const MapParams &m, int32_t vx, int32_t vy, int32_t vz, int32_t &sx, int32_t &sy, int32_t &sz)
+{
+  sx = ring(vx - m.pos[0] + m.offset[0] + m.size[0], m.size[0]);
+  sy = ring(vy - m.pos[1] + m.offset[1] + m.size[1], m.size[1]);
+  sz = ring(vz - m.pos[2] + m.offset[2] + m.size[2], m.size[2]);
+}
+__device__ __forceinline__ int64_t storage_index(const MapParams &m, int32_t sx, int32_t sy, int32_t sz)
+{
+  const int32_t row = sx * m.size[1] + sy; // size[0] * size[1] < 2^31 (checked by ws_map_create)
+  return (int64_t)row * (int64_t)m.size[2] + sz;
+}
+__device__ __forceinline__ uint32_t tile_of(int32_t nty, int32_t ntz, int32_t sx, int32_t sy, int32_t sz)
+{
+  return (uint32_t)(((sx >> TILE_XB) * nty + (sy >> TILE_YB)) * ntz + (sz >> TILE_ZB));
+}
+__device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
+{
+  return (uint32_t)(((sx & 7) << (TILE_YB + TILE_ZB)) | ((sy & 7) << TILE_ZB) | (sz & 15));
+}
+
+// update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
+__global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
+{
+  __shared__ unsigned long long ub_wave[4];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
-  if (ix >= a.n) return;
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
   r.div_k = 0;
   r.pad = 0;
+  r.kfirst = 0;
+  r.ub = 0;
   const int32_t res = a.res, tau = a.tau, half = res / 2;
-  const int32_t px = a.xyz[3 * (size_t)ix + 0], py = a.xyz[3 * (size_t)ix + 1], pz = a.xyz[3 * (size_t)ix + 2];
-  bool ok;
+  bool ok = false;
+  int32_t px = 0, py = 0, pz = 0;
+  if (ix < a.n)
   {
+    px = a.xyz[3 * (size_t)ix + 0];
+    py = a.xyz[3 * (size_t)ix + 1];
+    pz = a.xyz[3 * (size_t)ix + 2];
     // cu_to_map (cuda/util.h:111-114) + in_bounds_with_buffer_pos (update_tsdf.cu:55)
     const float fr = (float)res;
     const int32_t cx = (int32_t)floorf(__fdiv_rn((float)px, fr));
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
         const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
         if (steps > 65536 || (max_delta_z * 2) / res + 1 > 256 || !small_iv)
         {
-          atomicOr(&a.counters->error, 2u); // outside the range of the order key
+          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the order key
         }
         else
         {
@@ -178,31 +183,82 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(MarchArgs a)
           const int64_t dmax = max(max(llabs((long long)dx), llabs((long long)dy)), llabs((long long)dz));
           const int64_t pmax = max(max(llabs((long long)posx), llabs((long long)posy)), llabs((long long)posz));
           const int64_t ivmax = max(max(llabs(ivx), llabs(ivy)), llabs(ivz));
-          const bool fast = dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
+          // dmax <= distance: beyond ~46 m the reference's int sum of squares wraps and `distance` is not the length
+          // of the ray any more — the walk's "less than one voxel per step" then fails
+          const bool fast = dmax <= distance && dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
                             (2 * max_delta_z + res) * ivmax < (1ll << 31) &&
                             (len_end + 2 * (int64_t)res) * (len_end + 2 * (int64_t)res) < (1ll << 31);
           r.pad = fast ? 1 : 0;
+
+          // Split of the ray.  A candidate is "free space" iff it is on-ray (positive weight) with value == +tau;
+          // ALL candidates of a ray are of that kind while len < min(len_neg, distance - tau - slack): before len_neg
+          // there is no fan, and a voxel centre further than tau from the hit point gives min(dist, tau) == tau.  The
+          // slack covers |centre - proj| (1.5 voxels per axis for the double-width cell of trunc division + the fan
+          // offset).  The bound argues with exact positions: rays whose `int` products wrap (not `fast`) and scans
+          // into a non-default new_map send every step through the order keys.
+          int32_t kfirst = 0;
+          if (fast && !a.all_keyed)
+          {
+            const int32_t keyed_len = min(a.keyed_len_neg, distance - tau - a.keyed_slack);
+            kfirst = keyed_len > 1 ? max(0, (keyed_len - 1) / half - 1) : 0;
+            if (kfirst > (int32_t)steps) kfirst = (int32_t)steps;
+          }
+          r.kfirst = kfirst;
+          // upper bound of the tail's scatter targets: sum over its steps of iter_steps = 2*delta_z/res + 1
+          // (update_tsdf.cu:101-102) = steps + sum_j #{steps with delta_z >= ceil(j*res/2)}
+          unsigned long long ub = (unsigned long long)(steps - kfirst);
+          if ((int64_t)DZ_PER_DISTANCE * len_end >= (1ll << 31))
+          {
+            ub *= 256; // DZ * len wraps in the reference's int: any fan width the key admits
+          }
+          else
+          {
+            const int64_t len_last = 1 + (steps - 1) * half;
+            for (int64_t j = 1; j < 256; ++j)
+            {
+              const int64_t cj = (j * res + 1) / 2;
+              const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
+              if (Lj > len_last) break;
+              const int64_t kj = (Lj - 1 + half - 1) / half;
+              const int64_t first = kj > kfirst ? kj : kfirst;
+              if (first < steps) ub += (unsigned long long)(steps - first);
+            }
+          }
+          r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
     }
   }
-  // azimuth bin of the ray (any monotone function of the direction would do: it only groups rays that lie in
-  // the same vertical plane, whose voxels share z-columns and therefore cache lines); bin AZ_BINS = unused ray
-  uint32_t bin = AZ_BINS;
-  if (r.steps > 0)
+  // direction bin of the ray (any monotone function of the direction would do: it only groups rays that lie in
+  // the same vertical plane, whose voxels share tiles); bin AZ_BINS = unused ray
+  if (ix < a.n)
   {
-    const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
-    int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
-    b = b < 0 ? 0 : (b >= AZ_ONLY_BINS ? AZ_ONLY_BINS - 1 : b);
-    // elevation: sin(el) = dz / distance in [-1, 1]; LiDARs use the middle of that range, so bin tan-like: clamp +-0.5
-    float se = (float)r.dz / (float)r.distance;
-    int e = (int)((se + 0.5f) * (float)EL_BINS);
-    e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
-    bin = (uint32_t)(b * EL_BINS + e);
+    uint32_t bin = AZ_BINS;
+    if (r.steps > 0)
+    {
+      const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
+      int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
+      b = b < 0 ? 0 : (b >= AZ_ONLY_BINS ? AZ_ONLY_BINS - 1 : b);
+      // elevation: sin(el) = dz / distance in [-1, 1]; LiDARs use the middle of that range: clamp +-0.5
+      float se = (float)r.dz / (float)r.distance;
+      int e = (int)((se + 0.5f) * (float)EL_BINS);
+      e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
+      bin = (uint32_t)(b * EL_BINS + e);
+    }
+    r.pad |= (int32_t)(bin << 1);
+    atomicAdd(&a.az_hist[bin], 1u);
+    a.rays[ix] = r;
   }
-  r.pad |= (int32_t)(bin << 1);
-  atomicAdd(&a.az_hist[bin], 1u);
-  a.rays[ix] = r;
+  // capacity hint for the next scan: one 64-bit add per workgroup
+  unsigned long long ub = r.ub;
+  for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
+  if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long t = ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3];
+    if (t) atomicAdd(&a.counters->ub_total, t);
+  }
 }
 
 // exclusive scan of the AZ_BINS + 1 histogram entries (one workgroup), histogram reset for use as cursors
@@ -236,7 +292,7 @@ __global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t
   if (hi == TOTAL && lo < hi) off[TOTAL] = run; // off[AZ_BINS] = rays that contribute, off[AZ_BINS + 1] = all rays
 }
 
-__global__ __launch_bounds__(256) void ray_scatter_kernel(MarchArgs a)
+__global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
 {
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix >= a.n) return;
@@ -244,234 +300,798 @@ __global__ __launch_bounds__(256) void ray_scatter_kernel(MarchArgs a)
   a.ray_order[a.az_off[bin] + atomicAdd(&a.az_hist[bin], 1u)] = ix;
 }
 
-// 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of its ray
-// (CH = ceil(steps/32)), so every lane has the same amount of work whatever the ray length, and a scan
-// of 131 072 rays puts 4 M lanes in flight instead of 131 072 (update_tsdf.cu:67-125 per step).
-template <int MODE, bool HAS_S0>
-__global__ __launch_bounds__(256) void march_kernel(MarchArgs a)
-{
-  __shared__ uint32_t record_cursor;
-  if (MODE == MARCH_COLLECT)
-  {
-    if (threadIdx.x == 0) record_cursor = 0;
-    __syncthreads();
-  }
-  if (MODE == MARCH_COLLECT)
-  {
-    if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-  }
-  // Full-ray passes: 8 rays x 32 lanes per workgroup (see above).  Tail passes (ordered candidates, contested
-  // lists) do scattered 8-byte atomics near the surface: there a wave takes 64 rays of the same azimuth bin
-  // (ray_order) at the same quarter of the tail, so its lanes hit voxels of the same vertical plane — z-neighbours,
-  // i.e. the same cache lines — and one wave-wide atomic touches a handful of lines instead of 64.
-  constexpr bool TAIL = (MODE == MARCH_EMIT_KEYED); // (the collect pass is slower with this mapping: 308 vs 242 us)
-#ifndef WS_FULL_LANES
-#define WS_FULL_LANES 32
-#endif
-#ifndef WS_COLLECT_LANES
-#define WS_COLLECT_LANES 32
-#endif
-  constexpr int FULL_LANES = MODE == MARCH_COLLECT ? WS_COLLECT_LANES : WS_FULL_LANES;
-  constexpr int LANES = TAIL ? 4 : FULL_LANES;
-  constexpr int RAYS_PER_BLOCK = 256 / FULL_LANES;
-  uint32_t ix;
-  int32_t c;
-  if (TAIL)
-  {
-    const uint32_t slot = blockIdx.x * 64u + (threadIdx.x & 63u);
-    if (slot >= a.az_off[AZ_BINS]) return;
-    ix = a.ray_order[slot];
-    c = (int32_t)(threadIdx.x >> 6);
-  }
-  else
-  {
-    ix = blockIdx.x * (uint32_t)RAYS_PER_BLOCK + (threadIdx.x / (uint32_t)FULL_LANES);
-    if (ix >= a.n) return;
-    c = (int32_t)(threadIdx.x % (uint32_t)FULL_LANES);
-  }
-  const RaySetup r = a.rays[ix];
-  if (r.steps == 0) return;
-  const int32_t res = a.res, tau = a.tau;
-  const int32_t half = res / 2;
-  // COLLECT only needs the steps with len = 1 + k*half >= collect_min_len
-  int32_t kbeg = 0;
-  if (MODE == MARCH_COLLECT && a.collect_min_len > 1) kbeg = (a.collect_min_len - 1 + half - 1) / half;
-  // Split scatter: a candidate is "free space" iff it is on-ray (positive weight) with value == +tau; all of a
-  // ray's candidates are of that kind while len < min(len_neg, distance - tau - slack): before len_neg there is
-  // no fan, and a voxel centre further than tau from the hit point gives min(dist, tau) == tau.  The slack covers
-  // |centre - proj| (1.5 voxels per axis for the double-width cell of trunc division + the fan offset).
-  const int32_t keyed_len = min(a.keyed_len_neg, r.distance - tau - a.keyed_slack);
-  const int32_t keyed_first = keyed_len > 1 ? max(0, (keyed_len - 1) / half - 1) : 0;
-  // pass 1 (keyed) owns the steps from keyed_first on, pass 2 (free) the steps before it
-  int32_t kend = r.steps;
-  if (MODE == MARCH_EMIT_KEYED) kbeg = keyed_first;
-  if (MODE == MARCH_EMIT_FREE) kend = min(r.steps, keyed_first);
-  if (kbeg >= kend) return;
-  const int32_t ch = (kend - kbeg + LANES - 1) / LANES;
-  const int32_t k0 = kbeg + c * ch;
-  const int32_t k1 = min(k0 + ch, kend);
-  if (k0 >= k1) return;
+// ---------------------------------------------------------------------------------------------------------
+// ray tails -> records, sorted by tile inside the workgroup
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HT_BITS = 10, HT_SLOTS = 1 << HT_BITS;
+constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DONE = 0xffffffffu;
 
-  const MarchFrame f = make_march_frame(a.scanner_pos, res, tau, a.map);
-  march_steps<MODE == MARCH_EMIT_FREE>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-    const int64_t idx = get_index(a.map, vx, vy, vz);
-    const uint64_t t = order_key(ix, k, step);
-    if (HAS_S0)
+__device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
+{
+  uint32_t h = (tile * 0x9E3779B1u) >> (32 - HT_BITS);
+  for (int p = 0; p < HT_SLOTS; ++p)
+  {
+    const uint32_t cur = keys[h];
+    if (cur == tile) return (int)h;
+    if (cur == HT_EMPTY)
     {
-      // candidates the initial new_map entry would reject can never be accepted later either
-      // (the stored |value| only shrinks and a positive weight freezes the voxel): drop them here
-      const uint32_t s0 = a.new_data[idx];
-      const int32_t a0 = entry_value(s0) < 0 ? -entry_value(s0) : entry_value(s0);
-      if (entry_weight(s0) > 0 || (value < 0 ? -value : value) > a0) return;
+      const uint32_t old = atomicCAS(&keys[h], HT_EMPTY, tile);
+      if (old == HT_EMPTY || old == tile) return (int)h;
     }
-    if (MODE == MARCH_EMIT_FREE)
+    h = (h + 1) & (HT_SLOTS - 1);
+  }
+  return -1;
+}
+__device__ __forceinline__ int ht_find(const uint32_t *keys, uint32_t tile)
+{
+  uint32_t h = (tile * 0x9E3779B1u) >> (32 - HT_BITS);
+  for (int p = 0; p < HT_SLOTS; ++p)
+  {
+    const uint32_t cur = keys[h];
+    if (cur == tile) return (int)h;
+    if (cur == HT_EMPTY) return -1;
+    h = (h + 1) & (HT_SLOTS - 1);
+  }
+  return -1;
+}
+
+// slot of the calling lane in a bump allocation shared by the lanes that reach this point together:
+// one LDS atomic per wave, not per lane
+__device__ __forceinline__ uint32_t lds_append(uint32_t *cursor)
+{
+  const unsigned long long mask = __ballot(1);
+  const int lane = (int)(threadIdx.x & 63);
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
+// quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
+__global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
+{
+  __shared__ uint32_t s_cursor, s_base, s_ub, s_overflow, s_desc_base, s_round_total;
+  __shared__ uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_cur[HT_SLOTS];
+  __shared__ unsigned long long s_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n_sorted = a.az_off[AZ_BINS];
+  const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+  const bool has_ray = slot < n_sorted;
+  uint32_t ix = 0;
+  RaySetup r;
+  r.steps = 0;
+  r.kfirst = 0;
+  r.ub = 0;
+  if (has_ray)
+  {
+    ix = a.ray_order[slot];
+    r = a.rays[ix];
+  }
+  // ---- phase 0: reserve a slice of the raw record buffer for the upper bound of this workgroup's records
+  if (threadIdx.x == 0)
+  {
+    s_cursor = 0;
+    s_overflow = 0;
+  }
+  if (wave == 0)
+  {
+    unsigned long long ub = has_ray ? r.ub : 0u;
+    for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
+    if (lane == 0)
     {
-      // every candidate of these steps is free space: on the ray, further than tau from the hit point
-      if (!(positive && value == tau))
+      uint32_t base = 0xffffffffu;
+      if (ub == 0)
+        base = 0;
+      else if (ub <= a.rec_cap)
       {
-        atomicOr(&a.counters->error, 4u); // impossible by the bound above; never lose a candidate silently
-        return;
+        const uint32_t b = atomicAdd(&a.counters->raw_cursor, (uint32_t)ub);
+        if (b <= a.rec_cap - (uint32_t)ub) base = b;
       }
-      const uint8_t b = a.vstate[idx];
-      if (b & VOX_KEYED)
-      {
-        // the voxel also has ordered candidates (from pass 1): this one takes part in the key order
-        const uint64_t key = make_kpos(t, value);
-        if (key < a.kpos[idx]) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
-      }
-      else if (b == 0)
-      {
-        // free space only (the common case): the result will be (tau, 64) whoever comes first
-        a.vstate[idx] = VOX_TOUCHED;
-        const int64_t tile = idx >> TILE_SHIFT;
-        if (a.dirty[tile] == 0) a.dirty[tile] = 1;
-      }
-      return;
+      if (base == 0xffffffffu) raise_error(a.counters, a.status, ERR_CAPACITY);
+      s_base = base;
+      s_ub = (uint32_t)ub;
     }
-    if (MODE == MARCH_EMIT_KEYED)
+  }
+  __syncthreads();
+  const uint32_t base = s_base;
+  if (base == 0xffffffffu) return; // record buffer exhausted: this workgroup's candidates are lost, the error is sticky
+  const uint32_t ub_total = s_ub;
+
+  // ---- phase 1: march, one record per scatter target
+  if (has_ray && r.steps > 0 && r.kfirst < r.steps)
+  {
+    const int32_t kbeg = r.kfirst, kend = r.steps;
+    const int32_t ch = (kend - kbeg + 3) / 4;
+    const int32_t k0 = kbeg + wave * ch;
+    const int32_t k1 = min(k0 + ch, kend);
+    if (k0 < k1)
     {
-      // Ray tails: three fire-and-forget operations per candidate, nothing the lane has to wait for.  Measured on
-      // MI355X (tools/keyed_exp.sh): reading vstate / the key first to skip redundant stores and atomics makes
-      // every step wait for a scattered load (610 us for the pass); unconditional stores + atomicMin 395 us, of
-      // which the 7.5 M scattered 64-bit atomics are 390 (~19 G atomics/s, the same at workgroup and agent scope)
-      // and the march arithmetic 153.  The tails are spread over the surfaces, so the byte stores do not pile up
-      // on one address the way they would near the sensor (the full-ray EMIT pass below keeps its pre-read).
-      a.vstate[idx] = VOX_KEYED;
-      a.dirty[idx >> TILE_SHIFT] = 1;
-      if (positive)
-        atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)make_kpos(t, value));
-      else
-        atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)make_kneg(t, value));
-      return;
-    }
-    if (MODE == MARCH_EMIT)
-    {
-      // A lane that still reads the "never touched" pattern marks the 64-voxel tile (plain byte store, every
-      // writer stores the same value).  Only the first toucher(s) of a voxel get here, so the stores do not
-      // pile up on one byte the way an unconditional mark does near the sensor (measured: +0.8 ms), and the
-      // atomics stay non-returning (a returning atomicMin stalls the lane for the memory round trip).
-      if (positive)
-      {
-        const uint64_t key = make_kpos(t, value);
-        const uint64_t cur = a.kpos[idx];
-        if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
-        if (key < cur) atomicMin((unsigned long long *)&a.kpos[idx], (unsigned long long)key);
-      }
-      else
-      {
-        const uint64_t key = make_kneg(t, value);
-        const uint64_t cur = a.kneg[idx];
-        if (cur == KEY_INF) a.dirty[idx >> TILE_SHIFT] = 1;
-        if (key < cur) atomicMin((unsigned long long *)&a.kneg[idx], (unsigned long long)key);
-      }
-    }
-    else
-    {
-      // one byte per candidate where the split scatter keeps them (128 voxels per line instead of 16)
-      const bool tagged = a.tag_in_vstate ? a.vstate[idx] == VOX_CONTESTED : a.kpos[idx] == KEY_CONTESTED_TAG;
-      if (tagged)
-      {
-        const uint32_t rec = block_alloc(&record_cursor, blockIdx.x * a.arena_slice, a.arena_slice, &a.counters->records,
-                                         gridDim.x * a.arena_slice);
-        if (rec < a.arena_cap)
+      const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
+      const bool mark = !a.all_keyed;
+      march_steps<false>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+        int32_t sx, sy, sz;
+        storage_coords(a.map, vx, vy, vz, sx, sy, sz);
+        // the free-space pass must know that this voxel takes part in the key order
+        if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
+        const uint32_t p = lds_append(&s_cursor);
+        if (p < ub_total)
         {
-          ContestedRecord cr;
-          cr.key = (t << 17) | (positive ? 0ull : (1ull << 16)) | ((uint32_t)value & 0xffffu);
-          // the list head of a contested voxel lives in the low half of its (now unused) kneg word
-          cr.next = atomicExch(reinterpret_cast<uint32_t *>(&a.kneg[idx]), rec);
-          cr.pad = 0;
-          a.arena[rec] = cr;
+          u32x4 rec;
+          const uint64_t key = record_key(order_key(ix, k, step), value, positive);
+          rec.x = (uint32_t)key;
+          rec.y = (uint32_t)(key >> 32);
+          rec.z = tile_of(a.nty, a.ntz, sx, sy, sz);
+          rec.w = local_of(sx, sy, sz);
+          *reinterpret_cast<u32x4 *>(&a.rec_raw[base + p]) = rec;
         }
         else
         {
-          atomicOr(&a.counters->error, 1u);
+          raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
+        }
+      });
+    }
+  }
+  __syncthreads();
+  const uint32_t total = min(s_cursor, ub_total);
+  if (threadIdx.x == 0) a.tail_stats[blockIdx.x] = total;
+  if (total == 0) return;
+
+  // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
+  // publish one run per tile.  If more tiles are touched than the hash holds, the rest is binned in further rounds.
+  uint32_t round_base = 0;
+  for (;;)
+  {
+    for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
+    {
+      ht_key[i] = HT_EMPTY;
+      ht_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < total; i += 256)
+    {
+      const uint32_t tile = a.rec_raw[base + i].tile;
+      if (tile == REC_DONE) continue;
+      const int s = ht_insert(ht_key, tile);
+      if (s < 0)
+        s_overflow = 1;
+      else
+        atomicAdd(&ht_cnt[s], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the slots: records (low word) and runs (high word) together
+    uint32_t c[4];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      c[j] = ht_cnt[threadIdx.x * 4 + j];
+      mine += (unsigned long long)c[j] + (c[j] ? (1ull << 32) : 0ull);
+    }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const unsigned long long y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long excl = incl - mine;
+    for (int w = 0; w < wave; ++w) excl += s_wave[w];
+    if (threadIdx.x == 255)
+    {
+      const unsigned long long all = excl + mine;
+      const uint32_t runs = (uint32_t)(all >> 32);
+      s_round_total = (uint32_t)all;
+      uint32_t db = 0xffffffffu;
+      if (runs)
+      {
+        const uint32_t b = atomicAdd(&a.counters->desc_cursor, runs);
+        if (b <= a.desc_cap && runs <= a.desc_cap - b) db = b;
+        if (db == 0xffffffffu) raise_error(a.counters, a.status, ERR_CAPACITY);
+      }
+      s_desc_base = db;
+    }
+    __syncthreads();
+    const uint32_t desc_base = s_desc_base;
+    {
+      uint32_t off = (uint32_t)excl, rank = (uint32_t)(excl >> 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        const int s = threadIdx.x * 4 + j;
+        ht_cur[s] = off;
+        if (c[j])
+        {
+          if (desc_base != 0xffffffffu)
+          {
+            RunDesc d;
+            d.tile = ht_key[s];
+            d.count = c[j];
+            d.start = base + round_base + off;
+            d.pad = 0;
+            a.desc[desc_base + rank] = d;
+            atomicAdd(&a.tile_nruns[d.tile], 1u);
+          }
+          rank += 1;
+          off += c[j];
         }
       }
+    }
+    __syncthreads();
+    const bool more = s_overflow != 0;
+    for (uint32_t i = threadIdx.x; i < total; i += 256)
+    {
+      const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + i]);
+      if (rec.z == REC_DONE) continue;
+      const int s = ht_find(ht_key, rec.z);
+      if (s < 0) continue; // next round
+      const uint32_t p = atomicAdd(&ht_cur[s], 1u);
+      *reinterpret_cast<u32x4 *>(&a.rec_sorted[base + round_base + p]) = rec;
+      if (more) a.rec_raw[base + i].tile = REC_DONE;
+    }
+    __syncthreads();
+    if (!more) break;
+    round_base += s_round_total;
+    __syncthreads();
+    if (threadIdx.x == 0) s_overflow = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// free space
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fk_hash(unsigned long long idx, int32_t shift) { return (uint32_t)((idx * 0x9E3779B97F4A7C15ull) >> shift); }
+
+// 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
+// so every lane has the same amount of work whatever the ray length.
+__global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
+{
+  const uint32_t ix = blockIdx.x * 8u + (threadIdx.x >> 5);
+  if (ix >= a.n) return;
+  const int32_t c = (int32_t)(threadIdx.x & 31u);
+  const RaySetup r = a.rays[ix];
+  const int32_t kend = min(r.steps, r.kfirst);
+  if (kend <= 0) return;
+  const int32_t ch = (kend + 31) / 32;
+  const int32_t k0 = c * ch;
+  const int32_t k1 = min(k0 + ch, kend);
+  if (k0 >= k1) return;
+  const int32_t tau = a.tau;
+  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
+  march_steps<true>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+    // every candidate of these steps is free space: on the ray, further than tau from the hit point
+    if (!(positive && value == tau))
+    {
+      raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
+      return;
+    }
+    int32_t sx, sy, sz;
+    storage_coords(a.map, vx, vy, vz, sx, sy, sz);
+    const int64_t idx = storage_index(a.map, sx, sy, sz);
+    const uint8_t b = a.vstate[idx];
+    if (b & VOX_KEYED)
+    {
+      // the voxel also has ordered candidates (from the tails): this one takes part in the key order.  Only the
+      // earliest free-space candidate of a voxel can matter (a later one meets a state that is at least as final).
+      if (!(b & VOX_FREEHIT)) a.vstate[idx] = VOX_KEYED | VOX_FREEHIT;
+      const unsigned long long t = order_key(ix, k, step);
+      uint32_t h = fk_hash((unsigned long long)idx, a.fk_shift);
+      bool done = false;
+      for (int p = 0; p < 128 && !done; ++p)
+      {
+        const unsigned long long cur = a.fk_keys[h];
+        unsigned long long old = cur;
+        if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
+        if (old == KEY_INF || old == (unsigned long long)idx)
+        {
+          atomicMin(&a.fk_vals[h], t);
+          done = true;
+        }
+        h = (h + 1) & a.fk_mask;
+      }
+      if (!done) raise_error(a.counters, a.status, ERR_CAPACITY);
+    }
+    else if (b == 0)
+    {
+      // free space only (the common case): the result will be (tau, 64) whoever comes first
+      a.vstate[idx] = VOX_TOUCHED;
+      const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+      if (a.tile_dirty[tile] == 0) a.tile_dirty[tile] = 1;
     }
   });
 }
 
-struct ResolveArgs
+// ---------------------------------------------------------------------------------------------------------
+// runs per tile -> descriptor ranges, list of touched tiles
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SCAN_TILES_PER_THREAD = 16;
+constexpr int SCAN_TILES_PER_BLOCK = 256 * SCAN_TILES_PER_THREAD;
+uint32_t tile_scan_blocks(int64_t n_tiles) { return (uint32_t)((n_tiles + SCAN_TILES_PER_BLOCK - 1) / SCAN_TILES_PER_BLOCK); }
+
+struct TileScanArgs
 {
-  uint64_t *kpos;
-  uint64_t *kneg;
-  const uint32_t *dirty_list;
-  uint32_t *new_data;
-  int64_t n_vox;
-  int32_t tau;
+  uint32_t *tile_nruns;
+  uint32_t *tile_begin;
+  uint8_t *tile_dirty;
+  TileEntry *tile_list;
+  uint32_t *block_sums; // [blocks][2] (runs, listed), then [blocks][2] their exclusive scan
+  uint32_t n_blocks;
+  int64_t n_tiles;
   TsdfCounters *counters;
-  uint8_t *vstate;
-  int32_t split;                // the scatter used the keyed/free-space split
-  uint32_t *contested_per_wave; // [LIST_GRID_BLOCKS * 4]
-  const ContestedRecord *arena;
-  uint32_t arena_cap;
 };
 
-// touched-tile flags -> list of tile ids (order irrelevant); clears the flags it consumes.
-// Each workgroup owns a contiguous range of tiles: it counts its flags, reserves its part of the list with
-// ONE atomic, then writes the ids (a shared counter hit once per wave was 226 us of this pass).
-constexpr int COMPACT_BLOCKS = 256;
-__global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int64_t n_tiles, uint32_t *list, TsdfCounters *counters)
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
 {
-  __shared__ uint32_t wave_total[4];
-  __shared__ uint32_t block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t per_block = ((n_tiles + COMPACT_BLOCKS - 1) / COMPACT_BLOCKS + 255) & ~255ll;
-  const int64_t lo = (int64_t)blockIdx.x * per_block;
-  const int64_t hi = lo + per_block < n_tiles ? lo + per_block : n_tiles;
-  // pass 1: count
-  uint32_t cnt = 0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) cnt += dirty[i] != 0 ? 1u : 0u;
-  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
-  if (lane == 0) wave_total[wave] = cnt;
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const unsigned long long y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  unsigned long long excl = incl - mine;
+  total = 0;
+  const int n_waves = blockDim.x >> 6;
+  for (int w = 0; w < n_waves; ++w)
+  {
+    if (w < wave) excl += wave_sums[w];
+    total += wave_sums[w];
+  }
+  __syncthreads();
+  return excl;
+}
+
+__global__ __launch_bounds__(256) void tile_count_kernel(TileScanArgs a)
+{
+  __shared__ unsigned long long wave_sums[4];
+  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
+  unsigned long long mine = 0; // runs in the low word, listed tiles in the high word
+  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+  {
+    const int64_t t = t0 + j;
+    if (t >= a.n_tiles) break;
+    const uint32_t nr = a.tile_nruns[t];
+    mine += nr;
+    if (nr || a.tile_dirty[t]) mine += 1ull << 32;
+  }
+  unsigned long long total;
+  block_scan_u64(mine, wave_sums, total);
+  if (threadIdx.x == 0)
+  {
+    a.block_sums[2 * blockIdx.x + 0] = (uint32_t)total;
+    a.block_sums[2 * blockIdx.x + 1] = (uint32_t)(total >> 32);
+  }
+}
+
+__global__ __launch_bounds__(1024) void tile_blockscan_kernel(TileScanArgs a)
+{
+  __shared__ unsigned long long wave_sums[16];
+  uint32_t *out = a.block_sums + 2 * (size_t)a.n_blocks;
+  unsigned long long carry = 0;
+  for (uint32_t b0 = 0; b0 < a.n_blocks; b0 += 1024)
+  {
+    const uint32_t b = b0 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (b < a.n_blocks) mine = (unsigned long long)a.block_sums[2 * b] | ((unsigned long long)a.block_sums[2 * b + 1] << 32);
+    unsigned long long total;
+    const unsigned long long excl = block_scan_u64(mine, wave_sums, total) + carry;
+    if (b < a.n_blocks)
+    {
+      out[2 * b + 0] = (uint32_t)excl;
+      out[2 * b + 1] = (uint32_t)(excl >> 32);
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0)
+  {
+    a.counters->n_desc_sorted = (uint32_t)carry;
+    a.counters->n_listed = (uint32_t)(carry >> 32);
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_list_kernel(TileScanArgs a)
+{
+  __shared__ unsigned long long wave_sums[4];
+  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
+  uint32_t nr[SCAN_TILES_PER_THREAD];
+  uint32_t listed = 0; // bit mask
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+  {
+    const int64_t t = t0 + j;
+    nr[j] = 0;
+    if (t < a.n_tiles)
+    {
+      nr[j] = a.tile_nruns[t];
+      const bool dirty = a.tile_dirty[t] != 0;
+      if (dirty) a.tile_dirty[t] = 0;
+      mine += nr[j];
+      if (nr[j] || dirty)
+      {
+        mine += 1ull << 32;
+        listed |= 1u << j;
+      }
+    }
+  }
+  unsigned long long total;
+  unsigned long long excl = block_scan_u64(mine, wave_sums, total);
+  const uint32_t *boff = a.block_sums + 2 * (size_t)a.n_blocks;
+  uint32_t run_off = (uint32_t)excl + boff[2 * blockIdx.x + 0];
+  uint32_t list_off = (uint32_t)(excl >> 32) + boff[2 * blockIdx.x + 1];
+#pragma unroll
+  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+  {
+    if (!(listed & (1u << j))) continue;
+    const int64_t t = t0 + j;
+    if (nr[j]) a.tile_begin[t] = run_off;
+    TileEntry e;
+    e.tile = (uint32_t)t;
+    e.desc_begin = run_off;
+    e.nruns = nr[j];
+    e.pad = 0;
+    a.tile_list[list_off] = e;
+    run_off += nr[j];
+    list_off += 1;
+  }
+}
+
+// run descriptors grouped by tile: the tile's counter of runs doubles as its placement cursor (and ends at zero)
+__global__ __launch_bounds__(256) void desc_place_kernel(const RunDesc *desc, uint32_t desc_cap, uint32_t *tile_nruns, const uint32_t *tile_begin,
+                                                         uint32_t *sorted_desc, const TsdfCounters *counters)
+{
+  // n_desc_sorted = sum of tile_nruns = descriptors actually written: they are the first n of the array (a reservation
+  // that did not fit wrote nothing and counted nothing, and every later one failed too)
+  uint32_t n = counters->n_desc_sorted;
+  if (n > desc_cap) n = desc_cap;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+  {
+    const RunDesc d = desc[i];
+    const uint32_t old = atomicSub(&tile_nruns[d.tile], 1u);
+    const uint32_t pos = tile_begin[d.tile] + old - 1u;
+    sorted_desc[2 * (size_t)pos + 0] = d.start;
+    sorted_desc[2 * (size_t)pos + 1] = d.count;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// exact resolve of one tile in LDS
+// ---------------------------------------------------------------------------------------------------------
+struct ResolveArgs
+{
+  const TileEntry *tile_list;
+  const uint32_t *sorted_desc;
+  const CandRecord *recs;
+  uint32_t *new_data;
+  uint32_t *avg_data;
+  uint8_t *vstate;
+  const unsigned long long *fk_keys;
+  const unsigned long long *fk_vals;
+  int32_t fk_shift;
+  uint32_t fk_mask;
+  MapParams map;
+  int32_t nty, ntz;
+  int32_t tau, max_weight;
+  uint32_t *resolve_stats; // [grid][2]: contested voxels, free-space hits on keyed voxels
+  TsdfCounters *counters;
+  uint32_t *status;
+};
+
+constexpr int RESOLVE_GRID = 4096;
+constexpr uint32_t M_IDLE = 0xffffffffu, M_NONE = 0x10000u; // mstate: voxel not in the ordered rounds / no earlier negative seen
+
+// kneg: smallest |value| wins, the LATEST candidate among equal |value| (a later equal one replaces the entry)
+__device__ __forceinline__ uint64_t neg_key(uint64_t key, int32_t av, int32_t value)
+{
+  const uint64_t t = key >> 17;
+  return ((uint64_t)av << 45) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
+}
+
+template <class F>
+__device__ __forceinline__ void for_each_record(const TileEntry &te, const uint32_t *sorted_desc, const CandRecord *recs, F &&f)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t r = (uint32_t)wave; r < te.nruns; r += 4)
+  {
+    const uint32_t start = sorted_desc[2 * (size_t)(te.desc_begin + r)];
+    const uint32_t count = sorted_desc[2 * (size_t)(te.desc_begin + r) + 1];
+    for (uint32_t i = (uint32_t)lane; i < count; i += 64)
+    {
+      const u32x4 rec = *reinterpret_cast<const u32x4 *>(&recs[start + i]);
+      const uint64_t key = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
+      const int32_t value = (int32_t)(int16_t)(rec.x & 0xffffu);
+      f(key, value, value < 0 ? -value : value, (int)(rec.w & (TILE_VOXELS - 1)));
+    }
+  }
+}
+
+// One workgroup per touched tile, thread t owns the voxels 4t .. 4t+3 of the tile (one column, four consecutive z).
+// HAS_S0: new_map is not (tau, 0) — the fold starts from the stored entry (a positive weight there freezes the voxel).
+// FUSED: integrate the result straight into avg_map instead of writing new_map (new_map stays (tau, 0)).
+template <bool HAS_S0, bool FUSED>
+__global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
+{
+  __shared__ unsigned long long kpos[TILE_VOXELS]; // earliest eligible positive-weight candidate
+  __shared__ unsigned long long kneg[TILE_VOXELS]; // smallest-|value| (latest) negative-weight candidate
+  __shared__ unsigned long long klast[TILE_VOXELS]; // ordered rounds: the positive candidate that was blocked last
+  __shared__ uint32_t mstate[TILE_VOXELS];          // ordered rounds: min |value| of the negatives before the candidate
+  __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
+  __shared__ uint32_t s_unres[2];
+  const uint32_t n_list = a.counters->n_listed;
+  const int32_t weight_epsilon = a.tau / 10;
+  const uint32_t reset = pack_entry(a.tau, 0);
+  const int col = threadIdx.x >> 2, lx = col >> 3, ly = col & 7, z0 = (threadIdx.x & 3) * 4;
+  const int l0 = threadIdx.x * 4;
+  uint32_t n_contested = 0, n_freehit = 0;
+
+  for (uint32_t e = blockIdx.x; e < n_list; e += gridDim.x)
+  {
+    const TileEntry te = a.tile_list[e];
+    const int32_t tz = (int32_t)(te.tile % (uint32_t)a.ntz);
+    const int32_t ty = (int32_t)((te.tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
+    const int32_t tx = (int32_t)(te.tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
+    const int32_t sx = tx * 8 + lx, sy = ty * 8 + ly, sz = tz * 16 + z0;
+    const bool col_ok = sx < a.map.size[0] && sy < a.map.size[1];
+    int nz = a.map.size[2] - sz;
+    nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
+    const int64_t idx0 = col_ok ? storage_index(a.map, sx, sy, sz) : 0;
+
+    uint32_t entry[4];
+    uint8_t vs[4] = {0, 0, 0, 0};
+    uint32_t s0[4];
+    bool touched[4] = {false, false, false, false};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      entry[j] = reset;
+      s0[j] = reset;
+      if (j < nz)
+      {
+        if (HAS_S0)
+          s0[j] = a.new_data[idx0 + j];
+        else
+          vs[j] = a.vstate[idx0 + j];
+      }
+    }
+
+    if (te.nruns == 0)
+    {
+      // free space only
+      if (!HAS_S0)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (vs[j] & VOX_TOUCHED)
+          {
+            entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
+            touched[j] = true;
+          }
+      }
+    }
+    else
+    {
+      if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        kpos[l0 + j] = KEY_INF;
+        kneg[l0 + j] = KEY_INF;
+        mstate[l0 + j] = M_IDLE;
+        if (HAS_S0)
+        {
+          const int32_t v0 = entry_value(s0[j]);
+          bound0[l0 + j] = (uint16_t)((j < nz && entry_weight(s0[j]) <= 0) ? (v0 < 0 ? -v0 : v0) + 1 : 0);
+        }
+      }
+      __syncthreads();
+      // ---- pass 1: earliest positive, smallest negative per voxel
+      for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+        if (HAS_S0 && av >= (int32_t)bound0[l]) return; // rejected by the stored entry, now and for ever
+        if (key & KEY_NEG_BIT)
+          atomicMin(&kneg[l], (unsigned long long)neg_key(key, av, value));
+        else
+          atomicMin(&kpos[l], (unsigned long long)key);
+      });
+      if (!HAS_S0)
+      {
+        // free-space candidates that hit a keyed voxel: (tau, +weight) at their earliest order key
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (vs[j] & VOX_FREEHIT)
+          {
+            n_freehit += 1;
+            const unsigned long long want = (unsigned long long)(idx0 + j);
+            uint32_t h = fk_hash(want, a.fk_shift);
+            unsigned long long t = KEY_INF;
+            for (int p = 0; p < 128; ++p)
+            {
+              const unsigned long long cur = a.fk_keys[h];
+              if (cur == want)
+              {
+                t = a.fk_vals[h];
+                break;
+              }
+              if (cur == KEY_INF) break;
+              h = (h + 1) & a.fk_mask;
+            }
+            if (t != KEY_INF)
+              atomicMin(&kpos[l0 + j], (unsigned long long)record_key(t, a.tau, true));
+            else
+              raise_error(a.counters, a.status, ERR_INTERNAL);
+          }
+      }
+      __syncthreads();
+
+      // ---- decide every voxel whose earliest positive candidate cannot have been blocked
+      uint32_t unres = 0; // bit j: voxel j is in the ordered rounds
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+      {
+        if (j >= nz) continue;
+        const unsigned long long P = kpos[l0 + j], N = kneg[l0 + j];
+        if (P == KEY_INF && N == KEY_INF)
+        {
+          if (!HAS_S0 && (vs[j] & VOX_TOUCHED))
+          {
+            entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
+            touched[j] = true;
+          }
+          continue;
+        }
+        touched[j] = true;
+        if (P == KEY_INF)
+        {
+          const int32_t an = (int32_t)(N >> 45);
+          const int32_t v = (N & 1ull) ? -an : an;
+          entry[j] = pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon));
+          continue;
+        }
+        const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+        const int32_t ap = vp < 0 ? -vp : vp;
+        if (N == KEY_INF || ap <= (int32_t)(N >> 45))
+        {
+          entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon));
+          continue;
+        }
+        // a negative-weight candidate with a smaller |value| MAY have come first and blocked it: ordered rounds
+        unres |= 1u << j;
+        mstate[l0 + j] = M_NONE;
+        n_contested += 1;
+      }
+      if (unres) atomicAdd(&s_unres[0], 1u);
+      __syncthreads();
+
+      // ---- ordered rounds: winner = first positive p with |v_p| <= min |v_n| over the negatives before p
+      int phase = 0;
+      while (s_unres[phase] != 0)
+      {
+        // A: min |value| of the negatives that precede the current candidate
+        for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+          if (!(key & KEY_NEG_BIT)) return;
+          const uint32_t m = mstate[l];
+          if (m == M_IDLE || (uint32_t)av >= m) return;
+          if (HAS_S0 && av >= (int32_t)bound0[l]) return;
+          if (key < kpos[l]) atomicMin(&mstate[l], (uint32_t)av);
+        });
+        __syncthreads();
+        if (threadIdx.x == 0) s_unres[phase ^ 1] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          if (!(unres & (1u << j))) continue;
+          const unsigned long long P = kpos[l0 + j];
+          const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+          const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
+          if (ap <= mstate[l0 + j])
+          {
+            entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon));
+            unres &= ~(1u << j);
+            mstate[l0 + j] = M_IDLE;
+          }
+          else
+          {
+            // blocked: every later positive candidate needs |value| <= that minimum
+            klast[l0 + j] = P;
+            kpos[l0 + j] = KEY_INF;
+          }
+        }
+        __syncthreads();
+        // B: the next positive candidate that can still be accepted
+        for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+          if (key & KEY_NEG_BIT) return;
+          const uint32_t m = mstate[l];
+          if (m == M_IDLE || (uint32_t)av > m) return;
+          if (key > klast[l]) atomicMin(&kpos[l], (unsigned long long)key);
+        });
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          if (!(unres & (1u << j))) continue;
+          if (kpos[l0 + j] == KEY_INF)
+          {
+            // no positive candidate is ever accepted: the negatives fold to the smallest |value|, latest on ties
+            const unsigned long long N = kneg[l0 + j];
+            const int32_t an = (int32_t)(N >> 45);
+            const int32_t v = (N & 1ull) ? -an : an;
+            entry[j] = pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon));
+            unres &= ~(1u << j);
+            mstate[l0 + j] = M_IDLE;
+          }
+          else
+          {
+            mstate[l0 + j] = M_NONE;
+          }
+        }
+        if (unres) atomicAdd(&s_unres[phase ^ 1], 1u);
+        __syncthreads();
+        phase ^= 1;
+      }
+      __syncthreads(); // LDS is reused by the next tile
+    }
+
+    // ---- write-back
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      if (j >= nz) continue;
+      if (!HAS_S0 && vs[j]) a.vstate[idx0 + j] = 0;
+      if (!touched[j]) continue;
+      if (FUSED)
+      {
+        const uint32_t existing = a.avg_data[idx0 + j];
+        const uint32_t updated = integrate_entry(existing, entry[j], a.max_weight);
+        if (updated != existing) a.avg_data[idx0 + j] = updated;
+      }
+      else
+      {
+        a.new_data[idx0 + j] = entry[j];
+      }
+    }
+  }
+  // statistics: one slot per workgroup, no shared counter
+  for (int d = 32; d > 0; d >>= 1)
+  {
+    n_contested += __shfl_down(n_contested, d, 64);
+    n_freehit += __shfl_down(n_freehit, d, 64);
+  }
+  __shared__ uint32_t s_stat[8];
+  if ((threadIdx.x & 63) == 0)
+  {
+    s_stat[(threadIdx.x >> 6) * 2 + 0] = n_contested;
+    s_stat[(threadIdx.x >> 6) * 2 + 1] = n_freehit;
+  }
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    const uint32_t total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
-    block_base = total ? atomicAdd(&counters->dirty_tiles, total) : 0u;
-  }
-  __syncthreads();
-  // pass 2: write ids; running offset = block_base + flags seen so far in this workgroup
-  uint32_t running = block_base;
-  for (int64_t i0 = lo; i0 < hi; i0 += 256)
-  {
-    const int64_t i = i0 + threadIdx.x;
-    const bool flag = i < hi && dirty[i] != 0;
-    const unsigned long long mask = __ballot(flag);
-    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t before = 0;
-    for (int w = 0; w < wave; ++w) before += wave_total[w];
-    const uint32_t chunk_total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
-    if (flag)
-    {
-      list[running + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-      dirty[i] = 0;
-    }
-    running += chunk_total;
-    __syncthreads();
+    a.resolve_stats[2 * blockIdx.x + 0] = s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];
+    a.resolve_stats[2 * blockIdx.x + 1] = s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// integrate
+// ---------------------------------------------------------------------------------------------------------
+struct IntegrateArgs
+{
+  uint32_t *new_data;
+  uint32_t *avg_data;
+  const TileEntry *tile_list;
+  MapParams map;
+  int32_t nty, ntz;
+  int64_t n_vox;
+  int32_t max_weight;
+  int32_t tau;
+  TsdfCounters *counters;
+};
 
 #ifndef DENSE_GRID
 #define DENSE_GRID 3072
@@ -479,227 +1099,81 @@ __global__ __launch_bounds__(256) void compact_dirty_kernel(uint8_t *dirty, int6
 #ifndef DENSE_UNROLL
 #define DENSE_UNROLL 8
 #endif
-constexpr int LIST_GRID_BLOCKS = 2048; // persistent grid over the touched-tile list: 8192 waves
-#ifndef SPARSE_UNROLL
-#define SPARSE_UNROLL 4
-#endif
+constexpr int SPARSE_GRID = 4096;
 
-// One wave per touched 64-voxel tile (one lane per voxel), waves stride over the tile list.
-__global__ __launch_bounds__(256) void resolve_kernel(ResolveArgs a)
-{
-  const int lane = threadIdx.x & 63;
-  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int32_t weight_epsilon = a.tau / 10;
-  int n_contested = 0;
-  for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_dirty; i += gridDim.x * 4u)
-  {
-    const int64_t idx = ((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane;
-    if (idx >= a.n_vox) continue;
-    if (a.split)
-    {
-      // split scatter: one byte says whether the voxel was touched at all and whether it has order keys
-      const uint8_t b = a.vstate[idx];
-      if (b == 0) continue;
-      a.vstate[idx] = 0;
-      if (!(b & VOX_KEYED))
-      {
-        a.new_data[idx] = pack_entry(a.tau, WEIGHT_RESOLUTION); // free-space candidates only
-        continue;
-      }
-    }
-    const uint64_t kp = a.kpos[idx], kn = a.kneg[idx];
-    if (kp == KEY_INF && kn == KEY_INF) continue; // untouched voxel: new_map keeps its entry
-    bool decided = true;
-    int32_t value = 0;
-    bool positive = false;
-    if (kp != KEY_INF)
-    {
-      if (kp == KEY_CONTESTED_TAG) continue; // already handed to the ordered fallback
-      value = (int32_t)(int16_t)(kp & 0xffffu);
-      positive = true;
-      if (kn != KEY_INF)
-      {
-        const int32_t ap = value < 0 ? -value : value;
-        const int32_t an = (int32_t)(kn >> 45);
-        // a negative candidate with a smaller |value| MAY have come first and blocked it: ordered fallback
-        if (ap > an) decided = false;
-      }
-    }
-    else
-    {
-      const int32_t an = (int32_t)(kn >> 45);
-      value = (kn & 1ull) ? -an : an;
-    }
-    if (decided)
-    {
-      const int32_t w = tsdf_weight(value, a.tau, weight_epsilon);
-      a.new_data[idx] = pack_entry(value, positive ? w : -w);
-      a.kpos[idx] = KEY_INF;
-      if (kn != KEY_INF) a.kneg[idx] = KEY_INF;
-    }
-    else
-    {
-      // contested: tag the voxel; its kneg word becomes the (empty) head of the candidate list
-      a.kpos[idx] = KEY_CONTESTED_TAG;
-      a.kneg[idx] = 0xffffffffull;
-      if (a.split) a.vstate[idx] = VOX_CONTESTED;
-      n_contested += 1;
-    }
-  }
-  // no shared counter (even one atomic per wave on a single address costs ~100 us here): a wave that saw a
-  // contested voxel raises the flag with a plain store, the exact count is kept per wave for the statistics
-  for (int d = 32; d > 0; d >>= 1) n_contested += __shfl_down(n_contested, d, 64);
-  if (lane == 0)
-  {
-    a.contested_per_wave[blockIdx.x * 4u + (threadIdx.x >> 6)] = (uint32_t)n_contested;
-    if (n_contested) a.counters->contested = 1;
-  }
-}
-
-// Ordered fallback: walk the touched tiles again, one lane per voxel; a lane whose voxel is tagged folds
-// that voxel's candidate list in ascending key order with the accept rule of atomic_tsdf_min
-// (cuda/util.h:70-102): accept iff stored weight <= 0 and |new| <= |stored|.
-template <bool HAS_S0>
-__global__ __launch_bounds__(256) void resolve_lists_kernel(ResolveArgs a)
-{
-  if (__hip_atomic_load(&a.counters->contested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int32_t weight_epsilon = a.tau / 10;
-  constexpr int U = SPARSE_UNROLL; // tiles whose tags are fetched together (most tiles have no contested voxel)
-  const uint32_t stride = gridDim.x * 4u;
-  for (uint32_t i0 = blockIdx.x * 4u + (threadIdx.x >> 6); i0 < n_dirty; i0 += stride * U)
-  {
-    int64_t idxs[U];
-    bool tagged[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      const uint32_t i = i0 + (uint32_t)u * stride;
-      const bool ok = i < n_dirty;
-      idxs[u] = ok ? (((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane) : a.n_vox;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      tagged[u] = false;
-      if (idxs[u] < a.n_vox) tagged[u] = a.split ? (a.vstate[idxs[u]] == VOX_CONTESTED) : (a.kpos[idxs[u]] == KEY_CONTESTED_TAG);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-    if (!tagged[u]) continue;
-    const int64_t idx = idxs[u];
-    if (a.split) a.vstate[idx] = 0;
-    const uint32_t head = (uint32_t)(a.kneg[idx] & 0xffffffffull);
-    const uint32_t state = HAS_S0 ? a.new_data[idx] : pack_entry(a.tau, 0);
-    int32_t sv = entry_value(state), sw = entry_weight(state);
-    int32_t sa = sv < 0 ? -sv : sv;
-    uint64_t last = 0;
-    bool first = true;
-    while (sw <= 0)
-    {
-      // next record in key order (lists are short: a handful of rays reach a far voxel)
-      uint64_t best = KEY_INF;
-      for (uint32_t r = head; r != 0xffffffffu && r < a.arena_cap; r = a.arena[r].next)
-      {
-        const uint64_t k = a.arena[r].key;
-        if ((first || k > last) && k < best) best = k;
-      }
-      if (best == KEY_INF) break;
-      first = false;
-      last = best;
-      const int32_t v = (int32_t)(int16_t)(best & 0xffffu);
-      const int32_t av = v < 0 ? -v : v;
-      if (av <= sa)
-      {
-        const int32_t w = tsdf_weight(v, a.tau, weight_epsilon);
-        sv = v;
-        sa = av;
-        sw = (best & (1ull << 16)) ? -w : w;
-      }
-    }
-    a.new_data[idx] = pack_entry(sv, sw);
-    a.kpos[idx] = KEY_INF;
-    a.kneg[idx] = KEY_INF;
-    }
-  }
-}
-
-struct IntegrateArgs
-{
-  uint32_t *new_data;
-  uint32_t *avg_data;
-  const uint32_t *dirty_list;
-  int64_t n_vox;
-  int32_t max_weight;
-  int32_t tau;
-  TsdfCounters *counters;
-};
-
-// cu_avg_tsdf_krnl (update_tsdf.cu:13-43) over the touched tiles only: one wave per tile.
+// cu_avg_tsdf_krnl (update_tsdf.cu:13-43) over the touched tiles only: one workgroup per tile, the voxel mapping of
+// tile_resolve_kernel (64-byte runs along z).
 __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 {
-  // One tile per wave and trip was latency bound (a chain of three dependent loads per 256 B: tile id, new, avg):
-  // every wave works on SPARSE_UNROLL tiles at a time, all their loads are in flight before the first is used.
-  constexpr int U = SPARSE_UNROLL;
-  const int lane = threadIdx.x & 63;
-  const uint32_t n_dirty = __hip_atomic_load(&a.counters->dirty_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t n_list = a.counters->n_listed;
   const uint32_t reset = pack_entry(a.tau, 0);
-  const uint32_t stride = gridDim.x * 4u;
-  for (uint32_t i0 = blockIdx.x * 4u + (threadIdx.x >> 6); i0 < n_dirty; i0 += stride * U)
+  const int col = threadIdx.x >> 2, lx = col >> 3, ly = col & 7, z0 = (threadIdx.x & 3) * 4;
+  for (uint32_t e = blockIdx.x; e < n_list; e += gridDim.x)
   {
-    int64_t idx[U];
-    bool ok[U];
+    const uint32_t tile = a.tile_list[e].tile;
+    const int32_t tz = (int32_t)(tile % (uint32_t)a.ntz);
+    const int32_t ty = (int32_t)((tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
+    const int32_t tx = (int32_t)(tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
+    const int32_t sx = tx * 8 + lx, sy = ty * 8 + ly, sz = tz * 16 + z0;
+    if (sx >= a.map.size[0] || sy >= a.map.size[1]) continue;
+    int nz = a.map.size[2] - sz;
+    nz = nz > 4 ? 4 : nz;
+    const int64_t idx0 = storage_index(a.map, sx, sy, sz);
+    uint32_t fresh[4], existing[4];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int j = 0; j < 4; ++j) fresh[j] = j < nz ? a.new_data[idx0 + j] : reset;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) existing[j] = fresh[j] != reset ? a.avg_data[idx0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
     {
-      const uint32_t i = i0 + (uint32_t)u * stride;
-      ok[u] = i < n_dirty;
-      idx[u] = ok[u] ? (((int64_t)a.dirty_list[i] << TILE_SHIFT) + lane) : 0;
-      ok[u] = ok[u] && idx[u] < a.n_vox;
-    }
-    uint32_t fresh[U], existing[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) fresh[u] = ok[u] ? a.new_data[idx[u]] : reset;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      ok[u] = ok[u] && fresh[u] != reset;
-      existing[u] = ok[u] ? a.avg_data[idx[u]] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      if (!ok[u]) continue;
-      const uint32_t updated = integrate_entry(existing[u], fresh[u], a.max_weight);
-      if (updated != existing[u]) a.avg_data[idx[u]] = updated;
-      a.new_data[idx[u]] = reset;
+      if (fresh[j] == reset) continue;
+      const uint32_t updated = integrate_entry(existing[j], fresh[j], a.max_weight);
+      if (updated != existing[j]) a.avg_data[idx0 + j] = updated;
+      a.new_data[idx0 + j] = reset;
     }
   }
 }
 
-// bookkeeping after an integrate pass: remember how many tiles were streamed, restart the list
-__global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, const uint32_t *contested_per_wave, int n_waves)
+// bookkeeping after an update: statistics of the scan (no shared counters in the hot kernels: per-workgroup slots)
+__global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, const uint32_t *tail_stats, uint32_t n_tail, const uint32_t *resolve_stats,
+                                                            uint32_t n_resolve, uint32_t *status)
 {
-  __shared__ uint32_t part[4];
-  uint32_t s = 0;
-  for (int i = threadIdx.x; i < n_waves; i += 256) s += contested_per_wave[i];
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __shared__ uint32_t part[12];
+  uint32_t rec = 0, con = 0, fh = 0;
+  for (uint32_t i = threadIdx.x; i < n_tail; i += 256) rec += tail_stats[i];
+  for (uint32_t i = threadIdx.x; i < n_resolve; i += 256)
+  {
+    con += resolve_stats[2 * i + 0];
+    fh += resolve_stats[2 * i + 1];
+  }
+  for (int d = 32; d > 0; d >>= 1)
+  {
+    rec += __shfl_down(rec, d, 64);
+    con += __shfl_down(con, d, 64);
+    fh += __shfl_down(fh, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    part[(threadIdx.x >> 6) * 3 + 0] = rec;
+    part[(threadIdx.x >> 6) * 3 + 1] = con;
+    part[(threadIdx.x >> 6) * 3 + 2] = fh;
+  }
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    c->last_contested = part[0] + part[1] + part[2] + part[3];
-    c->last_dirty_tiles = c->dirty_tiles;
-    c->dirty_tiles = 0;
+    c->last_records = part[0] + part[3] + part[6] + part[9];
+    c->last_contested = part[1] + part[4] + part[7] + part[10];
+    c->last_free_keyed = part[2] + part[5] + part[8] + part[11];
+    c->last_listed = c->n_listed;
+    c->last_runs = c->desc_cursor;
+    // capacity hint for the host (read without synchronisation before the next scan)
+    *reinterpret_cast<volatile unsigned long long *>(status + 2) = c->ub_total;
   }
 }
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
 // (read new + existing, write existing + reset new), 4 voxels per lane as 128-bit accesses.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(256) void integrate_dense_kernel(IntegrateArgs a)
 {
   const int64_t n4 = a.n_vox >> 2;
@@ -753,11 +1227,6 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *dst, uint32_t v
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
 }
-__global__ __launch_bounds__(256) void fill_u64_kernel(uint64_t *dst, uint64_t v, int64_t n)
-{
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
-}
 
 // ---- slabs of the ring buffer <-> a dense box (device side of the map shift) ----
 // box-local order: x major, z fastest, like the maps; lo/ext in world voxel coordinates, box inside the window
@@ -780,18 +1249,18 @@ __global__ __launch_bounds__(256) void box_copy_kernel(uint32_t *map_data, MapPa
   }
 }
 
-int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack)
+int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t s)
 {
   const int64_t n = (int64_t)ext[0] * ext[1] * ext[2];
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   if (pack)
-    hipLaunchKernelGGL((box_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, m->ctx->stream, m->data[which], m->par[which], lo[0],
-                       lo[1], lo[2], ext[0], ext[1], ext[2], box_dev);
+    hipLaunchKernelGGL((box_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2],
+                       ext[0], ext[1], ext[2], box_dev);
   else
-    hipLaunchKernelGGL((box_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, m->ctx->stream, m->data[which], m->par[which], lo[0],
-                       lo[1], lo[2], ext[0], ext[1], ext[2], box_dev);
+    hipLaunchKernelGGL((box_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2],
+                       ext[0], ext[1], ext[2], box_dev);
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
@@ -805,159 +1274,139 @@ int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
-int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n)
-{
-  if (n <= 0) return WS_OK;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dst, value, n);
-  WS_HIP(hipGetLastError());
-  return WS_OK;
-}
 
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
-  // per-scatter counters (the touched-tile list survives until the integrate pass consumes it)
-  WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, dirty_tiles), s));
+  WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, last_records), s));
+  m->fused_done = false;
+  m->tail_blocks = 0;
   if (n == 0) return WS_OK;
 
-  MarchArgs ma;
-  ma.xyz = xyz_dev;
-  ma.n = (uint32_t)n;
+  const bool s0 = !m->new_is_default;
+  ScatterArgs sa;
+  sa.xyz = xyz_dev;
+  sa.n = (uint32_t)n;
   for (int k = 0; k < 3; ++k)
   {
-    ma.scanner_pos[k] = scanner_pos[k];
-    ma.up[k] = up[k];
+    sa.scanner_pos[k] = scanner_pos[k];
+    sa.up[k] = up[k];
   }
-  ma.map = m->par[WS_MAP_NEW];
-  ma.tau = m->tau;
-  ma.res = m->res;
-  ma.resdiv = make_fastdiv(m->res);
-  ma.rays = (RaySetup *)m->rays;
-  ma.kpos = m->kpos;
-  ma.kneg = m->kneg;
-  ma.dirty = m->dirty;
-  ma.vstate = m->vstate;
-  ma.az_hist = m->az_hist;
-  ma.az_off = m->az_off;
-  ma.ray_order = m->ray_order;
-  ma.new_data = m->data[WS_MAP_NEW];
-  ma.counters = m->counters;
-  ma.arena = m->arena;
-  ma.arena_cap = m->arena_cap;
-  {
-    // half of the arena is split evenly between the workgroups, the other half is the shared overflow area
-    const uint32_t blocks = (uint32_t)((n + 256 / WS_COLLECT_LANES - 1) / (256 / WS_COLLECT_LANES)); // workgroups of the collect pass
-    ma.arena_slice = (m->arena_cap / 2) / (blocks ? blocks : 1);
-  }
+  sa.map = m->par[WS_MAP_NEW];
+  sa.tau = m->tau;
+  sa.res = m->res;
+  sa.ntx = m->ntx;
+  sa.nty = m->nty;
+  sa.ntz = m->ntz;
+  sa.all_keyed = s0 ? 1 : 0;
   {
     // Negative-weight (off-ray) candidates only exist where iter_steps >= 2, i.e. delta_z*2 >= res
-    // (update_tsdf.cu:101-102): len >= ceil(ceil(res/2) * 32768 / 100).  A contested voxel holds such a
-    // candidate, and every other candidate of the same voxel has a ray length within one voxel
-    // diagonal + fan of it, so the collect pass can start 4 voxels below that length.
+    // (update_tsdf.cu:101-102): len >= ceil(ceil(res/2) * 32768 / 100).
     const int64_t dz_min = (m->res + 1) / 2;
     const int64_t len_neg = (dz_min * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
-    const int64_t lo = len_neg - 4 * (int64_t)m->res - 2 * dz_min;
-    ma.collect_min_len = lo > 1 ? (int32_t)(lo > INT32_MAX ? INT32_MAX : lo) : 1;
-    ma.keyed_len_neg = (int32_t)(len_neg > INT32_MAX ? INT32_MAX : len_neg);
-    ma.keyed_slack = (int32_t)(2 * (dz_min + 1) + 3 * (int64_t)m->res + 4);
+    sa.keyed_len_neg = (int32_t)(len_neg > INT32_MAX ? INT32_MAX : len_neg);
+    sa.keyed_slack = (int32_t)(2 * (dz_min + 1) + 3 * (int64_t)m->res + 4);
   }
-
-  ResolveArgs ra;
-  ra.kpos = m->kpos;
-  ra.kneg = m->kneg;
-  ra.dirty_list = m->dirty_list;
-  ra.new_data = m->data[WS_MAP_NEW];
-  ra.n_vox = m->n_vox;
-  ra.tau = m->tau;
-  ra.counters = m->counters;
-  ra.vstate = m->vstate;
-  ra.split = (m->scatter_mode != WS_SCATTER_TILES && m->new_is_default) ? 1 : 0;
-  ma.tag_in_vstate = ra.split;
-  ra.contested_per_wave = m->contested_per_wave;
-  ra.arena = m->arena;
-  ra.arena_cap = m->arena_cap;
+  sa.rays = (RaySetup *)m->rays;
+  sa.az_hist = m->az_hist;
+  sa.az_off = m->az_off;
+  sa.ray_order = m->ray_order;
+  sa.vstate = m->vstate;
+  sa.tile_dirty = m->tile_dirty;
+  sa.tile_nruns = m->tile_nruns;
+  sa.rec_raw = m->rec_raw;
+  sa.rec_sorted = m->rec_sorted;
+  sa.rec_cap = m->rec_cap;
+  sa.desc = m->desc;
+  sa.desc_cap = m->desc_cap;
+  sa.fk_keys = m->fk_keys;
+  sa.fk_vals = m->fk_vals;
+  {
+    int l = 0;
+    while ((1u << l) < m->fk_slots) ++l;
+    sa.fk_shift = 64 - l;
+    sa.fk_mask = m->fk_slots - 1;
+  }
+  sa.tail_stats = m->block_stats;
+  sa.counters = m->counters;
+  sa.status = m->status_dev;
 
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
-  constexpr size_t rays_per_block = 256 / WS_FULL_LANES;
-  const dim3 grid_rays((unsigned)((n + rays_per_block - 1) / rays_per_block));
   const dim3 grid_tail((unsigned)((n + 63) / 64));
-  constexpr size_t rays_per_collect_block = 256 / WS_COLLECT_LANES;
-  const dim3 grid_collect((unsigned)((n + rays_per_collect_block - 1) / rays_per_collect_block));
-  const dim3 grid_list(LIST_GRID_BLOCKS);
-  const bool s0 = !m->new_is_default;
+  const dim3 grid_free((unsigned)((n + 7) / 8));
+  m->tail_blocks = grid_tail.x;
 
-  // LDS-tile path: needs new_map == (tau, 0) (its local resolve starts every voxel from that state)
-  const bool tiles = m->scatter_mode == WS_SCATTER_TILES && !s0;
+  prof_begin(ctx, WS_K_SETUP);
   WS_HIP(hipMemsetAsync(m->az_hist, 0, (AZ_BINS + 1) * sizeof(uint32_t), s)); // the scatter pass leaves its cursors there
-  hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, ma);
+  WS_HIP(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
+  if (!s0)
+  {
+    WS_HIP(hipMemsetAsync(m->fk_keys, 0xff, (size_t)m->fk_slots * sizeof(unsigned long long), s));
+    WS_HIP(hipMemsetAsync(m->fk_vals, 0xff, (size_t)m->fk_slots * sizeof(unsigned long long), s));
+  }
+  hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
   hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, s, m->az_hist, m->az_off);
-  hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, ma);
-  if (tiles)
+  hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
+  prof_end(ctx, WS_K_SETUP);
+
+  prof_begin(ctx, WS_K_MARCH_TAILS);
+  hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);
+  prof_end(ctx, WS_K_MARCH_TAILS);
+  if (!s0)
   {
-    TileArgs ta;
-    ta.rays = ma.rays;
-    ta.n = ma.n;
-    ta.frame = make_march_frame(ma.scanner_pos, m->res, m->tau, ma.map);
-    ta.grid = make_tile_grid(ma.map);
-    ta.n_tiles = m->n_tiles3d;
-    ta.tile_count = m->tile_count;
-    ta.tile_offset = m->tile_offset;
-    ta.tile_cursor = m->tile_cursor;
-    ta.records = m->tile_records;
-    ta.records_cap = m->tile_records_cap;
-    ta.work = (uint4 *)m->tile_work;
-    ta.work_cap = m->tile_work_cap;
-    ta.tile_state = (TileState *)m->tile_state;
-    ta.kpos = m->kpos;
-    ta.kneg = m->kneg;
-    ta.dirty = m->dirty;
-    ta.new_data = m->data[WS_MAP_NEW];
-    ta.avg_data = m->data[WS_MAP_AVG];
-    ta.max_weight = m->max_weight;
-    ta.counters = m->counters;
-    WS_HIP(hipMemsetAsync(m->tile_state, 0, sizeof(TileState), s));
-    int rc = launch_tile_path(m, ta, n, fused);
-    if (rc != WS_OK) return rc;
-  }
-  else
-  {
-    prof_begin(ctx, WS_K_MARCH_EMIT);
-    if (s0)
-    {
-      hipLaunchKernelGGL((march_kernel<MARCH_EMIT, true>), grid_rays, block, 0, s, ma);
-    }
-    else
-    {
-      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_KEYED, false>), grid_tail, block, 0, s, ma);
-      hipLaunchKernelGGL((march_kernel<MARCH_EMIT_FREE, false>), grid_rays, block, 0, s, ma);
-    }
-    prof_end(ctx, WS_K_MARCH_EMIT);
+    prof_begin(ctx, WS_K_MARCH_FREE);
+    hipLaunchKernelGGL(march_free_kernel, grid_free, block, 0, s, sa);
+    prof_end(ctx, WS_K_MARCH_FREE);
   }
 
-  prof_begin(ctx, WS_K_RESOLVE);
-  {
-    hipLaunchKernelGGL(compact_dirty_kernel, dim3(COMPACT_BLOCKS), block, 0, s, m->dirty, m->n_tiles, m->dirty_list, m->counters);
-  }
-  hipLaunchKernelGGL(resolve_kernel, grid_list, block, 0, s, ra);
-  prof_end(ctx, WS_K_RESOLVE);
+  prof_begin(ctx, WS_K_TILE_BIN);
+  TileScanArgs ta;
+  ta.tile_nruns = m->tile_nruns;
+  ta.tile_begin = m->tile_begin;
+  ta.tile_dirty = m->tile_dirty;
+  ta.tile_list = m->tile_list;
+  ta.block_sums = m->block_sums;
+  ta.n_blocks = m->scan_blocks;
+  ta.n_tiles = m->n_tiles;
+  ta.counters = m->counters;
+  hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+  hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
+  hipLaunchKernelGGL(tile_list_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+  hipLaunchKernelGGL(desc_place_kernel, dim3(256), block, 0, s, (const RunDesc *)m->desc, m->desc_cap, m->tile_nruns, (const uint32_t *)m->tile_begin,
+                     m->sorted_desc, (const TsdfCounters *)m->counters);
+  prof_end(ctx, WS_K_TILE_BIN);
 
-  prof_begin(ctx, WS_K_MARCH_COLLECT);
+  ResolveArgs ra;
+  ra.tile_list = m->tile_list;
+  ra.sorted_desc = m->sorted_desc;
+  ra.recs = m->rec_sorted;
+  ra.new_data = m->data[WS_MAP_NEW];
+  ra.avg_data = m->data[WS_MAP_AVG];
+  ra.vstate = m->vstate;
+  ra.fk_keys = m->fk_keys;
+  ra.fk_vals = m->fk_vals;
+  ra.fk_shift = sa.fk_shift;
+  ra.fk_mask = sa.fk_mask;
+  ra.map = m->par[WS_MAP_NEW];
+  ra.nty = m->nty;
+  ra.ntz = m->ntz;
+  ra.tau = m->tau;
+  ra.max_weight = m->max_weight;
+  ra.resolve_stats = m->block_stats + WS_TAIL_STATS;
+  ra.counters = m->counters;
+  ra.status = m->status_dev;
+  prof_begin(ctx, WS_K_TILE_RESOLVE);
+  const bool fuse = fused && !s0;
   if (s0)
-    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, true>), grid_collect, block, 0, s, ma);
+    hipLaunchKernelGGL((tile_resolve_kernel<true, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
+  else if (fuse)
+    hipLaunchKernelGGL((tile_resolve_kernel<false, true>), dim3(RESOLVE_GRID), block, 0, s, ra);
   else
-    hipLaunchKernelGGL((march_kernel<MARCH_COLLECT, false>), grid_collect, block, 0, s, ma);
-  prof_end(ctx, WS_K_MARCH_COLLECT);
-
-  prof_begin(ctx, WS_K_RESOLVE_LISTS);
-  if (s0)
-    hipLaunchKernelGGL((resolve_lists_kernel<true>), grid_list, block, 0, s, ra);
-  else
-    hipLaunchKernelGGL((resolve_lists_kernel<false>), grid_list, block, 0, s, ra);
-  prof_end(ctx, WS_K_RESOLVE_LISTS);
+    hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
+  prof_end(ctx, WS_K_TILE_RESOLVE);
+  m->fused_done = fuse;
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
@@ -969,29 +1418,37 @@ int launch_tsdf_integrate(ws_map *m)
   IntegrateArgs ia;
   ia.new_data = m->data[WS_MAP_NEW];
   ia.avg_data = m->data[WS_MAP_AVG];
-  ia.dirty_list = m->dirty_list;
+  ia.tile_list = m->tile_list;
+  ia.map = m->par[WS_MAP_NEW];
+  ia.nty = m->nty;
+  ia.ntz = m->ntz;
   ia.n_vox = m->n_vox;
   ia.max_weight = m->max_weight;
   ia.tau = m->tau;
   ia.counters = m->counters;
   const dim3 block(256);
-  // a non-default new_map must be streamed completely: untouched voxels carry entries too
-  const bool dense = (m->integrate_mode == WS_INTEGRATE_DENSE) || !m->new_is_default;
-  prof_begin(ctx, WS_K_INTEGRATE);
-  if (dense)
+  if (!m->fused_done)
   {
-    int64_t blocks = ((m->n_vox >> 2) + 256 * DENSE_UNROLL - 1) / (256 * DENSE_UNROLL);
-    if (blocks > DENSE_GRID) blocks = DENSE_GRID;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(integrate_dense_kernel, dim3((unsigned)blocks), block, 0, s, ia);
+    // a non-default new_map must be streamed completely: untouched voxels carry entries too
+    const bool dense = (m->integrate_mode == WS_INTEGRATE_DENSE) || !m->new_is_default;
+    prof_begin(ctx, WS_K_INTEGRATE);
+    if (dense)
+    {
+      int64_t blocks = ((m->n_vox >> 2) + 256 * DENSE_UNROLL - 1) / (256 * DENSE_UNROLL);
+      if (blocks > DENSE_GRID) blocks = DENSE_GRID;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(integrate_dense_kernel, dim3((unsigned)blocks), block, 0, s, ia);
+    }
+    else
+    {
+      hipLaunchKernelGGL(integrate_sparse_kernel, dim3(SPARSE_GRID), block, 0, s, ia);
+    }
+    prof_end(ctx, WS_K_INTEGRATE);
   }
-  else
-  {
-    hipLaunchKernelGGL(integrate_sparse_kernel, dim3(LIST_GRID_BLOCKS), block, 0, s, ia);
-  }
-  prof_end(ctx, WS_K_INTEGRATE);
-  hipLaunchKernelGGL(finish_update_kernel, dim3(1), dim3(256), 0, s, m->counters, (const uint32_t *)m->contested_per_wave, LIST_GRID_BLOCKS * 4);
+  hipLaunchKernelGGL(finish_update_kernel, dim3(1), block, 0, s, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
+                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev);
   WS_HIP(hipGetLastError());
+  m->fused_done = false;
   m->new_is_default = true;
   return WS_OK;
 }

@@ -17,9 +17,15 @@ constexpr int WEIGHT_RESOLUTION = 64;    // include/warpsense/consts.h:9-10
 constexpr int DZ_PER_DISTANCE = 100;     // (int)(tan(45/128 deg)/2 * 32768), update_tsdf.cu:49-50 (checked on the host at load)
 constexpr size_t MAX_SCAN_POINTS = 1000000; // update_tsdf.h:33
 
-constexpr int TILE_SHIFT = 6; // dirty-tile granularity: 64 consecutive voxels (256 B of a map)
+// ---- tiles: 8 x 8 x 16 voxels of the ring buffer's STORAGE index space (sx >> 3, sy >> 3, sz >> 4) ----
+// A tile is the unit of the scatter's exact resolve (one workgroup folds all candidates of a tile in LDS) and of
+// the sparse integrate.  Storage space, not world space: a tile's z-runs are contiguous in memory and never
+// straddle the ring seam.
+constexpr int TILE_XB = 3, TILE_YB = 3, TILE_ZB = 4;
+constexpr int TILE_VOXELS = 1 << (TILE_XB + TILE_YB + TILE_ZB); // 1024
 constexpr uint64_t KEY_INF = ~0ull;
-constexpr uint64_t KEY_CONTESTED_TAG = 0xCull << 60; // kpos of a voxel handed to the ordered fallback (never a valid key: t < 2^44)
+constexpr uint32_t WS_TAIL_STATS = 16384; // per-workgroup slots of the tail march (1 000 000 points / 64 rays), then 2 per resolve workgroup
+constexpr uint32_t WS_BLOCK_STATS = WS_TAIL_STATS + 2 * 4096;
 
 // ring-buffer parameters passed BY VALUE to kernels (the reference chases three device pointers per
 // access, device_map.h:93-101)
@@ -32,27 +38,50 @@ struct MapParams
 
 // ---- order key layout -------------------------------------------------------------------
 // t    = point(20) | ray step(16) | fan step(8)                       -> 44 bits, unique per candidate
-// kpos = t << 16 | value(u16)                                          (min == earliest positive-weight candidate)
-// kneg = |value|(15) << 45 | (T_MASK - t) << 1 | (value < 0)           (min == smallest |value|, latest on ties)
+// key  = t << 17 | (weight < 0) << 16 | value(u16)                     (ascending key == canonical serial order)
 constexpr int T_BITS = 44;
 constexpr uint64_t T_MASK = (1ull << T_BITS) - 1;
+constexpr uint64_t KEY_NEG_BIT = 1ull << 16;
 
-struct ContestedRecord // 16 bytes
+// one scatter target of the ray tails (write_tsdf_min call, update_tsdf.cu:107-125)
+struct CandRecord // 16 bytes
 {
-  uint64_t key; // t << 17 | (weight < 0) << 16 | value(u16)
-  uint32_t next;
+  uint64_t key;
+  uint32_t tile;  // tile id in the window's tile grid
+  uint32_t local; // voxel inside the tile: lx << 7 | ly << 4 | lz
+};
+// a run of records of ONE tile, contiguous in the sorted record buffer (written by one workgroup of the tail march)
+struct RunDesc // 16 bytes
+{
+  uint32_t tile;
+  uint32_t count;
+  uint32_t start;
+  uint32_t pad;
+};
+struct TileEntry // 16 bytes: one touched tile of the scan in flight
+{
+  uint32_t tile;
+  uint32_t desc_begin; // its runs: sorted_desc[desc_begin .. desc_begin + nruns)
+  uint32_t nruns;
   uint32_t pad;
 };
 
-struct TsdfCounters // device-resident, zeroed at the start of every update
+struct TsdfCounters // device-resident, zeroed at the start of every scatter
 {
-  uint32_t contested;  // non-zero: the last resolve pass found contested voxels
-  uint32_t records;    // arena records used
-  uint32_t error;      // bit0 arena/list overflow, bit1 key range
-  uint32_t dirty_tiles;      // length of the touched-tile list (survives until the integrate pass)
-  uint32_t last_dirty_tiles; // tiles the last integrate pass streamed
-  uint32_t last_contested;   // contested voxels of the last update
-  uint32_t pad[2];
+  uint32_t raw_cursor;    // record slots handed to the workgroups of the tail march (upper bounds)
+  uint32_t desc_cursor;   // run descriptors written
+  uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
+  uint32_t n_desc_sorted; // == desc_cursor once the tile scan has run
+  uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
+  uint32_t pad0;
+  unsigned long long ub_total; // sum of the per-ray record upper bounds (capacity hint for the next scan)
+  // statistics of the last update, filled by finish_update_kernel
+  uint32_t last_records;
+  uint32_t last_contested;
+  uint32_t last_listed;
+  uint32_t last_runs;
+  uint32_t last_free_keyed;
+  uint32_t pad1[3];
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -91,6 +120,7 @@ struct ws_context
   };
   std::vector<Span> spans;       // recorded, not yet resolved
   std::vector<hipEvent_t> pool;  // free events
+  std::vector<struct ws_map *> maps; // maps of this context (sticky device-side errors are reported at ws_sync)
   double prof_ms[WS_K_COUNT] = {};
   int64_t prof_n[WS_K_COUNT] = {};
 };
@@ -100,35 +130,43 @@ struct ws_map
   ws_context *ctx = nullptr;
   ws::MapParams par[2]; // [WS_MAP_AVG], [WS_MAP_NEW]
   int64_t n_vox = 0;
-  int64_t n_tiles = 0;
   uint32_t *data[2] = {nullptr, nullptr};
-  uint64_t *kpos = nullptr, *kneg = nullptr;
-  uint8_t *dirty = nullptr;       // one flag per 64-voxel tile
-  uint8_t *vstate = nullptr;      // one byte per voxel for the split scatter (keyed / free space)
-  uint32_t *dirty_list = nullptr; // touched tiles of the scan in flight
-  void *rays = nullptr;           // per-ray set-up records (48 B x 1 000 000)
-  uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by azimuth bin
+  uint8_t *vstate = nullptr; // one byte per voxel: keyed / touched by free space / free-space hit on a keyed voxel
+  void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
+  uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
   int integrate_mode = WS_INTEGRATE_SPARSE;
   int32_t *scan_dev = nullptr; // 1 000 000-point upload buffer
-  // contested-voxel machinery
+  // tile grid (8 x 8 x 16 voxels of storage space)
+  int32_t ntx = 0, nty = 0, ntz = 0;
+  int64_t n_tiles = 0;
+  uint32_t *tile_nruns = nullptr;   // [n_tiles] runs per tile of the scan in flight (consumed by the placement pass)
+  uint32_t *tile_begin = nullptr;   // [n_tiles] first sorted descriptor of the tile
+  uint8_t *tile_dirty = nullptr;    // [n_tiles] touched by the free-space pass
+  ws::TileEntry *tile_list = nullptr; // [n_tiles] touched tiles of the scan in flight
+  uint32_t *block_sums = nullptr;   // [2 * 2 * scan blocks] tile scan scratch
+  uint32_t scan_blocks = 0;
+  // candidate records of the ray tails
+  ws::CandRecord *rec_raw = nullptr, *rec_sorted = nullptr;
+  uint32_t rec_cap = 0;
+  ws::RunDesc *desc = nullptr;
+  uint32_t *sorted_desc = nullptr; // [desc_cap][2]: start, count
+  uint32_t desc_cap = 0;
+  // free-space candidates that hit a keyed voxel: voxel index -> earliest order key (open addressing)
+  unsigned long long *fk_keys = nullptr, *fk_vals = nullptr;
+  uint32_t fk_slots = 0;
+  uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
+  uint32_t tail_blocks = 0;        // workgroups of the last tail march
+  bool fused_done = false;         // the last scatter already integrated into avg_map
   ws::TsdfCounters *counters = nullptr;
-  ws::ContestedRecord *arena = nullptr;
-  uint32_t arena_cap = 0;
-  uint32_t *contested_per_wave = nullptr; // statistics, one slot per wave of the resolve pass
-  // LDS-tile scatter (tsdf_tiles.hip)
-  int scatter_mode = WS_SCATTER_GLOBAL; // the LDS-tile path is exact but not yet faster
-  int64_t n_tiles3d = 0;
-  uint32_t *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr;
-  uint64_t *tile_records = nullptr;
-  uint32_t tile_records_cap = 0;
-  void *tile_work = nullptr; // uint4 per work item
-  uint32_t tile_work_cap = 0;
-  void *tile_state = nullptr;
+  ws::TsdfCounters *counters_host = nullptr; // pinned
+  uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [2..3] capacity hint (u64)
+  uint32_t *status_dev = nullptr;            // device view of status_host
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
-  ws::TsdfCounters *counters_host = nullptr; // pinned
+  uint32_t last_error_bits = 0;  // device error bits already taken from status_host, not yet shown by ws_tsdf_stats
+  hipStream_t shift_stream = nullptr; // second stream for asynchronous slab transfers (map shift off the scan path)
 };
 
 struct ws_reg
@@ -190,10 +228,11 @@ void prof_end(ws_context *ctx, int cls);
 
 // launchers implemented in the .hip files
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
+size_t ray_setup_bytes();
+uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
-int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack);
+int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
-int fill_u64(ws_context *ctx, uint64_t *dst, uint64_t value, int64_t n);
 int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
 
 int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags,

@@ -7,7 +7,7 @@
 namespace ws
 {
 // Per-ray constants of update_tsdf.cu:52-63, computed once by ray_setup_kernel.
-struct RaySetup // 48 bytes
+struct RaySetup // 56 bytes
 {
   int32_t dx, dy, dz;    // direction_vector = point - pos (mm)
   int32_t distance;      // (int)|direction_vector|
@@ -15,9 +15,11 @@ struct RaySetup // 48 bytes
   int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
   uint64_t div_m;        // multiply-shift constants for the division by `distance`
   int32_t div_k;
-  int32_t pad; // bit 0: the division-free walk (march_steps_fast) is exact for this ray; bits 1..: azimuth bin
+  int32_t pad;    // bit 0: the division-free walk (march_steps_fast) is exact for this ray; bits 1..: direction bin
+  int32_t kfirst; // first step of the ray TAIL: steps [kfirst, steps) go through the order keys, [0, kfirst) are free space
+  uint32_t ub;    // upper bound of the tail's scatter targets: sum over its steps of iter_steps (update_tsdf.cu:102)
 };
-static_assert(sizeof(RaySetup) == 48, "ws_map::rays is sized for 48-byte records");
+static_assert(sizeof(RaySetup) == 56, "ws_map::rays is sized with ray_setup_bytes()");
 
 // scan-wide constants of the march
 struct MarchFrame
@@ -323,11 +325,10 @@ __device__ __forceinline__ uint64_t order_key(uint32_t ix, int32_t k, int32_t st
 {
   return ((uint64_t)ix << 24) | ((uint64_t)(uint32_t)k << 8) | (uint64_t)(uint32_t)step;
 }
-__device__ __forceinline__ uint64_t make_kpos(uint64_t t, int32_t value) { return (t << 16) | ((uint32_t)value & 0xffffu); }
-__device__ __forceinline__ uint64_t make_kneg(uint64_t t, int32_t value)
+// record key: ascending == canonical serial order (t is unique per candidate)
+__device__ __forceinline__ uint64_t record_key(uint64_t t, int32_t value, bool positive)
 {
-  const uint64_t a = (uint64_t)((uint32_t)(value < 0 ? -value : value) & 0x7fffu);
-  return (a << 45) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
+  return (t << 17) | (positive ? 0ull : KEY_NEG_BIT) | ((uint32_t)value & 0xffffu);
 }
 
 } // namespace ws
