@@ -59,7 +59,7 @@ typedef enum
 #define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
 
 /* integrate pass selection, ws_tsdf_set_integrate() */
-#define WS_INTEGRATE_SPARSE 0 /* default: touched 8x8x16-voxel tiles only, folded into the scatter's tile resolve      */
+#define WS_INTEGRATE_SPARSE 0 /* default: touched 4x4x64-voxel tiles only, folded into the scatter's tile resolve      */
 #define WS_INTEGRATE_DENSE 1  /* stream every voxel like cu_avg_tsdf_krnl (update_tsdf.cu:13-43)                      */
 #define WS_INTEGRATE_SPARSE_SEPARATE 2 /* touched tiles only, as a separate pass over new_map (the resolve writes new_map) */
 
@@ -133,7 +133,7 @@ typedef struct
   int64_t contested_voxels; /* voxels of the last update decided by the exact ordered rounds (a negative-weight
                                candidate could have blocked the earliest positive one)                         */
   int64_t records;          /* scatter targets of the ray tails that went through the order keys                */
-  int64_t tiles;            /* touched 8x8x16-voxel tiles (resolved and integrated)                             */
+  int64_t tiles;            /* touched 4x4x64-voxel tiles (resolved and integrated)                             */
   int32_t error_flags;      /* device error bits since the last call: 1 capacity, 2 key range, 4 free-space bound, 8 internal */
   int32_t pad;
   int64_t runs;             /* (workgroup, tile) runs of records                                                */

@@ -1,8 +1,6 @@
-# diagnostic PMC passes for the TSDF kernels (separate runs, kernel-trace only); prints the march kernels' rows
+# diagnostic counter passes for the TSDF kernels (run on the GPU box via gpurun): bash tools/pmc_probe.sh TAG "CTR1 CTR2 ..."
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum" "SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_LDS"; do
-  i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/probe_$i -o pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-registration > gpurun_out/probe_$i.log 2>&1
-  python tools/pmc_summary.py gpurun_out/probe_$i/pmc_results.db 2>&1 | grep "march_kernel\|^kernel" | head -20
-done
+TAG=${1:-probe}
+CTRS=${2:-"SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"}
+rocprofv3 --kernel-trace --pmc ${CTRS} -d gpurun_out/pmc_${TAG} -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-registration ${3:-} > gpurun_out/pmc_${TAG}.log 2>&1
+python tools/pmc_summary.py $(ls gpurun_out/pmc_${TAG}/*.db gpurun_out/pmc_${TAG}/*/*.db 2>/dev/null | head -1) | grep -E "kernel|march|resolve|integrate|tile_|ray_|desc" | tee gpurun_out/pmc_${TAG}.txt

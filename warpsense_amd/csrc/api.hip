@@ -284,9 +284,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     copy3(m->par[w].offset, offset);
   }
   m->n_vox = (int64_t)size[0] * size[1] * size[2];
-  m->ntx = (size[0] + 7) >> TILE_XB;
-  m->nty = (size[1] + 7) >> TILE_YB;
-  m->ntz = (size[2] + 15) >> TILE_ZB;
+  m->ntx = (size[0] + (1 << TILE_XB) - 1) >> TILE_XB;
+  m->nty = (size[1] + (1 << TILE_YB) - 1) >> TILE_YB;
+  m->ntz = (size[2] + (1 << TILE_ZB) - 1) >> TILE_ZB;
   m->n_tiles = (int64_t)m->ntx * m->nty * m->ntz;
   if (m->n_tiles >= 0xffffffffll)
   {
@@ -313,9 +313,10 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     }                                                               \
   } while (0)
   const size_t map_bytes = (size_t)m->n_vox * sizeof(uint32_t);
-  TRY(hipMalloc((void **)&m->data[0], map_bytes));
-  TRY(hipMalloc((void **)&m->data[1], map_bytes));
-  TRY(hipMalloc((void **)&m->vstate, (size_t)m->n_vox));
+  // 16 bytes of slack: the tile kernels read the four voxels of a column as one access, also at the very end
+  TRY(hipMalloc((void **)&m->data[0], map_bytes + 16));
+  TRY(hipMalloc((void **)&m->data[1], map_bytes + 16));
+  TRY(hipMalloc((void **)&m->vstate, (size_t)m->n_vox + 16));
   TRY(hipMemsetAsync(m->vstate, 0, (size_t)m->n_vox, s));
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));

@@ -18,7 +18,7 @@
 //                            into a small (voxel -> earliest key) hash instead.
 //   tile_count/scan/list     runs per tile -> contiguous descriptor ranges + the list of touched tiles.
 //   desc_place_kernel        run descriptors grouped by tile.
-//   tile_resolve_kernel      ONE workgroup per touched 8x8x16-voxel tile: all candidates of the tile are present,
+//   tile_resolve_kernel      ONE workgroup per touched 4x4x64-voxel tile: all candidates of the tile are present,
 //                            so the canonical accept rule is a local fold in LDS (earliest positive / smallest
 //                            negative keys, then exact rounds for the voxels where a negative-weight candidate
 //                            may have blocked the earliest positive one).  Writes new_map, or — fused — integrates
@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t tile_of(int32_t nty, int32_t ntz, int32_t sx
 }
 __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
 {
-  return (uint32_t)(((sx & 7) << (TILE_YB + TILE_ZB)) | ((sy & 7) << TILE_ZB) | (sz & 15));
+  return (uint32_t)(((sx & ((1 << TILE_XB) - 1)) << (TILE_YB + TILE_ZB)) | ((sy & ((1 << TILE_YB) - 1)) << TILE_ZB) | (sz & ((1 << TILE_ZB) - 1)));
 }
 
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
@@ -349,6 +349,8 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t *cursor)
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4; // four consecutive voxels of a column: dword aligned only
+typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate bytes
 
 // A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
 // quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
@@ -451,15 +453,25 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
       ht_cnt[i] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < total; i += 256)
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
     {
-      const uint32_t tile = a.rec_raw[base + i].tile;
-      if (tile == REC_DONE) continue;
-      const int s = ht_insert(ht_key, tile);
-      if (s < 0)
-        s_overflow = 1;
-      else
-        atomicAdd(&ht_cnt[s], 1u);
+      uint32_t tile[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        tile[u] = i < total ? a.rec_raw[base + i].tile : REC_DONE;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        if (tile[u] == REC_DONE) continue;
+        const int s = ht_insert(ht_key, tile[u]);
+        if (s < 0)
+          s_overflow = 1;
+        else
+          atomicAdd(&ht_cnt[s], 1u);
+      }
     }
     __syncthreads();
     // exclusive scan over the slots: records (low word) and runs (high word) together
@@ -524,15 +536,28 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
     }
     __syncthreads();
     const bool more = s_overflow != 0;
-    for (uint32_t i = threadIdx.x; i < total; i += 256)
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
     {
-      const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + i]);
-      if (rec.z == REC_DONE) continue;
-      const int s = ht_find(ht_key, rec.z);
-      if (s < 0) continue; // next round
-      const uint32_t p = atomicAdd(&ht_cur[s], 1u);
-      *reinterpret_cast<u32x4 *>(&a.rec_sorted[base + round_base + p]) = rec;
-      if (more) a.rec_raw[base + i].tile = REC_DONE;
+      u32x4 rec[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        if (i < total)
+          rec[u] = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + i]);
+        else
+          rec[u].z = REC_DONE;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        if (rec[u].z == REC_DONE) continue;
+        const int s = ht_find(ht_key, rec[u].z);
+        if (s < 0) continue; // next round
+        const uint32_t p = atomicAdd(&ht_cur[s], 1u);
+        *reinterpret_cast<u32x4 *>(&a.rec_sorted[base + round_base + p]) = rec[u];
+        if (more) a.rec_raw[base + i0 + (uint32_t)u * 256u].tile = REC_DONE;
+      }
     }
     __syncthreads();
     if (!more) break;
@@ -780,6 +805,8 @@ struct ResolveArgs
   MapParams map;
   int32_t nty, ntz;
   int32_t tau, max_weight;
+  FastDiv wdiv;      // division by tau - tau/10 of the weight ramp (update_tsdf.cu:92)
+  uint32_t desc_cap; // entries of sorted_desc
   uint32_t *resolve_stats; // [grid][2]: contested voxels, free-space hits on keyed voxels
   TsdfCounters *counters;
   uint32_t *status;
@@ -813,54 +840,218 @@ __device__ __forceinline__ void for_each_record(const TileEntry &te, const uint3
   }
 }
 
+constexpr int RES_MAXD = 256; // runs whose descriptors are staged in LDS (up to 64: held by the lanes of every wave)
+constexpr int RES_MAXR = 8;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
+
+// what a thread needs of a tile before it can start, requested two tiles ahead
+struct TilePre
+{
+  int64_t idx0;
+  int nz;
+  uint32_t my_start, my_count; // run descriptor of this lane (nruns <= 64) or of this thread (nruns <= RES_MAXD)
+  uint32_t vs;                 // four vstate bytes
+  uint32_t s0[4];              // new_map entries (HAS_S0)
+  uint32_t existing[4];        // avg_map entries (FUSED)
+};
+// the result of a tile, written back one tile later (behind the next tile's wait for its records)
+struct TilePost
+{
+  int64_t idx0;
+  int nz;
+  uint32_t vs;
+  uint32_t touched; // bit j
+  uint32_t value[4];
+  uint32_t existing[4];
+};
+
 // One workgroup per touched tile, thread t owns the voxels 4t .. 4t+3 of the tile (one column, four consecutive z).
 // HAS_S0: new_map is not (tau, 0) — the fold starts from the stored entry (a positive weight there freezes the voxel).
 // FUSED: integrate the result straight into avg_map instead of writing new_map (new_map stays (tau, 0)).
+//
+// Per voxel, with the candidates in canonical order: the winner is the first positive-weight candidate p with
+// |v_p| <= min |v_n| over the negative-weight candidates n BEFORE p (atomic_tsdf_min accepts iff the stored weight is
+// <= 0 and |new| <= |stored|, cuda/util.h:70-102); if there is none, the negative candidate of smallest |value|
+// (latest on ties); else the entry stays.  LDS phases per tile:
+//   pass 1   kpos = earliest positive, kneg = smallest (latest) negative            (LDS atomicMin per record)
+//   scan A   m = min |v_n| over the negatives before kpos with |v_n| < |v_kpos|      (only those can block it)
+//   decide   no such negative -> kpos wins; no positive -> kneg; else kpos is blocked: later positives need |v| <= m
+//   scan B / decide / scan A ...  the next eligible positive, until every voxel is decided (rare after the first round)
+//
+// Memory pipeline.  gfx950 retires vector memory operations in order behind ONE counter (loads and stores), and the
+// counts here are data dependent, so every wait is a wait for everything outstanding.  The loop therefore has a single
+// such point per tile — the arrival of the tile's records — and everything else is arranged around it: entry, voxel
+// bytes and descriptors of later tiles and the records of the next tile are all requested together at the END of an
+// iteration, and the stores of a tile are issued right AFTER the next wait, so they drain under the LDS phases.
 template <bool HAS_S0, bool FUSED>
 __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
 {
-  __shared__ unsigned long long kpos[TILE_VOXELS]; // earliest eligible positive-weight candidate
-  __shared__ unsigned long long kneg[TILE_VOXELS]; // smallest-|value| (latest) negative-weight candidate
-  __shared__ unsigned long long klast[TILE_VOXELS]; // ordered rounds: the positive candidate that was blocked last
-  __shared__ uint32_t mstate[TILE_VOXELS];          // ordered rounds: min |value| of the negatives before the candidate
+  __shared__ unsigned long long kpos[TILE_VOXELS];
+  __shared__ unsigned long long kneg[TILE_VOXELS];
+  __shared__ unsigned long long klast[TILE_VOXELS]; // the positive candidate that was blocked last
+  __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
+  __shared__ uint32_t d_start[RES_MAXD], d_prefix[RES_MAXD];
+  __shared__ unsigned long long scan_tmp[4];
   __shared__ uint32_t s_unres[2];
   const uint32_t n_list = a.counters->n_listed;
   const int32_t weight_epsilon = a.tau / 10;
   const uint32_t reset = pack_entry(a.tau, 0);
-  const int col = threadIdx.x >> 2, lx = col >> 3, ly = col & 7, z0 = (threadIdx.x & 3) * 4;
+  const int lane = threadIdx.x & 63;
+  // thread t owns the voxels 4t .. 4t+3 of the tile: column t >> (ZB - 2), four consecutive z
+  const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
   const int l0 = threadIdx.x * 4;
+  const uint32_t G = gridDim.x;
   uint32_t n_contested = 0, n_freehit = 0;
+#ifdef WS_RESOLVE_TIMING
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = clock64();
+  int t_tiles = 0, t_rounds = 0;
+#define WS_TP(i)                      \
+  {                                   \
+    const long long now = clock64();  \
+    tp[i] += now - tl;                \
+    tl = now;                         \
+  }
+#else
+#define WS_TP(i)
+#endif
 
-  for (uint32_t e = blockIdx.x; e < n_list; e += gridDim.x)
-  {
-    const TileEntry te = a.tile_list[e];
+  // all loads unconditional (clamped addresses, results masked)
+  auto request = [&](const TileEntry &te, TilePre &p) {
     const int32_t tz = (int32_t)(te.tile % (uint32_t)a.ntz);
     const int32_t ty = (int32_t)((te.tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
     const int32_t tx = (int32_t)(te.tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
-    const int32_t sx = tx * 8 + lx, sy = ty * 8 + ly, sz = tz * 16 + z0;
+    const int32_t sx = (tx << TILE_XB) + lx, sy = (ty << TILE_YB) + ly, sz = (tz << TILE_ZB) + z0;
     const bool col_ok = sx < a.map.size[0] && sy < a.map.size[1];
     int nz = a.map.size[2] - sz;
-    nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
-    const int64_t idx0 = col_ok ? storage_index(a.map, sx, sy, sz) : 0;
-
-    uint32_t entry[4];
-    uint8_t vs[4] = {0, 0, 0, 0};
-    uint32_t s0[4];
-    bool touched[4] = {false, false, false, false};
+    p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
+    p.idx0 = p.nz ? storage_index(a.map, sx, sy, sz) : 0;
+    const uint32_t which = te.nruns <= 64 ? (uint32_t)lane : threadIdx.x;
+    const bool mine = which < te.nruns && te.nruns <= RES_MAXD;
+    uint32_t di = te.desc_begin + (mine ? which : 0u);
+    di = di < a.desc_cap ? di : a.desc_cap - 1;
+    const uint2 d = *reinterpret_cast<const uint2 *>(&a.sorted_desc[2 * (size_t)di]);
+    p.my_start = mine ? d.x : 0u;
+    p.my_count = mine ? d.y : 0u;
+    // four voxels of a column in one access each (the arrays carry 16 bytes of slack behind the last voxel)
+    const uint32_t keep = p.nz >= 4 ? 0xffffffffu : ((1u << (8 * p.nz)) - 1u);
+    p.vs = 0;
+    if (!HAS_S0) p.vs = *reinterpret_cast<const u32_a1 *>(a.vstate + p.idx0) & keep;
+    const u32x4 z4 = {reset, reset, reset, reset};
+    u32x4 s4 = z4, e4 = z4;
+    if (HAS_S0) s4 = *reinterpret_cast<const u32x4_a4 *>(a.new_data + p.idx0);
+    if (FUSED) e4 = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
+    p.s0[0] = s4.x; p.s0[1] = s4.y; p.s0[2] = s4.z; p.s0[3] = s4.w;
+    p.existing[0] = e4.x; p.existing[1] = e4.y; p.existing[2] = e4.z; p.existing[3] = e4.w;
+  };
+  auto init_lds = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-      entry[j] = reset;
-      s0[j] = reset;
-      if (j < nz)
+      kpos[l0 + j] = KEY_INF;
+      kneg[l0 + j] = KEY_INF;
+      mstate[l0 + j] = M_NONE;
+    }
+  };
+  // the records of a tile with at most 64 runs: every wave holds all descriptors in its lanes (prefix by a wave scan,
+  // run of a record by counting).  Returns false when the tile has more runs or more records than the registers hold.
+  unsigned long long rkey[RES_MAXR];
+  uint32_t rloc[RES_MAXR];
+  auto fetch_records = [&](const TileEntry &te, const TilePre &p) -> bool {
+#pragma unroll
+    for (int k = 0; k < RES_MAXR; ++k)
+    {
+      rkey[k] = 0;
+      rloc[k] = 0xffffffffu;
+    }
+    if (te.nruns == 0 || te.nruns > 64) return false;
+    uint32_t incl = p.my_count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t prefix = incl - p.my_count;
+    if (total > RES_MAXR * 256) return false;
+    uint32_t run[RES_MAXR];
+#pragma unroll
+    for (int k = 0; k < RES_MAXR; ++k) run[k] = 0;
+    const int nruns = (int)te.nruns;
+    for (int i = 1; i < nruns; ++i)
+    {
+      const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane((int)prefix, i);
+#pragma unroll
+      for (int k = 0; k < RES_MAXR; ++k) run[k] += (pi <= (uint32_t)(k * 256) + threadIdx.x) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < RES_MAXR; ++k)
+    {
+      const uint32_t f = (uint32_t)(k * 256) + threadIdx.x;
+      const uint32_t rs = (uint32_t)__shfl((int)p.my_start, (int)run[k], 64);
+      const uint32_t rp = (uint32_t)__shfl((int)prefix, (int)run[k], 64);
+      if (f < total)
       {
-        if (HAS_S0)
-          s0[j] = a.new_data[idx0 + j];
-        else
-          vs[j] = a.vstate[idx0 + j];
+        const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.recs[rs + (f - rp)]);
+        rkey[k] = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+        rloc[k] = rec.w & (TILE_VOXELS - 1);
       }
     }
+    return true;
+  };
+  auto write_back = [&](const TilePost &w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+      if (j >= w.nz) continue;
+      if (!HAS_S0 && ((w.vs >> (8 * j)) & 0xffu)) a.vstate[w.idx0 + j] = 0;
+      if (!(w.touched & (1u << j))) continue;
+      if (FUSED)
+      {
+        const uint32_t updated = integrate_entry(w.existing[j], w.value[j], a.max_weight);
+        if (updated != w.existing[j]) a.avg_data[w.idx0 + j] = updated;
+      }
+      else
+      {
+        a.new_data[w.idx0 + j] = w.value[j];
+      }
+    }
+  };
+
+  const uint32_t e0 = blockIdx.x;
+  if (e0 >= n_list)
+  {
+    if (threadIdx.x == 0) a.resolve_stats[2 * blockIdx.x + 0] = a.resolve_stats[2 * blockIdx.x + 1] = 0;
+    return;
+  }
+  const uint32_t last = n_list - 1;
+  TileEntry te_cur = a.tile_list[e0], te_n1 = a.tile_list[min(e0 + G, last)], te_n2 = a.tile_list[min(e0 + 2 * G, last)];
+  TilePre p_cur, p_n1;
+  request(te_cur, p_cur);
+  bool cached = fetch_records(te_cur, p_cur);
+  request(te_n1, p_n1);
+  TilePost post;
+  post.nz = 0;
+  post.idx0 = 0;
+  post.vs = post.touched = 0;
+  if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
+  init_lds();
+  __syncthreads();
+
+  for (uint32_t e = e0; e < n_list; e += G)
+  {
+    const TileEntry te = te_cur;
+    const TilePre p = p_cur;
+    const int nz = p.nz;
+    const int64_t idx0 = p.idx0;
+
+    uint32_t entry[4] = {reset, reset, reset, reset};
+    uint32_t touched = 0;
+    uint8_t vs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vs[j] = (uint8_t)(p.vs >> (8 * j)); // <- the wait of this iteration (with the records)
+    WS_TP(0)
+    write_back(post); // the previous tile's stores drain under this tile's LDS phases
 
     if (te.nruns == 0)
     {
@@ -872,29 +1063,98 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
           if (vs[j] & VOX_TOUCHED)
           {
             entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
-            touched[j] = true;
+            touched |= 1u << j;
           }
       }
     }
     else
     {
-      if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      if (HAS_S0)
       {
-        kpos[l0 + j] = KEY_INF;
-        kneg[l0 + j] = KEY_INF;
-        mstate[l0 + j] = M_IDLE;
-        if (HAS_S0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
         {
-          const int32_t v0 = entry_value(s0[j]);
-          bound0[l0 + j] = (uint16_t)((j < nz && entry_weight(s0[j]) <= 0) ? (v0 < 0 ? -v0 : v0) + 1 : 0);
+          const int32_t v0 = entry_value(p.s0[j]);
+          bound0[l0 + j] = (uint16_t)((j < nz && entry_weight(p.s0[j]) <= 0) ? (v0 < 0 ? -v0 : v0) + 1 : 0);
+        }
+        __syncthreads();
+      }
+      if (!cached && te.nruns <= RES_MAXD)
+      {
+        // 65 .. 256 runs: descriptors staged in LDS, records in registers if they fit
+        unsigned long long total64;
+        const uint32_t excl = (uint32_t)block_scan_u64(p.my_count, scan_tmp, total64);
+        d_start[threadIdx.x] = p.my_start;
+        d_prefix[threadIdx.x] = excl;
+        __syncthreads();
+        const uint32_t total = (uint32_t)total64;
+        if (te.nruns > 64 && total <= RES_MAXR * 256)
+        {
+          cached = true;
+          const int nruns = (int)te.nruns;
+#pragma unroll
+          for (int k = 0; k < RES_MAXR; ++k)
+          {
+            const uint32_t f = (uint32_t)(k * 256) + threadIdx.x;
+            if (f < total)
+            {
+              int r = 0;
+#pragma unroll
+              for (int step = RES_MAXD / 2; step > 0; step >>= 1)
+              {
+                const int c = r + step;
+                if (c < nruns && d_prefix[c] <= f) r = c;
+              }
+              const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.recs[d_start[r] + (f - d_prefix[r])]);
+              rkey[k] = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
+              rloc[k] = rec.w & (TILE_VOXELS - 1);
+            }
+          }
         }
       }
-      __syncthreads();
+      WS_TP(1)
+      auto scan_records = [&](auto &&f) {
+        if (cached)
+        {
+#pragma unroll
+          for (int k = 0; k < RES_MAXR; ++k)
+            if (rloc[k] != 0xffffffffu)
+            {
+              const int32_t value = (int32_t)(int16_t)(rkey[k] & 0xffffu);
+              const int32_t av = value < 0 ? -value : value;
+              if (HAS_S0 && av >= (int32_t)bound0[rloc[k]]) continue; // rejected by the stored entry, now and for ever
+              f((uint64_t)rkey[k], value, av, (int)rloc[k]);
+            }
+        }
+        else
+        {
+          for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+            if (HAS_S0 && av >= (int32_t)bound0[l]) return;
+            f(key, value, av, l);
+          });
+        }
+      };
+      // scan A: the negatives that come before the current positive candidate and can block it
+      auto scan_a = [&]() {
+        scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
+          if (!(key & KEY_NEG_BIT)) return;
+          const uint32_t m = mstate[l];
+          if (m == M_IDLE || (uint32_t)av >= m) return;
+          const unsigned long long P = kpos[l];
+          if (P == KEY_INF || key > P) return;
+          const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+          if (av < (vp < 0 ? -vp : vp)) atomicMin(&mstate[l], (uint32_t)av);
+        });
+      };
+      auto negative_entry = [&](unsigned long long N) {
+        // no positive candidate is accepted: the negatives fold to the smallest |value|, latest on ties
+        const int32_t an = (int32_t)(N >> 45);
+        const int32_t v = (N & 1ull) ? -an : an;
+        return pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon, a.wdiv));
+      };
+
       // ---- pass 1: earliest positive, smallest negative per voxel
-      for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
-        if (HAS_S0 && av >= (int32_t)bound0[l]) return; // rejected by the stored entry, now and for ever
+      scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
         if (key & KEY_NEG_BIT)
           atomicMin(&kneg[l], (unsigned long long)neg_key(key, av, value));
         else
@@ -911,7 +1171,7 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
             const unsigned long long want = (unsigned long long)(idx0 + j);
             uint32_t h = fk_hash(want, a.fk_shift);
             unsigned long long t = KEY_INF;
-            for (int p = 0; p < 128; ++p)
+            for (int q = 0; q < 128; ++q)
             {
               const unsigned long long cur = a.fk_keys[h];
               if (cur == want)
@@ -929,134 +1189,168 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
           }
       }
       __syncthreads();
+      WS_TP(2)
+      scan_a();
+      __syncthreads();
+      WS_TP(3)
 
-      // ---- decide every voxel whose earliest positive candidate cannot have been blocked
-      uint32_t unres = 0; // bit j: voxel j is in the ordered rounds
+      // ---- decide
+      uint32_t unres = 0; // bit j: voxel j is still open
 #pragma unroll
       for (int j = 0; j < 4; ++j)
       {
-        if (j >= nz) continue;
         const unsigned long long P = kpos[l0 + j], N = kneg[l0 + j];
-        if (P == KEY_INF && N == KEY_INF)
+        const uint32_t m = mstate[l0 + j];
+        bool open = false;
+        if (j < nz && !(P == KEY_INF && N == KEY_INF))
         {
-          if (!HAS_S0 && (vs[j] & VOX_TOUCHED))
+          touched |= 1u << j;
+          if (P == KEY_INF)
           {
-            entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
-            touched[j] = true;
+            entry[j] = negative_entry(N);
           }
-          continue;
+          else
+          {
+            const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+            const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
+            if (N != KEY_INF && ap > (uint32_t)(N >> 45)) n_contested += 1; // a negative candidate COULD have blocked it
+            if (ap <= m)
+            {
+              entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon, a.wdiv));
+            }
+            else
+            {
+              // blocked: every later positive candidate needs |value| <= m (which stays in mstate)
+              open = true;
+              unres |= 1u << j;
+              klast[l0 + j] = P;
+              kpos[l0 + j] = KEY_INF;
+            }
+          }
         }
-        touched[j] = true;
-        if (P == KEY_INF)
+        else if (j < nz && !HAS_S0 && (vs[j] & VOX_TOUCHED))
         {
-          const int32_t an = (int32_t)(N >> 45);
-          const int32_t v = (N & 1ull) ? -an : an;
-          entry[j] = pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon));
-          continue;
+          entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
+          touched |= 1u << j;
         }
-        const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
-        const int32_t ap = vp < 0 ? -vp : vp;
-        if (N == KEY_INF || ap <= (int32_t)(N >> 45))
+        if (!open)
         {
-          entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon));
-          continue;
+          // decided: ready for the next tile
+          kpos[l0 + j] = KEY_INF;
+          kneg[l0 + j] = KEY_INF;
+          mstate[l0 + j] = M_NONE;
         }
-        // a negative-weight candidate with a smaller |value| MAY have come first and blocked it: ordered rounds
-        unres |= 1u << j;
-        mstate[l0 + j] = M_NONE;
-        n_contested += 1;
       }
       if (unres) atomicAdd(&s_unres[0], 1u);
       __syncthreads();
+      WS_TP(4)
 
-      // ---- ordered rounds: winner = first positive p with |v_p| <= min |v_n| over the negatives before p
-      int phase = 0;
-      while (s_unres[phase] != 0)
+      if (s_unres[0] != 0)
       {
-        // A: min |value| of the negatives that precede the current candidate
-        for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
-          if (!(key & KEY_NEG_BIT)) return;
-          const uint32_t m = mstate[l];
-          if (m == M_IDLE || (uint32_t)av >= m) return;
-          if (HAS_S0 && av >= (int32_t)bound0[l]) return;
-          if (key < kpos[l]) atomicMin(&mstate[l], (uint32_t)av);
-        });
-        __syncthreads();
-        if (threadIdx.x == 0) s_unres[phase ^ 1] = 0;
+        // ---- ordered rounds (some voxel of the tile had its earliest positive candidate blocked)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+          if (!(unres & (1u << j))) mstate[l0 + j] = M_IDLE;
+        if (threadIdx.x == 0) s_unres[1] = 0;
+        __syncthreads();
+        int phase = 0;
+        for (;;)
         {
-          if (!(unres & (1u << j))) continue;
-          const unsigned long long P = kpos[l0 + j];
-          const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
-          const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
-          if (ap <= mstate[l0 + j])
-          {
-            entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon));
-            unres &= ~(1u << j);
-            mstate[l0 + j] = M_IDLE;
-          }
-          else
-          {
-            // blocked: every later positive candidate needs |value| <= that minimum
-            klast[l0 + j] = P;
-            kpos[l0 + j] = KEY_INF;
-          }
-        }
-        __syncthreads();
-        // B: the next positive candidate that can still be accepted
-        for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
-          if (key & KEY_NEG_BIT) return;
-          const uint32_t m = mstate[l];
-          if (m == M_IDLE || (uint32_t)av > m) return;
-          if (key > klast[l]) atomicMin(&kpos[l], (unsigned long long)key);
-        });
-        __syncthreads();
+          // B: the next positive candidate that can still be accepted
+          scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
+            if (key & KEY_NEG_BIT) return;
+            const uint32_t m = mstate[l];
+            if (m == M_IDLE || (uint32_t)av > m) return;
+            if (key > klast[l]) atomicMin(&kpos[l], (unsigned long long)key);
+          });
+          __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-          if (!(unres & (1u << j))) continue;
-          if (kpos[l0 + j] == KEY_INF)
+          for (int j = 0; j < 4; ++j)
           {
-            // no positive candidate is ever accepted: the negatives fold to the smallest |value|, latest on ties
-            const unsigned long long N = kneg[l0 + j];
-            const int32_t an = (int32_t)(N >> 45);
-            const int32_t v = (N & 1ull) ? -an : an;
-            entry[j] = pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon));
-            unres &= ~(1u << j);
-            mstate[l0 + j] = M_IDLE;
+            if (!(unres & (1u << j))) continue;
+            if (kpos[l0 + j] == KEY_INF)
+            {
+              entry[j] = negative_entry(kneg[l0 + j]);
+              unres &= ~(1u << j);
+              mstate[l0 + j] = M_IDLE;
+            }
+            else
+            {
+              mstate[l0 + j] = M_NONE;
+            }
           }
-          else
+          if (unres) atomicAdd(&s_unres[phase ^ 1], 1u);
+          __syncthreads();
+          if (threadIdx.x == 0) s_unres[phase] = 0;
+          phase ^= 1;
+#ifdef WS_RESOLVE_TIMING
+          t_rounds += 1;
+#endif
+          if (s_unres[phase] == 0) break;
+          scan_a();
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
           {
-            mstate[l0 + j] = M_NONE;
+            if (!(unres & (1u << j))) continue;
+            const unsigned long long P = kpos[l0 + j];
+            const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+            const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
+            if (ap <= mstate[l0 + j])
+            {
+              entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon, a.wdiv));
+              unres &= ~(1u << j);
+              mstate[l0 + j] = M_IDLE;
+            }
+            else
+            {
+              klast[l0 + j] = P;
+              kpos[l0 + j] = KEY_INF;
+            }
           }
+          if (unres) atomicAdd(&s_unres[phase ^ 1], 1u);
+          __syncthreads();
+          if (threadIdx.x == 0) s_unres[phase] = 0;
+          phase ^= 1;
+          if (s_unres[phase] == 0) break;
         }
-        if (unres) atomicAdd(&s_unres[phase ^ 1], 1u);
         __syncthreads();
-        phase ^= 1;
+        if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
+        init_lds();
+        __syncthreads();
       }
-      __syncthreads(); // LDS is reused by the next tile
+      WS_TP(5)
+#ifdef WS_RESOLVE_TIMING
+      t_tiles += 1;
+#endif
     }
 
-    // ---- write-back
+    // ---- this tile's result waits in registers; request what the next iterations need, all together
+    post.idx0 = idx0;
+    post.nz = nz;
+    post.vs = p.vs;
+    post.touched = touched;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-      if (j >= nz) continue;
-      if (!HAS_S0 && vs[j]) a.vstate[idx0 + j] = 0;
-      if (!touched[j]) continue;
-      if (FUSED)
-      {
-        const uint32_t existing = a.avg_data[idx0 + j];
-        const uint32_t updated = integrate_entry(existing, entry[j], a.max_weight);
-        if (updated != existing) a.avg_data[idx0 + j] = updated;
-      }
-      else
-      {
-        a.new_data[idx0 + j] = entry[j];
-      }
+      post.value[j] = entry[j];
+      post.existing[j] = p.existing[j];
     }
+    te_cur = te_n1;
+    p_cur = p_n1;
+    te_n1 = te_n2;
+    te_n2 = a.tile_list[min(e + 3 * G, last)];
+    request(te_n1, p_n1);
+    cached = fetch_records(te_cur, p_cur);
+    WS_TP(6)
   }
+  write_back(post);
+#ifdef WS_RESOLVE_TIMING
+  if (threadIdx.x == 0 && (blockIdx.x & 511) == 7)
+    printf("resolve wg %u: %d keyed tiles, %d rounds | wait %lld staged %lld pass1 %lld scanA %lld decide %lld rounds %lld issue %lld cycles per keyed tile\n",
+           blockIdx.x, t_tiles, t_rounds, tp[0] / max(t_tiles, 1), tp[1] / max(t_tiles, 1), tp[2] / max(t_tiles, 1), tp[3] / max(t_tiles, 1),
+           tp[4] / max(t_tiles, 1), tp[5] / max(t_tiles, 1), tp[6] / max(t_tiles, 1));
+#endif
   // statistics: one slot per workgroup, no shared counter
   for (int d = 32; d > 0; d >>= 1)
   {
@@ -1107,27 +1401,27 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 {
   const uint32_t n_list = a.counters->n_listed;
   const uint32_t reset = pack_entry(a.tau, 0);
-  const int col = threadIdx.x >> 2, lx = col >> 3, ly = col & 7, z0 = (threadIdx.x & 3) * 4;
+  // thread t owns the voxels 4t .. 4t+3 of the tile: column t >> (ZB - 2), four consecutive z
+  const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
   for (uint32_t e = blockIdx.x; e < n_list; e += gridDim.x)
   {
     const uint32_t tile = a.tile_list[e].tile;
     const int32_t tz = (int32_t)(tile % (uint32_t)a.ntz);
     const int32_t ty = (int32_t)((tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
     const int32_t tx = (int32_t)(tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
-    const int32_t sx = tx * 8 + lx, sy = ty * 8 + ly, sz = tz * 16 + z0;
+    const int32_t sx = (tx << TILE_XB) + lx, sy = (ty << TILE_YB) + ly, sz = (tz << TILE_ZB) + z0;
     if (sx >= a.map.size[0] || sy >= a.map.size[1]) continue;
     int nz = a.map.size[2] - sz;
     nz = nz > 4 ? 4 : nz;
     const int64_t idx0 = storage_index(a.map, sx, sy, sz);
-    uint32_t fresh[4], existing[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fresh[j] = j < nz ? a.new_data[idx0 + j] : reset;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) existing[j] = fresh[j] != reset ? a.avg_data[idx0 + j] : 0u;
+    // both arrays in one round trip (the arrays carry 16 bytes of slack behind the last voxel)
+    const u32x4 f4 = *reinterpret_cast<const u32x4_a4 *>(a.new_data + idx0);
+    const u32x4 e4 = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + idx0);
+    const uint32_t fresh[4] = {f4.x, f4.y, f4.z, f4.w}, existing[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-      if (fresh[j] == reset) continue;
+      if (j >= nz || fresh[j] == reset) continue;
       const uint32_t updated = integrate_entry(existing[j], fresh[j], a.max_weight);
       if (updated != existing[j]) a.avg_data[idx0 + j] = updated;
       a.new_data[idx0 + j] = reset;
@@ -1394,6 +1688,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.ntz = m->ntz;
   ra.tau = m->tau;
   ra.max_weight = m->max_weight;
+  ra.wdiv = make_fastdiv(m->tau - m->tau / 10);
+  ra.desc_cap = m->desc_cap;
   ra.resolve_stats = m->block_stats + WS_TAIL_STATS;
   ra.counters = m->counters;
   ra.status = m->status_dev;

@@ -114,6 +114,19 @@ __device__ __forceinline__ int32_t tsdf_weight(int32_t value, int32_t tau, int32
   return weight;
 }
 
+// the same with the division by the scan constant (tau - weight_epsilon) prepared (make_fastdiv): 64 * (tau + value) >= 0
+__device__ __forceinline__ int32_t tsdf_weight(int32_t value, int32_t tau, int32_t weight_epsilon, const FastDiv &wdiv)
+{
+  int32_t weight = WEIGHT_RESOLUTION;
+  if (value < -weight_epsilon) weight = div_trunc(WEIGHT_RESOLUTION * (tau + value), wdiv);
+  return weight;
+}
+// weight == 0 (update_tsdf.cu:96: the candidate is skipped) without dividing: 64 * (tau + value) < tau - weight_epsilon
+__device__ __forceinline__ bool tsdf_weight_is_zero(int32_t value, int32_t tau, int32_t weight_epsilon)
+{
+  return value < -weight_epsilon && WEIGHT_RESOLUTION * (tau + value) < tau - weight_epsilon;
+}
+
 // cu_avg_tsdf_krnl body — update_tsdf.cu:19-34; returns the updated existing entry
 __device__ __forceinline__ uint32_t integrate_entry(uint32_t existing, uint32_t fresh, int32_t max_weight)
 {

@@ -83,7 +83,7 @@ __device__ __forceinline__ void march_steps_direct(const MarchFrame &f, const Ra
     int32_t value = l2norm_i(wsub(px, tcx), wsub(py, tcy), wsub(pz, tcz));
     value = value < tau ? value : tau;
     if (len > r.distance) value = -value;
-    if (tsdf_weight(value, tau, f.weight_epsilon) == 0) continue;
+    if (tsdf_weight_is_zero(value, tau, f.weight_epsilon)) continue;
 
     // update_tsdf.cu:101-105
     const int32_t delta_z = wmul(DZ_PER_DISTANCE, len) / MATRIX_RESOLUTION;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
       value = l2norm_i(axis_centre_delta(wx, px, res, half), axis_centre_delta(wy, py, res, half), axis_centre_delta(wz, pz, res, half));
       value = value < tau ? value : tau;
       if (len > r.distance) value = -value;
-      if (value < -f.weight_epsilon && tsdf_weight(value, tau, f.weight_epsilon) == 0) continue;
+      if (tsdf_weight_is_zero(value, tau, f.weight_epsilon)) continue;
     }
 
     const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
