@@ -272,6 +272,10 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   if (!ctx || !size || !pos || !offset || !out) return invalid("ws_map_create: NULL argument");
   if (size[0] < 3 || size[1] < 3 || size[2] < 3) return invalid("ws_map_create: map sizes must be >= 3");
   if ((int64_t)size[0] * size[1] >= (1ll << 31) || size[2] > (1 << 20)) return invalid("ws_map_create: map too large (x*y must stay below 2^31 voxels)");
+  if (size[0] >= (1 << 24) || size[1] >= (1 << 24) ||
+      (int64_t)((size[0] + (1 << TILE_XB) - 1) >> TILE_XB) * ((size[1] + (1 << TILE_YB) - 1) >> TILE_YB) >= (1ll << 24) ||
+      ((size[2] + (1 << TILE_ZB) - 1) >> TILE_ZB) >= (1 << 24))
+    return invalid("ws_map_create: map too large (more than 2^24 tile columns)");
   if (res < 2) return invalid("ws_map_create: map_resolution must be >= 2 mm (the ray step is resolution/2)");
   if (tau <= 0 || tau > 32767) return invalid("ws_map_create: tau must fit the int16 TSDF value");
   ws_map *m = new (std::nothrow) ws_map();

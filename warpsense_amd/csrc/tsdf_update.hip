@@ -95,12 +95,15 @@ __device__ __forceinline__ void storage_coords(const MapParams &m, int32_t vx, i
 }
 __device__ __forceinline__ int64_t storage_index(const MapParams &m, int32_t sx, int32_t sy, int32_t sz)
 {
-  const int32_t row = sx * m.size[1] + sy; // size[0] * size[1] < 2^31 (checked by ws_map_create)
+  // sizes are below 2^24 and size[0] * size[1] below 2^31 (checked by ws_map_create): one full-rate 24-bit multiply-add
+  const int32_t row = (int32_t)(__umul24((uint32_t)sx, (uint32_t)m.size[1]) + (uint32_t)sy);
   return (int64_t)row * (int64_t)m.size[2] + sz;
 }
 __device__ __forceinline__ uint32_t tile_of(int32_t nty, int32_t ntz, int32_t sx, int32_t sy, int32_t sz)
 {
-  return (uint32_t)(((sx >> TILE_XB) * nty + (sy >> TILE_YB)) * ntz + (sz >> TILE_ZB));
+  // ntx * nty < 2^24 (checked by ws_map_create): full-rate 24-bit multiplies
+  const uint32_t col = __umul24((uint32_t)(sx >> TILE_XB), (uint32_t)nty) + (uint32_t)(sy >> TILE_YB);
+  return __umul24(col, (uint32_t)ntz) + (uint32_t)(sz >> TILE_ZB);
 }
 __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
 {
@@ -188,7 +191,22 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
           const bool fast = dmax <= distance && dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
                             (2 * max_delta_z + res) * ivmax < (1ll << 31) &&
                             (len_end + 2 * (int64_t)res) * (len_end + 2 * (int64_t)res) < (1ll << 31);
-          r.pad = fast ? 1 : 0;
+          r.pad = fast ? RAY_FAST : 0;
+          {
+            // the whole ray, its fans included, inside the window with room to spare: the per-candidate in_bounds tests
+            // (update_tsdf.cu:73,113) cannot fail.  Both ends inside a box shrunk by the fan reach (convexity does the rest).
+            const int64_t margin = 4 + (max_delta_z + res) / res;
+            const int64_t endx = (int64_t)posx + (int64_t)dx * len_end / distance, endy = (int64_t)posy + (int64_t)dy * len_end / distance,
+                          endz = (int64_t)posz + (int64_t)dz * len_end / distance;
+            const int64_t ev[3] = {endx / res, endy / res, endz / res};
+            bool inside = fast;
+            for (int k = 0; k < 3; ++k)
+            {
+              const int64_t lim = (int64_t)(a.map.size[k] / 2) - margin;
+              inside = inside && llabs((long long)((int64_t)a.scanner_pos[k] - a.map.pos[k])) <= lim && llabs((long long)(ev[k] - a.map.pos[k])) <= lim;
+            }
+            if (inside) r.pad |= RAY_SIMPLE;
+          }
 
           // Split of the ray.  A candidate is "free space" iff it is on-ray (positive weight) with value == +tau;
           // ALL candidates of a ray are of that kind while len < min(len_neg, distance - tau - slack): before len_neg
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
       e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
       bin = (uint32_t)(b * EL_BINS + e);
     }
-    r.pad |= (int32_t)(bin << 1);
+    r.pad |= (int32_t)(bin << 1); // bits 1 .. 14 (RAY_SIMPLE is bit 30)
     atomicAdd(&a.az_hist[bin], 1u);
     a.rays[ix] = r;
   }
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
 {
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix >= a.n) return;
-  const uint32_t bin = (uint32_t)a.rays[ix].pad >> 1;
+  const uint32_t bin = ((uint32_t)a.rays[ix].pad >> 1) & 0x3fffu;
   a.ray_order[a.az_off[bin] + atomicAdd(&a.az_hist[bin], 1u)] = ix;
 }
 
@@ -441,6 +459,9 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   const uint32_t total = min(s_cursor, ub_total);
   if (threadIdx.x == 0) a.tail_stats[blockIdx.x] = total;
   if (total == 0) return;
+#ifdef WS_EXP_TAIL_NOBIN
+  return;
+#endif
 
   // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
   // publish one run per tile.  If more tiles are touched than the hash holds, the rest is binned in further rounds.
@@ -572,63 +593,188 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fk_hash(unsigned long long idx, int32_t shift) { return (uint32_t)((idx * 0x9E3779B97F4A7C15ull) >> shift); }
 
+// what a free-space candidate does to its voxel (vx, vy, vz in world voxel coordinates, inside the window)
+__device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz)
+{
+  const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
+                sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+  const int64_t idx = storage_index(a.map, sx, sy, sz);
+  const uint8_t b = a.vstate[idx];
+  if (b & VOX_KEYED)
+  {
+    // the voxel also has ordered candidates (from the tails): this one takes part in the key order.  Only the
+    // earliest free-space candidate of a voxel can matter (a later one meets a state that is at least as final).
+    if (!(b & VOX_FREEHIT)) a.vstate[idx] = VOX_KEYED | VOX_FREEHIT;
+    const unsigned long long t = order_key(ix, k, 0);
+    uint32_t h = fk_hash((unsigned long long)idx, a.fk_shift);
+    bool done = false;
+    for (int p = 0; p < 128 && !done; ++p)
+    {
+      const unsigned long long cur = a.fk_keys[h];
+      unsigned long long old = cur;
+      if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
+      if (old == KEY_INF || old == (unsigned long long)idx)
+      {
+        atomicMin(&a.fk_vals[h], t);
+        done = true;
+      }
+      h = (h + 1) & a.fk_mask;
+    }
+    if (!done) raise_error(a.counters, a.status, ERR_CAPACITY);
+  }
+  else if (b == 0)
+  {
+    // free space only (the common case): the result will be (tau, 64) whoever comes first
+    a.vstate[idx] = VOX_TOUCHED;
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+    if (a.tile_dirty[tile] == 0) a.tile_dirty[tile] = 1;
+  }
+}
+
+constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
+
 // 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
-// so every lane has the same amount of work whatever the ray length.
+// so every lane has the same amount of work whatever the ray length.  Waves whose rays are all RAY_SIMPLE use the
+// compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
 __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 {
+  __shared__ u32x4 s_queue[4 * FREE_QCAP];
   const uint32_t ix = blockIdx.x * 8u + (threadIdx.x >> 5);
-  if (ix >= a.n) return;
   const int32_t c = (int32_t)(threadIdx.x & 31u);
-  const RaySetup r = a.rays[ix];
+  const int lane = threadIdx.x & 63;
+  RaySetup r;
+  r.steps = 0;
+  r.kfirst = 0;
+  r.pad = 0;
+  if (ix < a.n) r = a.rays[ix];
   const int32_t kend = min(r.steps, r.kfirst);
-  if (kend <= 0) return;
   const int32_t ch = (kend + 31) / 32;
   const int32_t k0 = c * ch;
   const int32_t k1 = min(k0 + ch, kend);
-  if (k0 >= k1) return;
+  const bool work = k0 < k1;
   const int32_t tau = a.tau;
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
-  march_steps<true>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-    // every candidate of these steps is free space: on the ray, further than tau from the hit point
-    if (!(positive && value == tau))
-    {
-      raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
-      return;
-    }
-    int32_t sx, sy, sz;
-    storage_coords(a.map, vx, vy, vz, sx, sy, sz);
-    const int64_t idx = storage_index(a.map, sx, sy, sz);
-    const uint8_t b = a.vstate[idx];
-    if (b & VOX_KEYED)
-    {
-      // the voxel also has ordered candidates (from the tails): this one takes part in the key order.  Only the
-      // earliest free-space candidate of a voxel can matter (a later one meets a state that is at least as final).
-      if (!(b & VOX_FREEHIT)) a.vstate[idx] = VOX_KEYED | VOX_FREEHIT;
-      const unsigned long long t = order_key(ix, k, step);
-      uint32_t h = fk_hash((unsigned long long)idx, a.fk_shift);
-      bool done = false;
-      for (int p = 0; p < 128 && !done; ++p)
+#ifdef WS_EXP_FORCE_OLD
+  if (true)
+#else
+  if (!__all(!work || (r.pad & RAY_SIMPLE)))
+#endif
+  {
+    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
+    if (!work) return;
+    march_steps<true>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+      // every candidate of these steps is free space: on the ray, further than tau from the hit point
+      if (!(positive && value == tau))
       {
-        const unsigned long long cur = a.fk_keys[h];
-        unsigned long long old = cur;
-        if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
-        if (old == KEY_INF || old == (unsigned long long)idx)
-        {
-          atomicMin(&a.fk_vals[h], t);
-          done = true;
-        }
-        h = (h + 1) & a.fk_mask;
+        raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
+        return;
       }
-      if (!done) raise_error(a.counters, a.status, ERR_CAPACITY);
-    }
-    else if (b == 0)
+      free_emit(a, f, ix, k, vx, vy, vz);
+    });
+    return;
+  }
+  if (!__any(work)) return;
+
+  // wave-private ring buffer: LDS operations of one wave are performed in order, so no barrier between push and pop
+  u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
+  uint32_t qhead = 0, qtail = 0;
+  const int32_t res = f.res, half = f.half, dist = r.distance;
+  AxisRun wx, wy, wz;
+  wx.r = wx.ar = wx.aq = wx.q = wx.spos = wx.sm = 0;
+  wx.gap = 0x3fffffff;
+  wy = wx;
+  wz = wx;
+  int32_t k = k0;
+  bool first = false; // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71)
+  if (work)
+  {
+    const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+    run_init(wx, f, r, r.dx, f.posx, kinit, true);
+    run_init(wy, f, r, r.dy, f.posy, kinit, true);
+    run_init(wz, f, r, r.dz, f.posz, kinit, false);
+    if (k0 == 0)
     {
-      // free space only (the common case): the result will be (tau, 64) whoever comes first
-      a.vstate[idx] = VOX_TOUCHED;
-      const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-      if (a.tile_dirty[tile] == 0) a.tile_dirty[tile] = 1;
+      const int32_t px = run_proj(wx, false, res), py = run_proj(wy, false, res);
+      first = div_trunc(px, f.rM, f.rK, res) != 0 || div_trunc(py, f.rM, f.rK, res) != 0;
     }
-  });
+  }
+  int32_t len = 1 + k * half;
+  int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
+  bool alive = work;
+  for (;;)
+  {
+    const bool any_alive = __any(alive);
+    if (any_alive)
+    {
+      // ---- sample phase
+      bool cand = false, cx = false, cy = false;
+      if (alive)
+      {
+        if (k == 0)
+        {
+          cand = first;
+        }
+        else
+        {
+          cx = run_step(wx, dist, res);
+          cy = run_step(wy, dist, res);
+          run_step_z(wz, dist);
+          cand = cx || cy;
+        }
+      }
+      const unsigned long long mask = __ballot(cand);
+      if (mask)
+      {
+        if (cand)
+        {
+          const int32_t px = run_proj(wx, cx, res), py = run_proj(wy, cy, res), pz = run_proj(wz, false, res);
+          const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0; no fan in the free-space part: delta_z * 2 < res
+          if (delta_z != last_dz)
+          {
+            last_dz = delta_z;
+            c0x = trunc_shift15(delta_z * r.ivx);
+            c0y = trunc_shift15(delta_z * r.ivy);
+            c0z = trunc_shift15(delta_z * r.ivz);
+          }
+          // target of the single on-ray candidate (update_tsdf.cu:103-112 with iter_steps == 1)
+          u32x4 e;
+          e.x = (uint32_t)(px - c0x);
+          e.y = (uint32_t)(py - c0y);
+          e.z = (uint32_t)(pz - c0z);
+          e.w = (uint32_t)k | ((uint32_t)lane << 16);
+          const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+          const uint32_t slot = (qtail + rank) & (FREE_QCAP - 1);
+          queue[slot] = e;
+        }
+        qtail += (uint32_t)__popcll(mask);
+      }
+      if (alive)
+      {
+        k += 1;
+        len += half;
+        alive = k < k1;
+      }
+    }
+    // ---- emit phase: 64 queued candidates, one per lane
+    const uint32_t cnt = qtail - qhead;
+    if (cnt >= 64 || (!any_alive && cnt > 0))
+    {
+      const uint32_t n = cnt < 64 ? cnt : 64;
+      u32x4 e = {0, 0, 0, 0};
+      if ((uint32_t)lane < n)
+      {
+        const uint32_t slot = (qhead + (uint32_t)lane) & (FREE_QCAP - 1);
+        e = queue[slot];
+      }
+      const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
+      if ((uint32_t)lane < n)
+      {
+        free_emit(a, f, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
+      }
+      qhead += n;
+    }
+    if (!any_alive && qtail == qhead) break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------

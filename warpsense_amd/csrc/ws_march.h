@@ -28,6 +28,9 @@ struct MarchFrame
   int32_t res, half, tau, weight_epsilon;
   uint64_t rM; // multiply-shift division by res
   int32_t rK;
+  uint32_t rM32; // the same constant as 32 bits (it is below 2^32 for every res >= 2) for v_mul_hi_u32
+  int32_t rS;    // rK - 32
+  int32_t ringK[3]; // offset - pos + size: storage coordinate = ring(v + ringK, size) (device_map.h:93-101)
   MapParams map;
 };
 __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos[3], int32_t res, int32_t tau, const MapParams &map)
@@ -43,6 +46,9 @@ __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos
   const FastDiv fd = make_fastdiv(res);
   f.rM = fd.M;
   f.rK = fd.k;
+  f.rM32 = (uint32_t)fd.M; // M = ceil(2^(31+l) / res) with 2^(l-1) < res <= 2^l: M < 2^32
+  f.rS = fd.k - 32;
+  for (int k = 0; k < 3; ++k) f.ringK[k] = (int32_t)((uint32_t)map.offset[k] - (uint32_t)map.pos[k] + (uint32_t)map.size[k]);
   f.map = map;
   return f;
 }
@@ -318,6 +324,103 @@ __device__ __forceinline__ void march_steps(const MarchFrame &f, const RaySetup 
     march_steps_fast<FREE_SPACE>(f, r, k0, k1, emit);
   else
     march_steps_direct(f, r, k0, k1, emit);
+}
+
+// trunc(x / res) for |x| < 2^31 with one v_mul_hi_u32
+__device__ __forceinline__ int32_t div_res(int32_t x, const MarchFrame &f)
+{
+  const uint32_t ax = (uint32_t)(x < 0 ? -x : x);
+  const uint32_t q = __umulhi(ax, f.rM32) >> f.rS;
+  return x < 0 ? -(int32_t)q : (int32_t)q;
+}
+// ring-buffer storage coordinate of a world voxel coordinate INSIDE the window: (v - pos + offset + size) mod size,
+// the sum being below 3 * size (device_map.h:14-30); min(x, x - size) in unsigned arithmetic subtracts size iff x >= size
+__device__ __forceinline__ int32_t ring_fast(int32_t v, int32_t ringK, int32_t size)
+{
+  uint32_t x = (uint32_t)(v + ringK);
+  x = min(x, x - (uint32_t)size);
+  x = min(x, x - (uint32_t)size);
+  return (int32_t)x;
+}
+
+// ---- compacting walk -----------------------------------------------------------------------------------------
+// The walks above do the per-sample arithmetic for all lanes and the per-candidate work for the lanes whose sample
+// entered a new voxel column — about half of them, at different samples in different lanes, so the expensive part runs
+// half empty.  The kernels therefore split the two: a SAMPLE phase that only advances the rays and pushes what a
+// candidate needs into a per-wave queue in LDS, and an EMIT phase that pops 64 entries at a time with every lane busy.
+// The sample phase needs no division and no multiplication:
+//   * |d| * len = q * dist + r is carried as before (len grows by res/2 per step);
+//   * the position along the direction of travel is a = s*pos + q (s = sign of d); `gap` counts the millimetres left
+//     before trunc(a / res) changes — the column test of update_tsdf.cu:71 becomes "gap <= 0".  Cells of the truncating
+//     division are res wide, except the one around zero ([-res+1, res-1]): entering it from below adds res - 1.
+// Only for rays marked RAY_SIMPLE by ray_setup_kernel: no int32 wrap (march_steps_fast's domain) AND the whole ray with
+// its fans stays inside the window, so the two in_bounds tests per candidate (update_tsdf.cu:73,113) are decided per ray.
+constexpr int32_t RAY_FAST = 1, RAY_SIMPLE = 1 << 30;
+
+struct AxisRun
+{
+  int32_t r, ar, aq; // |d| * len = q * dist + r; per-step increment of (q, r)
+  int32_t q;
+  int32_t gap;  // x, y only
+  int32_t spos; // s * pos
+  int32_t sm;   // 0 for d >= 0, -1 for d < 0: proj = ((spos + q) ^ sm) - sm
+};
+__device__ __forceinline__ void run_init(AxisRun &w, const MarchFrame &f, const RaySetup &r, int32_t d, int32_t pos, int32_t k, bool want_gap)
+{
+  const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+  w.sm = d < 0 ? -1 : 0;
+  w.spos = d < 0 ? -pos : pos;
+  const uint32_t inc = ad * (uint32_t)f.half;
+  w.aq = (int32_t)(((uint64_t)inc * r.div_m) >> r.div_k);
+  w.ar = (int32_t)(inc - (uint32_t)w.aq * (uint32_t)r.distance);
+  const uint32_t n = ad * (uint32_t)(1 + k * f.half);
+  w.q = (int32_t)(((uint64_t)n * r.div_m) >> r.div_k);
+  w.r = (int32_t)(n - (uint32_t)w.q * (uint32_t)r.distance);
+  w.gap = 0x3fffffff;
+  if (want_gap && ad != 0)
+  {
+    const int32_t a = w.spos + w.q;
+    const int32_t m = div_trunc(a < 0 ? -a : a, f.rM, f.rK, f.res); // |a| / res
+    const int32_t rem = (a < 0 ? -a : a) - m * f.res;
+    if (a >= 0)
+      w.gap = f.res - rem;
+    else
+      w.gap = m >= 1 ? rem + 1 : f.res - a;
+  }
+}
+// one sample; returns true if the truncated voxel index of this axis changed (x, y)
+__device__ __forceinline__ bool run_step(AxisRun &w, int32_t dist, int32_t res)
+{
+  w.r += w.ar;
+  int32_t dq = w.aq;
+  if (w.r >= dist)
+  {
+    w.r -= dist;
+    dq += 1;
+  }
+  w.q += dq;
+  w.gap -= dq;
+  const bool crossed = w.gap <= 0;
+  if (crossed) w.gap += res;
+  return crossed;
+}
+__device__ __forceinline__ void run_step_z(AxisRun &w, int32_t dist)
+{
+  w.r += w.ar;
+  int32_t dq = w.aq;
+  if (w.r >= dist)
+  {
+    w.r -= dist;
+    dq += 1;
+  }
+  w.q += dq;
+}
+// position of the sample on this axis (update_tsdf.cu:69); `fix_gap`: the axis crossed into the cell around zero
+__device__ __forceinline__ int32_t run_proj(AxisRun &w, bool crossed, int32_t res)
+{
+  const int32_t a = w.spos + w.q;
+  if (crossed && (uint32_t)(a + res - 1) < (uint32_t)(res - 1)) w.gap += res - 1; // a in [-res+1, -1]
+  return (a ^ w.sm) - w.sm;
 }
 
 // order key of a candidate: point(20) | ray step(16) | fan step(8)
