@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
 // ray tails -> records, sorted by tile inside the workgroup
 // ---------------------------------------------------------------------------------------------------------
 constexpr int HT_BITS = 10, HT_SLOTS = 1 << HT_BITS;
+constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
 constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DONE = 0xffffffffu;
 
 __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   __shared__ uint32_t s_cursor, s_base, s_ub, s_overflow, s_desc_base, s_round_total;
   __shared__ uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_cur[HT_SLOTS];
   __shared__ unsigned long long s_wave[4];
+  __shared__ u32x4 s_queue[4 * TAIL_QCAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n_sorted = a.az_off[AZ_BINS];
   const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
@@ -422,37 +424,162 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   const uint32_t ub_total = s_ub;
 
   // ---- phase 1: march, one record per scatter target
+  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
+  const bool mark = !a.all_keyed;
+  // one scatter target -> one record (vx, vy, vz: world voxel inside the window)
+  auto put_record = [&](uint32_t rix, int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+    const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
+                  sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+    // the free-space pass must know that this voxel takes part in the key order
+    if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
+    const uint32_t p = lds_append(&s_cursor);
+    if (p < ub_total)
+    {
+      u32x4 rec;
+      const uint64_t key = record_key(order_key(rix, k, step), value, positive);
+      rec.x = (uint32_t)key;
+      rec.y = (uint32_t)(key >> 32);
+      rec.z = tile_of(a.nty, a.ntz, sx, sy, sz);
+      rec.w = local_of(sx, sy, sz);
+      *reinterpret_cast<u32x4 *>(&a.rec_raw[base + p]) = rec;
+    }
+    else
+    {
+      raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
+    }
+  };
+  int32_t k0 = 0, k1 = 0;
   if (has_ray && r.steps > 0 && r.kfirst < r.steps)
   {
     const int32_t kbeg = r.kfirst, kend = r.steps;
     const int32_t ch = (kend - kbeg + 3) / 4;
-    const int32_t k0 = kbeg + wave * ch;
-    const int32_t k1 = min(k0 + ch, kend);
-    if (k0 < k1)
-    {
-      const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
-      const bool mark = !a.all_keyed;
+    k0 = kbeg + wave * ch;
+    k1 = min(k0 + ch, kend);
+  }
+  const bool work = k0 < k1;
+  if (!__all(!work || (r.pad & RAY_SIMPLE)))
+  {
+    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
+    if (work)
       march_steps<false>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-        int32_t sx, sy, sz;
-        storage_coords(a.map, vx, vy, vz, sx, sy, sz);
-        // the free-space pass must know that this voxel takes part in the key order
-        if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
-        const uint32_t p = lds_append(&s_cursor);
-        if (p < ub_total)
-        {
-          u32x4 rec;
-          const uint64_t key = record_key(order_key(ix, k, step), value, positive);
-          rec.x = (uint32_t)key;
-          rec.y = (uint32_t)(key >> 32);
-          rec.z = tile_of(a.nty, a.ntz, sx, sy, sz);
-          rec.w = local_of(sx, sy, sz);
-          *reinterpret_cast<u32x4 *>(&a.rec_raw[base + p]) = rec;
-        }
-        else
-        {
-          raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
-        }
+        put_record(ix, k, step, vx, vy, vz, value, positive);
       });
+  }
+  else if (__any(work))
+  {
+    // compacting walk (ws_march.h): the sample phase queues (position, step, ray) of every sample that enters a new
+    // voxel column; the emit phase pops 64 of them and does update_tsdf.cu:81-125 with every lane busy
+    u32x4 *queue = s_queue + wave * TAIL_QCAP;
+    uint32_t qhead = 0, qtail = 0;
+    const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
+    const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
+    AxisRun wx, wy, wz;
+    wx.r = wx.ar = wx.aq = wx.q = wx.spos = wx.sm = 0;
+    wx.gap = 0x3fffffff;
+    wy = wx;
+    wz = wx;
+    int32_t k = k0;
+    bool first = false; // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71)
+    if (work)
+    {
+      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+      run_init(wx, f, r, r.dx, f.posx, kinit, true);
+      run_init(wy, f, r, r.dy, f.posy, kinit, true);
+      run_init(wz, f, r, r.dz, f.posz, kinit, false);
+      if (k0 == 0) first = div_res(run_proj(wx, false, res), f) != 0 || div_res(run_proj(wy, false, res), f) != 0;
+    }
+    bool alive = work;
+    for (;;)
+    {
+      const bool any_alive = __any(alive);
+      if (any_alive)
+      {
+        // ---- sample phase
+        bool cand = false, cx = false, cy = false;
+        if (alive)
+        {
+          if (k == 0)
+          {
+            cand = first;
+          }
+          else
+          {
+            cx = run_step(wx, dist, res);
+            cy = run_step(wy, dist, res);
+            run_step_z(wz, dist);
+            cand = cx || cy;
+          }
+        }
+        const unsigned long long mask = __ballot(cand);
+        if (mask)
+        {
+          if (cand)
+          {
+            u32x4 e;
+            e.x = (uint32_t)run_proj(wx, cx, res);
+            e.y = (uint32_t)run_proj(wy, cy, res);
+            e.z = (uint32_t)run_proj(wz, false, res);
+            e.w = (uint32_t)k | ((uint32_t)lane << 16);
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
+          }
+          qtail += (uint32_t)__popcll(mask);
+        }
+        if (alive)
+        {
+          k += 1;
+          alive = k < k1;
+        }
+      }
+      // ---- emit phase: 64 queued samples, one per lane
+      const uint32_t cnt = qtail - qhead;
+      if (cnt >= 64 || (!any_alive && cnt > 0))
+      {
+        const uint32_t n = cnt < 64 ? cnt : 64;
+        u32x4 e = {0, 0, 0, 0};
+        const bool has = (uint32_t)lane < n;
+        if (has) e = queue[(qhead + (uint32_t)lane) & (TAIL_QCAP - 1)];
+        qhead += n;
+        // constants of the ray the sample belongs to (a lane of this wave)
+        const int src = (int)(e.w >> 16);
+        const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
+        const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
+        const int32_t s_dist = __shfl(r.distance, src, 64);
+        const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
+        if (has)
+        {
+          const int32_t ek = (int32_t)(e.w & 0xffffu);
+          const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
+          const int32_t len = 1 + ek * half;
+          // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
+          const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
+                        ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
+          int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
+          value = value < tau ? value : tau;
+          if (len > s_dist) value = -value;
+          if (!tsdf_weight_is_zero(value, tau, f.weight_epsilon))
+          {
+            // update_tsdf.cu:101-125
+            const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
+            int32_t iter_steps = 1, mid = 0;
+            if (delta_z * 2 >= res)
+            {
+              iter_steps = (int32_t)(__umulhi((uint32_t)(delta_z * 2), f.rM32) >> f.rS) + 1;
+              mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
+            }
+            const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
+                          lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
+            for (int32_t step = 0; step < iter_steps; ++step)
+            {
+              const int32_t sm = step * res;
+              const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
+                            vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
+              put_record(s_ix, ek, step, vx, vy, vz, value, step == mid);
+            }
+          }
+        }
+      }
+      if (!any_alive && qtail == qhead) break;
     }
   }
   __syncthreads();
