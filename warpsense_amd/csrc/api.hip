@@ -214,7 +214,7 @@ static int map_free(ws_map *m)
     }
   map_free_records(m);
   void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_order, m->rays, m->scan_dev, m->counters, m->tile_nruns,
-                  m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->fk_vals, m->block_stats, m->box_stage};
+                  m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -339,8 +339,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->block_sums, (size_t)m->scan_blocks * 4 * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->tile_dirty, 0, (size_t)m->n_tiles, s));
-  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * sizeof(unsigned long long)));
-  TRY(hipMalloc((void **)&m->fk_vals, (size_t)m->fk_slots * sizeof(unsigned long long)));
+  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * 2 * sizeof(unsigned long long))); // keys, then values
+  m->fk_vals = m->fk_keys + m->fk_slots;
   TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));

@@ -110,6 +110,17 @@ __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
   return (uint32_t)(((sx & ((1 << TILE_XB) - 1)) << (TILE_YB + TILE_ZB)) | ((sy & ((1 << TILE_YB) - 1)) << TILE_ZB) | (sz & ((1 << TILE_ZB) - 1)));
 }
 
+// everything the scatter expects to be zero / empty, in ONE launch (five memsets cost five launch gaps)
+__global__ __launch_bounds__(256) void scatter_prep_kernel(TsdfCounters *counters, uint32_t *az_hist, uint32_t n_hist, uint32_t *tile_nruns, int64_t n_tiles,
+                                                           unsigned long long *fk, int64_t n_fk)
+{
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(counters)[tid] = 0;
+  for (int64_t i = tid; i < n_hist; i += stride) az_hist[i] = 0;
+  for (int64_t i = tid; i < n_tiles; i += stride) tile_nruns[i] = 0;
+  for (int64_t i = tid; i < n_fk; i += stride) fk[i] = KEY_INF; // keys and values: one allocation
+}
+
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
 __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
 {
@@ -399,6 +410,11 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
     s_cursor = 0;
     s_overflow = 0;
   }
+  for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
+  {
+    ht_key[i] = HT_EMPTY;
+    ht_cnt[i] = 0;
+  }
   if (wave == 0)
   {
     unsigned long long ub = has_ray ? r.ub : 0u;
@@ -440,7 +456,14 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
       rec.x = (uint32_t)key;
       rec.y = (uint32_t)(key >> 32);
       rec.z = tile_of(a.nty, a.ntz, sx, sy, sz);
-      rec.w = local_of(sx, sy, sz);
+      // the workgroup's tile histogram is built on the fly (the slot travels in the record); a full table defers
+      // the record to the extra rounds of phase 2
+      const int slot = ht_insert(ht_key, rec.z);
+      if (slot >= 0)
+        atomicAdd(&ht_cnt[slot], 1u);
+      else
+        s_overflow = 1;
+      rec.w = local_of(sx, sy, sz) | ((uint32_t)(slot >= 0 ? slot : HT_SLOTS) << 10);
       *reinterpret_cast<u32x4 *>(&a.rec_raw[base + p]) = rec;
     }
     else
@@ -593,35 +616,39 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
   // publish one run per tile.  If more tiles are touched than the hash holds, the rest is binned in further rounds.
   uint32_t round_base = 0;
-  for (;;)
+  for (int round = 0;; ++round)
   {
-    for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
+    if (round > 0)
     {
-      ht_key[i] = HT_EMPTY;
-      ht_cnt[i] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
-    {
-      uint32_t tile[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
+      // records the table of the previous round had no room for
+      for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
       {
-        const uint32_t i = i0 + (uint32_t)u * 256u;
-        tile[u] = i < total ? a.rec_raw[base + i].tile : REC_DONE;
+        ht_key[i] = HT_EMPTY;
+        ht_cnt[i] = 0;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
+      __syncthreads();
+      for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
       {
-        if (tile[u] == REC_DONE) continue;
-        const int s = ht_insert(ht_key, tile[u]);
-        if (s < 0)
-          s_overflow = 1;
-        else
-          atomicAdd(&ht_cnt[s], 1u);
+        uint32_t tile[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+          const uint32_t i = i0 + (uint32_t)u * 256u;
+          tile[u] = i < total ? a.rec_raw[base + i].tile : REC_DONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+          if (tile[u] == REC_DONE) continue;
+          const int s = ht_insert(ht_key, tile[u]);
+          if (s < 0)
+            s_overflow = 1;
+          else
+            atomicAdd(&ht_cnt[s], 1u);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     // exclusive scan over the slots: records (low word) and runs (high word) together
     uint32_t c[4];
     unsigned long long mine = 0;
@@ -700,9 +727,15 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
       for (int u = 0; u < 4; ++u)
       {
         if (rec[u].z == REC_DONE) continue;
-        const int s = ht_find(ht_key, rec[u].z);
+        // round 0: the slot was found when the record was written; later rounds look the tile up again
+        int s = (int)(rec[u].w >> 10);
+        if (round > 0)
+          s = ht_find(ht_key, rec[u].z);
+        else if (s >= HT_SLOTS)
+          s = -1;
         if (s < 0) continue; // next round
         const uint32_t p = atomicAdd(&ht_cur[s], 1u);
+        rec[u].w &= (uint32_t)(TILE_VOXELS - 1);
         *reinterpret_cast<u32x4 *>(&a.rec_sorted[base + round_base + p]) = rec[u];
         if (more) a.rec_raw[base + i0 + (uint32_t)u * 256u].tile = REC_DONE;
       }
@@ -920,6 +953,7 @@ struct TileScanArgs
   uint32_t *block_sums; // [blocks][2] (runs, listed), then [blocks][2] their exclusive scan
   uint32_t n_blocks;
   int64_t n_tiles;
+  int32_t nty, ntz;
   TsdfCounters *counters;
 };
 
@@ -1035,7 +1069,10 @@ __global__ __launch_bounds__(256) void tile_list_kernel(TileScanArgs a)
     e.tile = (uint32_t)t;
     e.desc_begin = run_off;
     e.nruns = nr[j];
-    e.pad = 0;
+    e.tz = (int32_t)((uint32_t)t % (uint32_t)a.ntz);
+    e.ty = (int32_t)(((uint32_t)t / (uint32_t)a.ntz) % (uint32_t)a.nty);
+    e.tx = (int32_t)((uint32_t)t / ((uint32_t)a.ntz * (uint32_t)a.nty));
+    e.pad[0] = e.pad[1] = 0;
     a.tile_list[list_off] = e;
     run_off += nr[j];
     list_off += 1;
@@ -1078,7 +1115,8 @@ struct ResolveArgs
   MapParams map;
   int32_t nty, ntz;
   int32_t tau, max_weight;
-  FastDiv wdiv;      // division by tau - tau/10 of the weight ramp (update_tsdf.cu:92)
+  uint32_t wM32;     // division by tau - tau/10 of the weight ramp (update_tsdf.cu:92) as one v_mul_hi_u32 + shift
+  int32_t wS;
   uint32_t desc_cap; // entries of sorted_desc
   uint32_t *resolve_stats; // [grid][2]: contested voxels, free-space hits on keyed voxels
   TsdfCounters *counters;
@@ -1156,7 +1194,7 @@ struct TilePost
 // bytes and descriptors of later tiles and the records of the next tile are all requested together at the END of an
 // iteration, and the stores of a tile are issued right AFTER the next wait, so they drain under the LDS phases.
 template <bool HAS_S0, bool FUSED>
-__global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
+__global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
 {
   __shared__ unsigned long long kpos[TILE_VOXELS];
   __shared__ unsigned long long kneg[TILE_VOXELS];
@@ -1190,10 +1228,7 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
 
   // all loads unconditional (clamped addresses, results masked)
   auto request = [&](const TileEntry &te, TilePre &p) {
-    const int32_t tz = (int32_t)(te.tile % (uint32_t)a.ntz);
-    const int32_t ty = (int32_t)((te.tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
-    const int32_t tx = (int32_t)(te.tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
-    const int32_t sx = (tx << TILE_XB) + lx, sy = (ty << TILE_YB) + ly, sz = (tz << TILE_ZB) + z0;
+    const int32_t sx = (te.tx << TILE_XB) + lx, sy = (te.ty << TILE_YB) + ly, sz = (te.tz << TILE_ZB) + z0;
     const bool col_ok = sx < a.map.size[0] && sy < a.map.size[1];
     int nz = a.map.size[2] - sz;
     p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
@@ -1215,6 +1250,12 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
     if (FUSED) e4 = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
     p.s0[0] = s4.x; p.s0[1] = s4.y; p.s0[2] = s4.z; p.s0[3] = s4.w;
     p.existing[0] = e4.x; p.existing[1] = e4.y; p.existing[2] = e4.z; p.existing[3] = e4.w;
+  };
+  // weight ramp of update_tsdf.cu:90-94; 64 * (tau + value) >= 0 is below 2^31
+  auto weight_of = [&](int32_t value) -> int32_t {
+    int32_t w = WEIGHT_RESOLUTION;
+    if (value < -weight_epsilon) w = (int32_t)(__umulhi((uint32_t)(WEIGHT_RESOLUTION * (a.tau + value)), a.wM32) >> a.wS);
+    return w;
   };
   auto init_lds = [&]() {
 #pragma unroll
@@ -1423,7 +1464,7 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
         // no positive candidate is accepted: the negatives fold to the smallest |value|, latest on ties
         const int32_t an = (int32_t)(N >> 45);
         const int32_t v = (N & 1ull) ? -an : an;
-        return pack_entry(v, -tsdf_weight(v, a.tau, weight_epsilon, a.wdiv));
+        return pack_entry(v, -weight_of(v));
       };
 
       // ---- pass 1: earliest positive, smallest negative per voxel
@@ -1489,7 +1530,7 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
             if (N != KEY_INF && ap > (uint32_t)(N >> 45)) n_contested += 1; // a negative candidate COULD have blocked it
             if (ap <= m)
             {
-              entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon, a.wdiv));
+              entry[j] = pack_entry(vp, weight_of(vp));
             }
             else
             {
@@ -1571,7 +1612,7 @@ __global__ __launch_bounds__(256) void tile_resolve_kernel(ResolveArgs a)
             const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
             if (ap <= mstate[l0 + j])
             {
-              entry[j] = pack_entry(vp, tsdf_weight(vp, a.tau, weight_epsilon, a.wdiv));
+              entry[j] = pack_entry(vp, weight_of(vp));
               unres &= ~(1u << j);
               mstate[l0 + j] = M_IDLE;
             }
@@ -1678,10 +1719,8 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
   const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
   for (uint32_t e = blockIdx.x; e < n_list; e += gridDim.x)
   {
-    const uint32_t tile = a.tile_list[e].tile;
-    const int32_t tz = (int32_t)(tile % (uint32_t)a.ntz);
-    const int32_t ty = (int32_t)((tile / (uint32_t)a.ntz) % (uint32_t)a.nty);
-    const int32_t tx = (int32_t)(tile / ((uint32_t)a.ntz * (uint32_t)a.nty));
+    const TileEntry te = a.tile_list[e];
+    const int32_t tx = te.tx, ty = te.ty, tz = te.tz;
     const int32_t sx = (tx << TILE_XB) + lx, sy = (ty << TILE_YB) + ly, sz = (tz << TILE_ZB) + z0;
     if (sx >= a.map.size[0] || sy >= a.map.size[1]) continue;
     int nz = a.map.size[2] - sz;
@@ -1846,10 +1885,13 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
-  WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, last_records), s));
   m->fused_done = false;
   m->tail_blocks = 0;
-  if (n == 0) return WS_OK;
+  if (n == 0)
+  {
+    WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, last_records), s));
+    return WS_OK;
+  }
 
   const bool s0 = !m->new_is_default;
   ScatterArgs sa;
@@ -1906,13 +1948,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   m->tail_blocks = grid_tail.x;
 
   prof_begin(ctx, WS_K_SETUP);
-  WS_HIP(hipMemsetAsync(m->az_hist, 0, (AZ_BINS + 1) * sizeof(uint32_t), s)); // the scatter pass leaves its cursors there
-  WS_HIP(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
-  if (!s0)
-  {
-    WS_HIP(hipMemsetAsync(m->fk_keys, 0xff, (size_t)m->fk_slots * sizeof(unsigned long long), s));
-    WS_HIP(hipMemsetAsync(m->fk_vals, 0xff, (size_t)m->fk_slots * sizeof(unsigned long long), s));
-  }
+  // (az_hist: the direction sort leaves its cursors there; fk: keys followed by values in one allocation)
+  hipLaunchKernelGGL(scatter_prep_kernel, dim3(512), block, 0, s, m->counters, m->az_hist, (uint32_t)(AZ_BINS + 1), m->tile_nruns, m->n_tiles,
+                     m->fk_keys, s0 ? (int64_t)0 : (int64_t)2 * m->fk_slots);
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
   hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, s, m->az_hist, m->az_off);
   hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
@@ -1937,6 +1975,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ta.block_sums = m->block_sums;
   ta.n_blocks = m->scan_blocks;
   ta.n_tiles = m->n_tiles;
+  ta.nty = m->nty;
+  ta.ntz = m->ntz;
   ta.counters = m->counters;
   hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
   hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
@@ -1961,7 +2001,11 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.ntz = m->ntz;
   ra.tau = m->tau;
   ra.max_weight = m->max_weight;
-  ra.wdiv = make_fastdiv(m->tau - m->tau / 10);
+  {
+    const FastDiv wd = make_fastdiv(m->tau - m->tau / 10);
+    ra.wM32 = (uint32_t)wd.M;
+    ra.wS = wd.k - 32;
+  }
   ra.desc_cap = m->desc_cap;
   ra.resolve_stats = m->block_stats + WS_TAIL_STATS;
   ra.counters = m->counters;

@@ -66,12 +66,13 @@ struct RunDesc // 16 bytes
   uint32_t start;
   uint32_t pad;
 };
-struct TileEntry // 16 bytes: one touched tile of the scan in flight
+struct TileEntry // 32 bytes: one touched tile of the scan in flight
 {
   uint32_t tile;
   uint32_t desc_begin; // its runs: sorted_desc[desc_begin .. desc_begin + nruns)
   uint32_t nruns;
-  uint32_t pad;
+  int32_t tx, ty, tz;  // tile coordinates (so that 256 threads per tile do not divide the tile id again)
+  uint32_t pad[2];
 };
 
 struct TsdfCounters // device-resident, zeroed at the start of every scatter
