@@ -123,9 +123,10 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers).  The default (32 Mi) holds a
- * 131 072-point scan at 50 mm; the buffers grow by themselves before a scan when the PREVIOUS scan needed more, so only
- * the first scan of a much larger kind can overflow (WS_ERR_CAPACITY, sticky).  Reserve up front to rule that out. */
+/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers; default 32 Mi).  The FIRST scan of a map
+ * synchronises once after its set-up pass and sizes the buffers for what that scan needs; later scans grow them from the
+ * previous scan's need without waiting, so only a scan much larger than its predecessor can overflow (WS_ERR_CAPACITY,
+ * sticky).  Reserving up front rules that out and skips the first-scan synchronisation. */
 int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
 
 typedef struct

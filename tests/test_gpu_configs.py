@@ -1,0 +1,124 @@
+"""BASELINE.json configs[2] and configs[4] at their real map sizes.
+
+configs[2]: a stream through the replay App on the 1025^3 sliding map @ 50 mm with a map shift in it — the final window
+and every pose against the same cloud_callback / map_shift sequence driven through the CPU oracle.
+configs[4]: the 2049^3 map @ 20 mm (8.6e9 voxels, voxel indices beyond 2^32): the oracle cannot hold it, so the test uses
+the size-independent property that the same scans give the same voxels in a 1025^3 map wherever the windows overlap,
+across a map shift, plus an export of a slab of the big window to the .h5 file against the small map's voxels.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_host_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        return 0.0
+
+
+def _free_gpu_gb():
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    return free / 2 ** 30
+
+
+def test_config2_stream_on_the_1025_sliding_map():
+    import test_gpu_replay as R
+    import warpsense_amd as W
+    if _free_host_gb() < 48 or _free_gpu_gb() < 24:
+        pytest.skip("needs ~48 GB of host memory (oracle maps) and ~24 GB on the GPU")
+    tau, res, mw, size = 1000, 50, 640, (1024, 1024, 1024)
+    reg = (200, 0.1, 0.03)
+    shift_m = 0.45
+    params = W.Params(W.MapParams(resolution=res, max_distance=tau / 1000.0, max_weight=mw // 64, size=tuple(s * res / 1000.0 for s in size),
+                                  shift=shift_m), W.RegistrationParams(*reg))
+    # sensor moving through a 20 x 16 x 5 m room (the benchmark room), 64 x 512 rays per scan
+    clouds = []
+    for k in range(7):
+        sensor = np.array([k * 220.0, 0.4 * k * 220.0, 0.0])
+        pts = S.os1_128_scan(sensor_mm=tuple(sensor), rings=64, azimuths=512, seed=300 + k)
+        clouds.append(((pts.astype(np.float64) - sensor) / 1000.0).astype(np.float32))
+    app = W.App(params, None)
+    for c in clouds:
+        app.cloud_callback(c)
+    app.gpu_.ctx.sync() if hasattr(app.gpu_, "ctx") else W.pause()
+    want_poses, want_its, want_updates, want_shifts, om = R.oracle_replay(clouds, app.hdf5_local_map_.size, tau, mw, res, reg, shift_m)
+    assert app.n_updates == want_updates >= 2 and app.n_shifts == want_shifts >= 1
+    assert [t["iterations"] for t in app.timings] == want_its
+    for got, want in zip(app.poses, want_poses):
+        assert np.linalg.norm(got[:3, 3] - want[:3, 3]) / 1000.0 < 1e-4
+        assert R._angle(got[:3, :3], want[:3, :3]) < 1e-4
+    if all(np.array_equal(g, w) for g, w in zip(app.poses, want_poses)):
+        lm = app.hdf5_local_map_
+        host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+        app.gpu_.tsdf().avg_map().to_host(host)
+        assert list(host.pos_) == list(om.pos) and list(host.offset_) == list(om.offset)
+        assert np.array_equal(host.data_, om.data)
+        assert int(np.count_nonzero(host.data_ != O.pack(tau, 0))) > 5_000_000
+    st = app.gpu_.tsdf().stats()
+    assert st["error_flags"] == 0
+
+
+def test_config4_2049_map_at_20mm_equals_1025_map_on_the_overlap(tmp_path):
+    import torch
+    import warpsense_amd as W
+    from warpsense_amd import build
+    if _free_gpu_gb() < 110 or _free_host_gb() < 24:
+        pytest.skip("needs ~110 GB on the GPU (2049^3: two maps of 34.4 GB + 8.6 GB of voxel bytes + the 1025^3 twin)")
+    tau, res, mw = 1000, 20, 640
+    room = (10_000.0, 8_000.0, 2_500.0)  # 1000 x 800 x 250 voxels at 20 mm: fits the small window
+    shift = (7, -5, 3)
+    sensors = [(0.0, 0.0, 0.0), (shift[0] * res + 4.0, shift[1] * res + 9.0, shift[2] * res + 2.0)]
+    scans = [S.os1_128_scan(sensor_mm=s, half_extents_mm=room, seed=900 + k) for k, s in enumerate(sensors)]
+    boxes = {}
+    stats = {}
+    export = None
+    for name, msize in (("small", 1024), ("big", 2048)):
+        size = (msize,) * 3
+        mp = W.MapParams(resolution=res, max_distance=tau / 1000.0, max_weight=mw // 64, size=tuple(s * res / 1000.0 for s in size))
+        h5 = None
+        if name == "big" and build.find_hdf5() is not None and build.build_h5():
+            h5 = str(tmp_path / "big.h5")
+        g = W.GlobalMap(tau, 0, filename=h5, map_params=mp if h5 else None)
+        lm = W.LocalMap(*size, tau, 0, g, host_voxels=False)  # 8.6e9 voxels do not belong in host memory
+        tm = W.TSDFMapping(W.Params(mp), lm)
+        pos0 = [int(np.floor(np.float32(v) / np.float32(res))) for v in sensors[0]]
+        tm.update_tsdf(torch.from_numpy(scans[0]).cuda(), pos_rm=pos0, up_rm=(0, 0, 32768))
+        tm.shift_map(shift)
+        pos1 = [int(np.floor(np.float32(v) / np.float32(res))) for v in sensors[1]]
+        tm.update_tsdf(torch.from_numpy(scans[1]).cuda(), pos_rm=pos1, up_rm=(0, 0, 32768))
+        st = tm.tsdf().stats()
+        assert st["error_flags"] == 0, st
+        stats[name] = st
+        # compared region: inside BOTH windows after the shift, minus the outermost layers (a ray step whose on-ray voxel
+        # is outside the window is skipped together with its in-window fan voxels, update_tsdf.cu:78)
+        half_small = 1025 // 2 - 12
+        lo = (shift[0] - half_small, shift[1] - half_small, shift[2] - 160)
+        hi = (shift[0] + half_small, shift[1] + half_small, shift[2] + 160)
+        boxes[name] = tm.tsdf().avg_map().extract_box(lo, hi)
+        if name == "small":
+            chunk_ref = tm.tsdf().avg_map().extract_box((0, 0, 0), (63, 63, 63))  # world chunk (0, 0, 0)
+        if h5:
+            # H5 export of part of the big window (configs[4] names the export): the eight 64^3 chunks around the origin
+            tm.write_back(box_lo=(-64, -64, -64), box_hi=(63, 63, 63))
+            g.close()
+            export = h5
+        tm.tsdf().close()
+        del tm
+        torch.cuda.empty_cache()
+    # (the small window cuts the last metre of the rays that end near its border, so it sees fewer targets)
+    assert stats["big"]["records"] >= stats["small"]["records"] > 10_000_000
+    assert np.array_equal(boxes["small"], boxes["big"])
+    assert int(np.count_nonzero(boxes["big"] != O.pack(tau, 0))) > 50_000_000
+    if export:
+        g2 = W.GlobalMap(tau, 0, filename=export, open_existing=True)
+        assert np.array_equal(g2.activate_chunk(0, 0, 0), chunk_ref)
+        assert int(np.count_nonzero(chunk_ref != O.pack(tau, 0))) > 50_000
+        g2.close()

@@ -316,12 +316,14 @@ class LocalMap:
     shift() moves the window, saving the slabs that leave to the global map and loading the ones that enter
     (:53-118).  Owns the host arrays a DeviceMap views."""
 
-    def __init__(self, sx, sy, sz, default_value, default_weight=0, global_map: GlobalMap | None = None):
+    def __init__(self, sx, sy, sz, default_value, default_weight=0, global_map: GlobalMap | None = None, host_voxels: bool = True):
         self.size = np.array([s if s % 2 == 1 else s + 1 for s in (int(sx), int(sy), int(sz))], dtype=np.int32)
         self.pos = np.zeros(3, dtype=np.int32)
         self.offset = (self.size // 2).astype(np.int32)
         self.map_ = global_map or GlobalMap(default_value, default_weight)
-        self.data = np.full(int(np.prod(self.size.astype(np.int64))), self.map_.default_raw, dtype=np.uint32)
+        # host_voxels=False: the window lives on the device only (a 2049^3 window is 34 GB; the device-side shift and
+        # export never need the host copy)
+        self.data = np.full(int(np.prod(self.size.astype(np.int64))), self.map_.default_raw, dtype=np.uint32) if host_voxels else None
 
     def device_map(self) -> DeviceMap:
         return DeviceMap(self.size, self.offset, self.data, self.pos)
@@ -752,16 +754,21 @@ class TSDFMapping:
                 avg.insert_box(start, end, lm.map_.load_box(start, end))
 
 
-    def write_back(self):
+    def write_back(self, box_lo=None, box_hi=None):
         """HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:220) from the
         DEVICE map: every 64^3 chunk the window overlaps is gathered out of the ring buffer by the GPU
         (ws_map_extract_box: chunk layout, x major / z fastest), merged into the global map's chunk and written to
-        its file.  The reference downloads the whole window and copies voxel by voxel on the host."""
+        its file.  The reference downloads the whole window and copies voxel by voxel on the host.
+        box_lo / box_hi (inclusive world voxels) restrict the export to a part of the window."""
         lm, avg = self.local_map_, self.tsdf_.avg_map()
         cs = GlobalMap.CHUNK_SIZE
         with self.mutex_:
             half = lm.size.astype(np.int64) // 2
             lo, hi = lm.pos.astype(np.int64) - half, lm.pos.astype(np.int64) + half
+            if box_lo is not None:
+                lo = np.maximum(lo, np.asarray(box_lo, dtype=np.int64))
+            if box_hi is not None:
+                hi = np.minimum(hi, np.asarray(box_hi, dtype=np.int64))
             # one gather per 64-voxel-thick x slab of chunks (a few large device->host copies instead of one small one
             # per chunk); save_box cuts the slab into its chunks
             for cx in range(int(np.floor_divide(lo[0], cs)), int(np.floor_divide(hi[0], cs)) + 1):

@@ -497,6 +497,7 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  m->capacity_known = true; // the caller decides: no sizing synchronisation on the first scan
   return map_alloc_records(m, records);
 }
 
@@ -954,3 +955,8 @@ int ws_prof_reset(ws_context *ctx)
 }
 
 } // extern "C"
+
+namespace ws
+{
+int resize_records(ws_map *m, uint64_t records) { return map_alloc_records(m, records); }
+} // namespace ws

@@ -1955,6 +1955,26 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, s, m->az_hist, m->az_off);
   hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
   prof_end(ctx, WS_K_SETUP);
+  if (!m->capacity_known)
+  {
+    // first scan of this map: nothing is known about what its scans need.  One synchronisation, once: read the sum of
+    // the per-ray record bounds the set-up pass has just computed and size the buffers for it.  Later scans use the
+    // previous scan's need as the hint (grow_for_next_scan), without waiting.
+    unsigned long long need = 0;
+    WS_HIP(hipMemcpyAsync(&need, &m->counters->ub_total, sizeof need, hipMemcpyDeviceToHost, s));
+    WS_HIP(hipStreamSynchronize(s));
+    m->capacity_known = true;
+    if (need + need / 8 > m->rec_cap)
+    {
+      const int rc = resize_records(m, need + need / 4);
+      if (rc != WS_OK) return rc;
+      sa.rec_raw = m->rec_raw;
+      sa.rec_sorted = m->rec_sorted;
+      sa.rec_cap = m->rec_cap;
+      sa.desc = m->desc;
+      sa.desc_cap = m->desc_cap;
+    }
+  }
 
   prof_begin(ctx, WS_K_MARCH_TAILS);
   hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);

@@ -168,6 +168,7 @@ struct ws_map
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
   uint32_t tail_blocks = 0;        // workgroups of the last tail march
   bool fused_done = false;         // the last scatter already integrated into avg_map
+  bool capacity_known = false;     // a scan has told what the record buffers must hold
   ws::TsdfCounters *counters = nullptr;
   ws::TsdfCounters *counters_host = nullptr; // pinned
   uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [2..3] capacity hint (u64)
@@ -238,6 +239,7 @@ void prof_end(ws_context *ctx, int cls);
 // launchers implemented in the .hip files
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
+int resize_records(ws_map *m, uint64_t records); // api.hip: (re)allocate the candidate-record buffers
 uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
 int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
