@@ -45,7 +45,7 @@ typedef enum
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
   WS_ERR_CAPACITY = -4,    /* candidate-record buffers exhausted: a TSDF update is not exact (sticky, see below) */
   WS_ERR_RANGE = -5,       /* ray too long for the order key; the ray was dropped (sticky)       */
-  WS_ERR_TIMEOUT = -6,     /* the resident registration loop could not get the whole GPU */
+  WS_ERR_TIMEOUT = -6,     /* (kept for ABI stability: ws_register_cloud now retries with one launch per iteration) */
   WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
 } ws_status;
 
@@ -107,6 +107,27 @@ int ws_map_download(ws_map *map, int which, int32_t size[3], int32_t pos[3], int
  * (exactly the three steps of HDF5LocalMap::shift: save, move window, load).  Both synchronise. */
 int ws_map_extract_box(ws_map *map, int which, const int32_t lo[3], const int32_t hi[3], uint32_t *host_out);
 int ws_map_insert_box(ws_map *map, int which, const int32_t lo[3], const int32_t hi[3], const uint32_t *host_in);
+/* The same shift OFF the scan path (in the reference TSDFMapping::map_shift runs on its own thread and only blocks the
+ * scans while it swaps the maps, tsdf_mapping.cpp:97-136).  ws_shift_begin is stream-ordered on the map's stream and
+ * returns without waiting: per axis (x, y, z, like HDF5LocalMap::shift) the slab of avg_map that leaves the window is
+ * packed into a device staging buffer, pos/offset of BOTH device maps move, and the slab that enters is filled with
+ * `fill_entry` (the global map's default entry).  The staged slabs then travel to pinned host memory on a SECOND stream
+ * while the next scans already run against the new window.  The caller
+ *   - overwrites, with ws_map_insert_box, those parts of the entering slabs the global map already holds (revisits),
+ *   - and, typically on a worker thread: ws_shift_wait (blocks on the second stream only), ws_shift_slab for each
+ *     leaving slab -> global map, ws_shift_end.
+ * One shift can be in flight per map: ws_shift_begin fails with WS_ERR_INVALID while a ticket is open. */
+typedef struct ws_shift ws_shift;
+int ws_shift_begin(ws_map *map, const int32_t new_pos[3], uint32_t fill_entry, ws_shift **out);
+/* staging (device + pinned host) for shifts of up to `voxels` leaving voxels, so that no shift has to allocate */
+int ws_shift_reserve(ws_map *map, uint64_t voxels);
+int ws_shift_count(const ws_shift *shift);                                              /* slabs: 0 .. 3 */
+int ws_shift_entering(const ws_shift *shift, int i, int32_t lo[3], int32_t hi[3]);      /* box filled with fill_entry (world voxels) */
+int ws_shift_wait(ws_shift *shift);                                                     /* the host copies are complete */
+int ws_shift_slab(const ws_shift *shift, int i, int32_t lo[3], int32_t hi[3], const uint32_t **host_data); /* after ws_shift_wait */
+int ws_shift_end(ws_shift *shift);
+/* the ring-buffer parameters the kernels currently use for `which` (no synchronisation; any of the outputs may be NULL) */
+int ws_map_get_params(const ws_map *map, int which, int32_t size[3], int32_t pos[3], int32_t offset[3]);
 /* device pointer of the voxel array (uint32 per voxel, z fastest) — what DeviceMap::data_ is on the device */
 void *ws_map_device_data(ws_map *map, int which);
 int64_t ws_map_n_voxels(const ws_map *map);
@@ -151,6 +172,9 @@ int ws_reg_destroy(ws_reg *reg);
 /* RegistrationCuda::prepare_registration — registration.cu:303-308 */
 int ws_reg_prepare(ws_reg *reg, const int32_t *xyz_host, size_t n);
 int ws_reg_prepare_dev(ws_reg *reg, const int32_t *xyz_dev, size_t n); /* device-to-device copy */
+/* the registration's own copy of the prepared cloud (device memory, n x 3 int32) and its point count; the pointer
+ * changes when a larger cloud makes the buffer grow (callers that capture kernels into HIP graphs key on it) */
+const int32_t *ws_reg_points_dev(const ws_reg *reg, size_t *n);
 /* RegistrationCuda::perform_registration — registration.cu:347-368. T, h column-major. Synchronises. */
 int ws_reg_iterate(ws_reg *reg, const ws_map *map, const float T[16], int32_t map_resolution, uint32_t flags,
                    int64_t h[36], int64_t g[6], int32_t *e, int32_t *c);

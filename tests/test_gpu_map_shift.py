@@ -126,3 +126,49 @@ def test_write_back_exports_device_map_to_h5(tmp_path):
     for key in in_file - set(ref_g.chunks):
         assert np.all(g2.activate_chunk(*key) == W.pack_entry(tau, 0)), key
     g2.close()
+
+
+def test_async_shift_equals_synchronous_shift():
+    """TSDFMapping.shift_map_async (window moved by device kernels inside the call, leaving slabs filed by a worker
+    thread) == shift_map, for a path that leaves a region and comes back to it (revisited chunks are uploaded again),
+    with diagonal moves (a corner that enters with x leaves again with y in the same shift)."""
+    W, tm_a, dev_a, host_lm = _maps((21, 17, 13), seed=5)
+    _, tm_s, dev_s, _ = _maps((21, 17, 13), seed=5)
+    for new_pos in [(3, 0, 0), (3, -4, 2), (10, 5, -3), (-2, -6, 4), (0, 0, 0), (7, 7, 7), (0, 0, 0)]:
+        tm_a.shift_map_async(new_pos)
+        tm_s.shift_map(new_pos)
+        host_lm.shift(new_pos)
+        got_a, got_s = _download(W, tm_a, dev_a), _download(W, tm_s, dev_s)
+        assert list(got_a.pos_) == list(host_lm.pos) and list(got_a.offset_) == list(host_lm.offset)
+        assert np.array_equal(got_s.data_, host_lm.data), new_pos
+        assert np.array_equal(got_a.data_, host_lm.data), new_pos
+    tm_a.wait_shift()
+    # both global maps hold the same chunks
+    ga, gs = dev_a.map_, dev_s.map_
+    assert set(ga.chunks) == set(gs.chunks)
+    for key in gs.chunks:
+        assert np.array_equal(ga.chunks[key], gs.chunks[key]), key
+
+
+def test_async_shift_does_not_stall_the_stream():
+    """a scan enqueued right after shift_map_async runs against the moved window and gives the same map as after the
+    synchronous shift"""
+    import torch
+    import warpsense_amd as W
+    tau, res, mw, size = 1000, 50, 640, (64, 64, 32)
+    outs = []
+    for asyn in (False, True):
+        lm = W.LocalMap(*size, tau, 0)
+        params = W.Params(W.MapParams(resolution=res, max_distance=1.0, max_weight=10, size=tuple(s * res / 1000.0 for s in size)))
+        tm = W.TSDFMapping(params, lm)
+        for k, pos in enumerate([(0, 0, 0), (5, -3, 2), (9, 1, 2)]):
+            if k:
+                (tm.shift_map_async if asyn else tm.shift_map)(pos)
+            sensor = (pos[0] * res + 10, pos[1] * res + 7, pos[2] * res + 3)
+            pts = S.os1_128_scan(sensor_mm=sensor, rings=16, azimuths=128, half_extents_mm=(1400.0, 1300.0, 700.0), seed=4 + k)
+            pts = (pts.astype(np.int64)).astype(np.int32)
+            tm.update_tsdf(torch.from_numpy(pts).cuda(), pos_rm=list(pos), up_rm=(0, 0, 32768))
+        tm.wait_shift()
+        outs.append(_download(W, tm, lm).data_.copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert int(np.count_nonzero(outs[0] != W.pack_entry(tau, 0))) > 10_000

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--shift", type=float, default=5.0, help="map shift distance in metres (map/shift)")
     ap.add_argument("--room", type=float, nargs=3, default=(22.0, 16.0, 2.5), help="half extents of the room in metres")
     ap.add_argument("--h5", default=None)
+    ap.add_argument("--async-shift", action="store_true", help="map shift off the scan path (TSDFMapping.shift_map_async)")
     args = ap.parse_args()
     import warpsense_amd as W
     from warpsense_amd import synthetic as S
@@ -34,7 +35,7 @@ def main():
     params = W.Params(W.MapParams(resolution=args.res, max_distance=1.0, max_weight=10, size=(size_m, size_m, size_m), shift=args.shift),
                       W.RegistrationParams(200, 0.1, 0.03))
     t0 = time.perf_counter()
-    app = W.App(params, args.h5)
+    app = W.App(params, args.h5, async_shift=args.async_shift)
     t_setup = time.perf_counter() - t0
     he = tuple(1000.0 * r for r in args.room)
     clouds = []
@@ -58,7 +59,9 @@ def main():
     t4 = time.perf_counter()
     print(json.dumps({"workload": f"{args.scans} synthetic OS1-128 scans (131072 pts), {args.map}^3 sliding map @ {args.res} mm, App replay",
                       "scans_per_s": args.scans / (t2 - t1), "stream_s": t2 - t1, "setup_s": t_setup, **stages,
-                      "tsdf_updates": app.n_updates, "map_shifts": app.n_shifts,
+                      "tsdf_updates": app.n_updates, "map_shifts": app.n_shifts, "async_shift": bool(args.async_shift),
+                      "slowest_scan_ms": 1000.0 * float(max(t["total"] for t in app.timings[2:])),
+                      "scans_over_100ms": int(sum(1 for t in app.timings[2:] if t["total"] > 0.1)),
                       "points_after_preprocess": float(np.mean([t["points"] for t in app.timings])),
                       "iterations_mean": float(np.mean([t["iterations"] for t in app.timings])),
                       "final_position_error_mm": float(np.linalg.norm(app.poses[-1][:3, 3] - true_last)),

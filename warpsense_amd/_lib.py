@@ -21,9 +21,10 @@ KERNEL_CLASSES = ["ray_setup", "march_tails", "march_free", "tile_bin", "tile_re
 EXPORTS = [
     "ws_last_error", "ws_version", "ws_ctx_create", "ws_ctx_destroy", "ws_ctx_set_stream", "ws_sync",
     "ws_device_reset", "ws_map_create", "ws_map_destroy", "ws_map_upload", "ws_map_set_params", "ws_map_download",
-    "ws_map_extract_box", "ws_map_insert_box", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
+    "ws_map_extract_box", "ws_map_insert_box", "ws_shift_begin", "ws_shift_reserve", "ws_shift_count", "ws_shift_entering", "ws_shift_wait", "ws_shift_slab",
+    "ws_shift_end", "ws_map_get_params", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
     "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
-    "ws_reg_prepare_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
+    "ws_reg_prepare_dev", "ws_reg_points_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
     "ws_reg_solve_dev", "ws_reg_poll", "ws_reg_set_loop", "ws_debug_solve6", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
     "ws_scan_preprocess_dev", "ws_scan_points_dev", "ws_scan_download", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
 ]
@@ -116,6 +117,14 @@ def load() -> C.CDLL:
     L.ws_map_download.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.ws_map_extract_box.argtypes = [vp, C.c_int, vp, vp, vp]
     L.ws_map_insert_box.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ws_map_get_params.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ws_shift_begin.argtypes = [vp, vp, u32, P(vp)]
+    L.ws_shift_count.argtypes = [vp]
+    L.ws_shift_reserve.argtypes = [vp, C.c_uint64]
+    L.ws_shift_entering.argtypes = [vp, C.c_int, vp, vp]
+    L.ws_shift_wait.argtypes = [vp]
+    L.ws_shift_slab.argtypes = [vp, C.c_int, vp, vp, P(vp)]
+    L.ws_shift_end.argtypes = [vp]
     L.ws_map_device_data.argtypes = [vp, C.c_int]
     L.ws_map_device_data.restype = vp
     L.ws_map_n_voxels.argtypes = [vp]
@@ -131,6 +140,8 @@ def load() -> C.CDLL:
     L.ws_reg_destroy.argtypes = [vp]
     L.ws_reg_prepare.argtypes = [vp, vp, sz]
     L.ws_reg_prepare_dev.argtypes = [vp, vp, sz]
+    L.ws_reg_points_dev.argtypes = [vp, P(sz)]
+    L.ws_reg_points_dev.restype = vp
     L.ws_reg_iterate.argtypes = [vp, vp, vp, i32, u32, vp, vp, P(i32), P(i32)]
     L.ws_register_cloud.argtypes = [vp, vp, vp, i32, C.c_float, C.c_float, i32, u32, vp, P(i32)]
     L.ws_reg_begin.argtypes = [vp, vp, i32, C.c_float, C.c_float]

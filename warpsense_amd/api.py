@@ -194,6 +194,7 @@ class GlobalMap:
     def __init__(self, default_value, default_weight=0, filename: str | None = None, map_params=None, open_existing: bool = False):
         from collections import OrderedDict
         self.default_raw = int(pack_entry(default_value, default_weight))
+        self.lock = threading.RLock()  # the map-shift worker saves slabs while the scan thread writes poses / loads boxes
         self.chunks: "OrderedDict[tuple[int, int, int], np.ndarray]" = OrderedDict()
         self._file = None
         self._filename = filename
@@ -205,6 +206,15 @@ class GlobalMap:
             else:
                 _lib.check_h5(self._H.ws_h5_create(filename.encode(), C.byref(h)), "ws_h5_create")
             self._file = h
+            # which chunks the file holds, without asking HDF5 again (the map shift looks this up per entering chunk)
+            self._in_file: set[tuple[int, int, int]] = set()
+            if open_existing:
+                n = C.c_int64(0)
+                _lib.check_h5(self._H.ws_h5_num_chunks(h, C.byref(n)), "ws_h5_num_chunks")
+                if n.value:
+                    pos = np.zeros((n.value, 3), dtype=np.int32)
+                    _lib.check_h5(self._H.ws_h5_list_chunks(h, _ptr(pos), n.value, C.byref(n)), "ws_h5_list_chunks")
+                    self._in_file = {tuple(int(v) for v in p) for p in pos[:n.value]}
             if map_params is not None and not open_existing:
                 self.write_meta(map_params)
 
@@ -214,6 +224,13 @@ class GlobalMap:
     # -- chunk cache --------------------------------------------------------------------------------
     def _write_chunk(self, key, data):
         _lib.check_h5(self._H.ws_h5_write_chunk(self._file, key[0], key[1], key[2], _ptr(data)), "ws_h5_write_chunk")
+        self._in_file.add(key)
+
+    def has_chunk(self, cx, cy, cz) -> bool:
+        """True if the map holds data for this chunk (in memory or in the file) — a chunk never seen is all default."""
+        key = (int(cx), int(cy), int(cz))
+        with self.lock:
+            return key in self.chunks or (self._file is not None and key in self._in_file)
 
     def activate_chunk(self, cx, cy, cz) -> np.ndarray:
         key = (int(cx), int(cy), int(cz))
@@ -250,15 +267,17 @@ class GlobalMap:
     def write_back(self):
         if self._file is None:
             return
-        for key, data in self.chunks.items():
-            self._write_chunk(key, data)
-        _lib.check_h5(self._H.ws_h5_flush(self._file), "ws_h5_flush")
+        with self.lock:
+            for key, data in self.chunks.items():
+                self._write_chunk(key, data)
+            _lib.check_h5(self._H.ws_h5_flush(self._file), "ws_h5_flush")
 
     def write_pose(self, pose, scale: float):
         if self._file is None:
             raise WsError("write_pose: this GlobalMap has no file")
         vals = pose_to_values(pose, scale)
-        _lib.check_h5(self._H.ws_h5_write_pose(self._file, _ptr(vals)), "ws_h5_write_pose")
+        with self.lock:  # the map-shift worker may be writing chunks: the HDF5 library is used by one thread at a time
+            _lib.check_h5(self._H.ws_h5_write_pose(self._file, _ptr(vals)), "ws_h5_write_pose")
         return vals
 
     def write_meta(self, p):
@@ -289,16 +308,17 @@ class GlobalMap:
         for cx in range(c0[0], c1[0] + 1):
             for cy in range(c0[1], c1[1] + 1):
                 for cz in range(c0[2], c1[2] + 1):
-                    chunk = self.activate_chunk(cx, cy, cz).reshape(cs, cs, cs)
                     base = np.array([cx, cy, cz], dtype=np.int64) * cs
                     a = np.maximum(lo, base)
                     b = np.minimum(hi, base + cs - 1)
                     sl_c = tuple(slice(int(a[k] - base[k]), int(b[k] - base[k]) + 1) for k in range(3))
                     sl_b = tuple(slice(int(a[k] - lo[k]), int(b[k] - lo[k]) + 1) for k in range(3))
-                    if save:
-                        chunk[sl_c] = box[sl_b]
-                    else:
-                        box[sl_b] = chunk[sl_c]
+                    with self.lock:  # per chunk: a pose written by the scan thread never waits for a whole slab
+                        chunk = self.activate_chunk(cx, cy, cz).reshape(cs, cs, cs)
+                        if save:
+                            chunk[sl_c] = box[sl_b]
+                        else:
+                            box[sl_b] = chunk[sl_c]
 
     def save_box(self, lo, hi, buf):
         self._box(lo, hi, buf, True)
@@ -725,6 +745,7 @@ class TSDFMapping:
         unpacked (the three steps of HDF5LocalMap::shift, hdf5_local_map.cpp:53-118).  The reference copies the whole
         map device -> host -> device instead.  The host LocalMap only follows pos/offset; its voxel array is stale
         until avg_map().to_host() is called."""
+        self.wait_shift()
         lm, avg, new = self.local_map_, self.tsdf_.avg_map(), self.tsdf_.new_map()
         new_pos = np.asarray(new_pos, dtype=np.int64)
         with self.mutex_:
@@ -754,12 +775,96 @@ class TSDFMapping:
                 avg.insert_box(start, end, lm.map_.load_box(start, end))
 
 
+    # ---- the same shift off the scan path ---------------------------------------------------------------
+    def shift_map_async(self, new_pos):
+        """TSDFMapping::map_shift as the reference runs it — on its own thread, the scans only wait for the swap
+        (tsdf_mapping.cpp:97-136).  On the scan path: ws_shift_begin (device kernels: pack the leaving slabs into a staging
+        buffer, move the window, fill the entering slabs with the default entry — stream-ordered, no waiting) and, only for
+        revisited space, the upload of the chunks the global map already holds for the entering slabs.  The leaving slabs
+        travel to the host on a second stream and a worker thread files them into the global map.  Same result as
+        shift_map(); wait_shift() joins the worker (write_back() and the next shift do that themselves)."""
+        self.wait_shift()  # one shift in flight; its slabs must be in the global map before entering data is looked up
+        lm, avg = self.local_map_, self.tsdf_.avg_map()
+        new_pos = _i3(new_pos)
+        L = self.tsdf_._L
+        with self.mutex_:
+            ticket = C.c_void_p()
+            check(L.ws_shift_begin(self.tsdf_.handle, _ptr(new_pos), int(lm.map_.default_raw), C.byref(ticket)), "ws_shift_begin")
+            n = L.ws_shift_count(ticket)
+            # the host view of the window follows (pos / offset per axis exactly like HDF5LocalMap::shift)
+            diff = new_pos.astype(np.int64) - lm.pos
+            for axis in range(3):
+                d = int(diff[axis])
+                lm.pos[axis] += d
+                lm.offset[axis] = (lm.offset[axis] + d + lm.size[axis]) % lm.size[axis]
+            # revisited space: chunks the global map already has overwrite the default fill
+            cs = GlobalMap.CHUNK_SIZE
+            lo, hi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
+            for i in range(n):
+                check(L.ws_shift_entering(ticket, i, _ptr(lo), _ptr(hi)), "ws_shift_entering")
+                # a later axis step moves the window again: only the part of the slab still inside the FINAL window counts
+                half = lm.size.astype(np.int64) // 2
+                a = np.maximum(lo.astype(np.int64), lm.pos.astype(np.int64) - half)
+                b = np.minimum(hi.astype(np.int64), lm.pos.astype(np.int64) + half)
+                if np.any(a > b):
+                    continue
+                c0, c1 = np.floor_divide(a, cs), np.floor_divide(b, cs)
+                for cx in range(int(c0[0]), int(c1[0]) + 1):
+                    for cy in range(int(c0[1]), int(c1[1]) + 1):
+                        for cz in range(int(c0[2]), int(c1[2]) + 1):
+                            if not lm.map_.has_chunk(cx, cy, cz):
+                                continue
+                            base = np.array([cx, cy, cz], dtype=np.int64) * cs
+                            sa, sb = np.maximum(a, base), np.minimum(b, base + cs - 1)
+                            avg.insert_box(sa, sb, lm.map_.load_box(sa, sb))
+
+        def file_slabs():
+            check(L.ws_shift_wait(ticket), "ws_shift_wait")
+            slo, shi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
+            elo, ehi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
+            for i in range(n):
+                data = C.c_void_p()
+                check(L.ws_shift_slab(ticket, i, _ptr(slo), _ptr(shi), C.byref(data)), "ws_shift_slab")
+                ext = shi.astype(np.int64) - slo + 1
+                buf = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint32)), shape=(int(np.prod(ext)),))
+                box = buf.reshape(int(ext[0]), int(ext[1]), int(ext[2]))
+                # A corner that ENTERED with an earlier axis of this shift and leaves again with this one was packed as
+                # default fill; the synchronous route would have loaded it from the global map and saved it back
+                # unchanged.  Put the global map's own data there, so the save below changes nothing for it.
+                for j in range(i):
+                    check(L.ws_shift_entering(ticket, j, _ptr(elo), _ptr(ehi)), "ws_shift_entering")
+                    a, b = np.maximum(slo, elo).astype(np.int64), np.minimum(shi, ehi).astype(np.int64)
+                    if np.all(a <= b):
+                        e = b - a + 1
+                        sl = tuple(slice(int(a[k] - slo[k]), int(b[k] - slo[k]) + 1) for k in range(3))
+                        box[sl] = lm.map_.load_box(a, b).reshape(int(e[0]), int(e[1]), int(e[2]))
+                lm.map_.save_box(slo.copy(), shi.copy(), buf)
+            L.ws_shift_end(ticket)
+
+        self._shift_worker = threading.Thread(target=file_slabs, name="warpsense-map-shift", daemon=True)
+        self._shift_worker.start()
+
+    def reserve_shift(self, shift_voxels: int):
+        """staging for asynchronous shifts of up to `shift_voxels` per axis (plus slack), allocated now instead of inside
+        the first shift (a pinned allocation of that size takes tens of milliseconds)"""
+        s = self.local_map_.size.astype(np.int64)
+        d = int(shift_voxels) + 8
+        total = int(d * (s[0] * s[1] + s[1] * s[2] + s[0] * s[2]))
+        check(self.tsdf_._L.ws_shift_reserve(self.tsdf_.handle, total), "ws_shift_reserve")
+
+    def wait_shift(self):
+        w = getattr(self, "_shift_worker", None)
+        if w is not None:
+            w.join()
+            self._shift_worker = None
+
     def write_back(self, box_lo=None, box_hi=None):
         """HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:220) from the
         DEVICE map: every 64^3 chunk the window overlaps is gathered out of the ring buffer by the GPU
         (ws_map_extract_box: chunk layout, x major / z fastest), merged into the global map's chunk and written to
         its file.  The reference downloads the whole window and copies voxel by voxel on the host.
         box_lo / box_hi (inclusive world voxels) restrict the export to a part of the window."""
+        self.wait_shift()
         lm, avg = self.local_map_, self.tsdf_.avg_map()
         cs = GlobalMap.CHUNK_SIZE
         with self.mutex_:

@@ -21,7 +21,10 @@ from .api import (GlobalMap, LocalMap, Params, ScanPreprocessor, TSDFRegistratio
 
 
 class App:
-    def __init__(self, params: Params, filename: str | None = None, ctx=None, max_points: int = 128 * 1024):
+    def __init__(self, params: Params, filename: str | None = None, ctx=None, max_points: int = 128 * 1024, async_shift: bool = False):
+        # async_shift: TSDFMapping.shift_map_async — the window moves on the device inside the scan that triggers it and
+        # the leaving slabs are filed into the global map by a worker thread (same maps and poses as the synchronous route)
+        self.async_shift_ = bool(async_shift)
         m = params.map
         self.params_ = params
         # app.cpp:33-41: global map (file), local map around the origin, the GPU mapping/registration object
@@ -29,6 +32,8 @@ class App:
         self.hdf5_local_map_ = LocalMap(m.size[0], m.size[1], m.size[2], m.tau, m.initial_weight, self.hdf5_global_map_)
         self.gpu_ = TSDFRegistration(params, self.hdf5_local_map_, ctx)
         self.pre_ = ScanPreprocessor(max_points, ctx)
+        if self.async_shift_:
+            self.gpu_.reserve_shift(int(np.ceil(m.shift * 1000.0 / m.resolution)))
         self.pose_ = np.eye(4, dtype=np.float32)            # mm
         self.last_tsdf_pose_ = np.eye(4, dtype=np.float32)
         self.last_shift_pose_ = np.eye(4, dtype=np.float32)
@@ -62,7 +67,10 @@ class App:
         d = np.linalg.norm(self.last_shift_pose_[:3, 3] / np.float32(1000) - self.pose_[:3, 3] / np.float32(1000))
         if d >= self.params_.map.shift:
             self.last_shift_pose_ = self.pose_.copy()
-            self.gpu_.shift_map(to_map(self.pose_, self.params_.map.resolution))
+            if self.async_shift_:
+                self.gpu_.shift_map_async(to_map(self.pose_, self.params_.map.resolution))
+            else:
+                self.gpu_.shift_map(to_map(self.pose_, self.params_.map.resolution))
             self.shifted_ = True
             self.n_shifts += 1
 
@@ -98,6 +106,7 @@ class App:
 
     def terminate(self):
         """App::terminate (app.cpp:192-224): write the map; here straight from the device map."""
+        self.gpu_.wait_shift()
         if self.initialized_:
             self.gpu_.write_back()
         self.hdf5_global_map_.close()

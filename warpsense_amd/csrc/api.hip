@@ -219,6 +219,10 @@ static int map_free(ws_map *m)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
   if (m->status_host) (void)hipHostFree(m->status_host);
+  if (m->shift_open) delete m->shift_open;
+  if (m->shift_stage_dev) (void)hipFree(m->shift_stage_dev);
+  if (m->shift_stage_host) (void)hipHostFree(m->shift_stage_host);
+  if (m->shift_event) (void)hipEventDestroy(m->shift_event);
   if (m->shift_stream) (void)hipStreamDestroy(m->shift_stream);
   delete m;
   return WS_OK;
@@ -476,6 +480,172 @@ int ws_map_insert_box(ws_map *m, int which, const int32_t lo[3], const int32_t h
   return WS_OK;
 }
 
+// ---- map shift off the scan path
+static int shift_reserve(ws_map *m, size_t total)
+{
+  if (total <= m->shift_stage_cap) return WS_OK;
+  hipError_t e = hipStreamSynchronize(m->ctx->stream);
+  if (e == hipSuccess && m->shift_stage_dev) e = hipFree(m->shift_stage_dev);
+  if (e == hipSuccess && m->shift_stage_host) e = hipHostFree(m->shift_stage_host);
+  m->shift_stage_dev = nullptr;
+  m->shift_stage_host = nullptr;
+  m->shift_stage_cap = 0;
+  if (e == hipSuccess) e = hipMalloc((void **)&m->shift_stage_dev, total * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&m->shift_stage_host, total * sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess && !m->shift_stream) e = hipStreamCreateWithFlags(&m->shift_stream, hipStreamNonBlocking);
+  if (e == hipSuccess && !m->shift_event) e = hipEventCreateWithFlags(&m->shift_event, hipEventDisableTiming);
+  if (e != hipSuccess) return hip_fail(e, "map shift staging", __FILE__, __LINE__);
+  m->shift_stage_cap = total;
+  return WS_OK;
+}
+
+int ws_shift_reserve(ws_map *m, uint64_t voxels)
+{
+  if (!m) return invalid("ws_shift_reserve: map is NULL");
+  if (m->shift_open) return invalid("ws_shift_reserve: a shift is in flight");
+  return shift_reserve(m, (size_t)voxels);
+}
+
+int ws_shift_begin(ws_map *m, const int32_t new_pos[3], uint32_t fill_entry, ws_shift **out)
+{
+  if (!m || !new_pos || !out) return invalid("ws_shift_begin: NULL argument");
+  if (m->shift_open) return invalid("ws_shift_begin: the previous shift of this map has not been ended (ws_shift_end)");
+  const MapParams &p0 = m->par[WS_MAP_AVG];
+  ws_shift *sh = new (std::nothrow) ws_shift();
+  if (!sh) return invalid("ws_shift_begin: out of host memory");
+  sh->map = m;
+  // plan: per axis, like HDF5LocalMap::shift (hdf5_local_map.cpp:53-118), with the window as it is when that axis moves
+  int32_t pos[3] = {p0.pos[0], p0.pos[1], p0.pos[2]};
+  size_t total = 0;
+  for (int axis = 0; axis < 3; ++axis)
+  {
+    const int64_t d = (int64_t)new_pos[axis] - pos[axis];
+    if (d == 0) continue;
+    if (std::llabs((long long)d) > p0.size[axis])
+    {
+      delete sh;
+      return invalid("ws_shift_begin: shift larger than the window");
+    }
+    const int i = sh->n++;
+    int32_t start[3], end[3];
+    for (int k = 0; k < 3; ++k)
+    {
+      start[k] = pos[k] - p0.size[k] / 2;
+      end[k] = pos[k] + p0.size[k] / 2;
+    }
+    if (d > 0)
+      end[axis] = start[axis] + (int32_t)d - 1;
+    else
+      start[axis] = end[axis] + (int32_t)d + 1;
+    copy3(sh->leave_lo[i], start);
+    copy3(sh->leave_hi[i], end);
+    pos[axis] += (int32_t)d;
+    for (int k = 0; k < 3; ++k)
+    {
+      start[k] = pos[k] - p0.size[k] / 2;
+      end[k] = pos[k] + p0.size[k] / 2;
+    }
+    if (d > 0)
+      start[axis] = end[axis] - ((int32_t)d - 1);
+    else
+      end[axis] = start[axis] - (int32_t)d - 1;
+    copy3(sh->enter_lo[i], start);
+    copy3(sh->enter_hi[i], end);
+    sh->offset[i] = total;
+    total += (size_t)(sh->leave_hi[i][0] - sh->leave_lo[i][0] + 1) * (size_t)(sh->leave_hi[i][1] - sh->leave_lo[i][1] + 1) *
+             (size_t)(sh->leave_hi[i][2] - sh->leave_lo[i][2] + 1);
+  }
+  sh->total = total;
+  hipStream_t s = m->ctx->stream;
+  {
+    // (a shift larger than anything reserved: the staging buffers grow, which waits for the stream once)
+    const int rc0 = shift_reserve(m, total ? total : 1);
+    if (rc0 != WS_OK)
+    {
+      delete sh;
+      return rc0;
+    }
+  }
+  // execute the plan on the map's stream
+  int rc = WS_OK;
+  for (int i = 0, axis = 0; i < sh->n && rc == WS_OK; ++i, ++axis)
+  {
+    while (new_pos[axis] == m->par[WS_MAP_AVG].pos[axis]) ++axis; // the axis slab i belongs to
+    int32_t ext[3];
+    for (int k = 0; k < 3; ++k) ext[k] = sh->leave_hi[i][k] - sh->leave_lo[i][k] + 1;
+    rc = launch_box_copy(m, WS_MAP_AVG, sh->leave_lo[i], ext, m->shift_stage_dev + sh->offset[i], true, s);
+    const int32_t d = new_pos[axis] - m->par[WS_MAP_AVG].pos[axis];
+    for (int w = 0; w < 2; ++w)
+    {
+      MapParams &p = m->par[w];
+      p.pos[axis] += d;
+      p.offset[axis] = (int32_t)((((int64_t)p.offset[axis] + d) % p.size[axis] + p.size[axis]) % p.size[axis]);
+    }
+    for (int k = 0; k < 3; ++k) ext[k] = sh->enter_hi[i][k] - sh->enter_lo[i][k] + 1;
+    if (rc == WS_OK) rc = launch_box_fill(m, WS_MAP_AVG, sh->enter_lo[i], ext, fill_entry, s);
+    // new_map is (tau, 0) everywhere between updates: only its window moves (DeviceMapMemWrapper::update_params)
+  }
+  if (rc == WS_OK && total)
+  {
+    hipError_t e = hipEventRecord(m->shift_event, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(m->shift_stream, m->shift_event, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->shift_stage_host, m->shift_stage_dev, total * sizeof(uint32_t), hipMemcpyDeviceToHost, m->shift_stream);
+    if (e != hipSuccess) rc = hip_fail(e, "ws_shift_begin copy", __FILE__, __LINE__);
+  }
+  if (rc != WS_OK)
+  {
+    delete sh;
+    return rc;
+  }
+  m->shift_open = sh;
+  *out = sh;
+  return WS_OK;
+}
+
+int ws_shift_count(const ws_shift *sh) { return sh ? sh->n : 0; }
+
+int ws_shift_entering(const ws_shift *sh, int i, int32_t lo[3], int32_t hi[3])
+{
+  if (!sh || i < 0 || i >= sh->n || !lo || !hi) return invalid("ws_shift_entering: bad argument");
+  copy3(lo, sh->enter_lo[i]);
+  copy3(hi, sh->enter_hi[i]);
+  return WS_OK;
+}
+
+int ws_shift_wait(ws_shift *sh)
+{
+  if (!sh) return invalid("ws_shift_wait: shift is NULL");
+  if (sh->map->shift_stream) WS_HIP(hipStreamSynchronize(sh->map->shift_stream));
+  return WS_OK;
+}
+
+int ws_shift_slab(const ws_shift *sh, int i, int32_t lo[3], int32_t hi[3], const uint32_t **host_data)
+{
+  if (!sh || i < 0 || i >= sh->n || !lo || !hi || !host_data) return invalid("ws_shift_slab: bad argument");
+  copy3(lo, sh->leave_lo[i]);
+  copy3(hi, sh->leave_hi[i]);
+  *host_data = sh->map->shift_stage_host + sh->offset[i];
+  return WS_OK;
+}
+
+int ws_shift_end(ws_shift *sh)
+{
+  if (!sh) return WS_OK;
+  if (sh->map->shift_stream) (void)hipStreamSynchronize(sh->map->shift_stream);
+  if (sh->map->shift_open == sh) sh->map->shift_open = nullptr;
+  delete sh;
+  return WS_OK;
+}
+
+int ws_map_get_params(const ws_map *m, int which, int32_t size[3], int32_t pos[3], int32_t offset[3])
+{
+  if (!m || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("ws_map_get_params: bad argument");
+  if (size) copy3(size, m->par[which].size);
+  if (pos) copy3(pos, m->par[which].pos);
+  if (offset) copy3(offset, m->par[which].offset);
+  return WS_OK;
+}
+
 void *ws_map_device_data(ws_map *m, int which)
 {
   if (!m || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return nullptr;
@@ -664,6 +834,12 @@ int ws_reg_prepare_dev(ws_reg *r, const int32_t *xyz_dev, size_t n)
   return WS_OK;
 }
 
+const int32_t *ws_reg_points_dev(const ws_reg *r, size_t *n)
+{
+  if (n) *n = r ? r->n : 0;
+  return r ? r->points : nullptr;
+}
+
 int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, int64_t h[36], int64_t g[6],
                    int32_t *e, int32_t *c)
 {
@@ -750,14 +926,16 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
     r->latest = 0;
     WS_HIP(hipStreamSynchronize(r->ctx->stream));
     const GnCore *h = &r->result_host->core;
-    if (h->error)
+    if (!h->error)
     {
-      set_error("ws_register_cloud: grid barrier timed out (another kernel is holding compute units); use WS_REG_LOOP_LAUNCHES");
-      return WS_ERR_TIMEOUT;
+      std::memcpy(T_out, h->T, 16 * sizeof(float));
+      if (iterations) *iterations = h->iterations;
+      return map_take_error(const_cast<ws_map *>(m));
     }
-    std::memcpy(T_out, h->T, 16 * sizeof(float));
-    if (iterations) *iterations = h->iterations;
-    return map_take_error(const_cast<ws_map *>(m));
+    // The grid barrier timed out: another kernel held compute units the resident grid needs (its workgroups must all
+    // be on the chip at once).  Nothing was lost — the loop state is only ever produced from complete sums — so the
+    // registration simply runs again with one launch per iteration, which needs no co-residency.
+    r->resident_fallbacks += 1;
   }
   int rc = ws_reg_begin(r, T_in, max_iterations, it_weight_gradient, epsilon);
   if (rc != WS_OK) return rc;

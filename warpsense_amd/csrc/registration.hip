@@ -719,7 +719,7 @@ constexpr int REG_BAR_STRIDE = 64; // uint32 words between counters (256 B)
 constexpr int REG_BAR_ABORT = REG_BAR_COUNTERS * REG_BAR_STRIDE;
 constexpr size_t REG_BAR_BYTES = (REG_BAR_ABORT + REG_BAR_STRIDE) * sizeof(uint32_t);
 static_assert(REG_BLOCKS % REG_BAR_COUNTERS == 0 && REG_BAR_COUNTERS <= 64, "arrival counters");
-constexpr long long REG_BARRIER_TIMEOUT_TICKS = 100000000ll; // 1 s of the 100 MHz wall clock
+constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
 
 __device__ __forceinline__ void grid_arrive(uint32_t *bar)
 {

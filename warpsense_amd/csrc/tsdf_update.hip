@@ -1871,6 +1871,32 @@ int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext
   return WS_OK;
 }
 
+__global__ __launch_bounds__(256) void box_fill_kernel(uint32_t *map_data, MapParams mp, int32_t lox, int32_t loy, int32_t loz, int32_t ex, int32_t ey,
+                                                       int32_t ez, uint32_t value)
+{
+  const int64_t n = (int64_t)ex * ey * ez;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+  {
+    const int32_t z = (int32_t)(i % ez);
+    const int32_t y = (int32_t)((i / ez) % ey);
+    const int32_t x = (int32_t)(i / ((int64_t)ez * ey));
+    map_data[get_index(mp, lox + x, loy + y, loz + z)] = value;
+  }
+}
+
+int launch_box_fill(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t s)
+{
+  const int64_t n = (int64_t)ext[0] * ext[1] * ext[2];
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(box_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2], ext[0], ext[1],
+                     ext[2], value);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
 {
   if (n <= 0) return WS_OK;

@@ -177,6 +177,21 @@ struct ws_map
   size_t box_stage_cap = 0;
   uint32_t last_error_bits = 0;  // device error bits already taken from status_host, not yet shown by ws_tsdf_stats
   hipStream_t shift_stream = nullptr; // second stream for asynchronous slab transfers (map shift off the scan path)
+  hipEvent_t shift_event = nullptr;
+  uint32_t *shift_stage_dev = nullptr;  // packed leaving slabs
+  uint32_t *shift_stage_host = nullptr; // pinned
+  size_t shift_stage_cap = 0;           // voxels
+  ws_shift *shift_open = nullptr;       // the ticket in flight
+};
+
+struct ws_shift
+{
+  ws_map *map = nullptr;
+  int n = 0;
+  int32_t leave_lo[3][3], leave_hi[3][3]; // world boxes that left (coordinates of the window before that axis moved)
+  int32_t enter_lo[3][3], enter_hi[3][3]; // world boxes that entered
+  size_t offset[3];                       // of slab i in the staging buffers (voxels)
+  size_t total = 0;
 };
 
 struct ws_reg
@@ -197,6 +212,7 @@ struct ws_reg
   uint32_t *grid_bar = nullptr;      // [2] arrival counter + abort flag of reg_loop_kernel
   int loop_mode = 0;                 // WS_REG_LOOP_*
   int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
+  int resident_fallbacks = 0;        // registrations redone with one launch per iteration after a barrier timeout
 };
 
 // scan pre-processing buffers (App::preprocess on the device, scan_preprocess.hip)
@@ -244,6 +260,7 @@ uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
 int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
+int launch_box_fill(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t stream);
 int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
 
 int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags,

@@ -18,6 +18,9 @@ import numpy as np
 from ._lib import check
 
 
+GRAPH_CACHE_MAX = 8  # captured batches kept by sharded_register_cloud's `graphs` dict
+
+
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous index range of `rank`: [rank*n//world, (rank+1)*n//world)."""
     lo = (rank * n) // world
@@ -46,6 +49,18 @@ class HipGnBackend:
 
     def solve(self, sums):
         check(self._L.ws_reg_solve_dev(self.reg.handle, C.c_void_p(sums.data_ptr())), "ws_reg_solve_dev")
+
+    def binding(self) -> tuple:
+        """Everything a captured kernel launch bakes in by value: the map window (size, pos, offset travel as kernel
+        arguments), the voxel array and the registration's point buffer and count.  A HIP graph captured under one
+        binding must not be replayed under another (stale window / freed buffer)."""
+        par = np.zeros((3, 3), dtype=np.int32)
+        check(self._L.ws_map_get_params(self.tsdf.device_map(), 0, par[0].ctypes.data_as(C.c_void_p), par[1].ctypes.data_as(C.c_void_p),
+                                        par[2].ctypes.data_as(C.c_void_p)), "ws_map_get_params")
+        n = C.c_size_t(0)
+        pts = self._L.ws_reg_points_dev(self.reg.handle, C.byref(n))
+        return (tuple(int(v) for v in par.reshape(-1)), int(self._L.ws_map_device_data(self.tsdf.device_map(), 0) or 0), int(pts or 0), int(n.value),
+                self.res, self.flags)
 
     def poll(self):
         fin, it = C.c_int32(0), C.c_int32(0)
@@ -117,19 +132,24 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
     """cuda::TSDFRegistration::register_cloud (tsdf_registration.cpp:28-96) with the points sharded over the
     ranks of `group`.  Returns (total_transform 4x4, iterations).  Every rank returns the same values.
 
-    `graphs`: a dict the caller keeps between calls; with it the per-batch work is captured once as a HIP graph
-    (keyed by shard and batch size) and replayed."""
+    `graphs`: a dict the caller keeps between calls; with it the per-batch work is captured once as a HIP graph and
+    replayed.  The key holds everything the captured launches bake in (shard, batch size, map window, voxel and point
+    buffers, point count — HipGnBackend.binding()), so a map shift or a cloud of another size captures anew instead of
+    replaying against a stale window; the dict keeps the GRAPH_CACHE_MAX most recent graphs."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     first, count = shard_range(n_points, rank, world)
     runner = None
     if graphs is not None:
-        key = (first, count, batch)
-        runner = graphs.get(key)
+        key = (first, count, batch) + (backend.binding() if hasattr(backend, "binding") else ())
+        runner = graphs.pop(key, None)
         if runner is None:
             backend.begin(T_in, 1, it_weight_gradient, epsilon)  # a throw-away state for the warm-up / capture launches
-            runner = graphs[key] = _GraphBatch(backend, first, count, group, batch)
+            runner = _GraphBatch(backend, first, count, group, batch)
+        graphs[key] = runner  # most recently used last
+        while len(graphs) > GRAPH_CACHE_MAX:
+            graphs.pop(next(iter(graphs)))
     backend.begin(T_in, max_iterations, it_weight_gradient, epsilon)
     done, finished, iterations, T = 0, False, 0, np.asarray(T_in, dtype=np.float32)
     while not finished and done < max_iterations:
