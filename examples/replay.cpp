@@ -30,6 +30,7 @@ int main(int argc, char **argv)
   p.hot.max_weight = atoi(argv[7]);
   p.max_distance = (float)p.hot.tau / 1000.f;
   p.shift = (float)atof(argv[8]);
+  p.async_shift = getenv("WS_REPLAY_ASYNC_SHIFT") != nullptr; // the map shift off the scan path (MappingNode::shift_map_async)
 
   std::vector<float> clouds(scans * n * 3);
   {

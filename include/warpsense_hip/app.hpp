@@ -13,8 +13,11 @@
 #include <array>
 #include <list>
 #include <map>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include "warpsense_hip/mapping.hpp"
 #ifdef WARPSENSE_HIP_WITH_H5
@@ -108,16 +111,25 @@ public:
     const Key c{floor_div(x, CHUNK_SIZE), floor_div(y, CHUNK_SIZE), floor_div(z, CHUNK_SIZE)};
     activate_chunk(c)[index_from_pos(x, y, z, c)] = v.raw();
   }
-  // dense world-voxel box [lo, hi] (inclusive, x major / z fastest) <-> chunks
-  void save_box(const rm::Pointi &lo, const rm::Pointi &hi, const std::vector<TSDFEntry> &box) { move_box(lo, hi, const_cast<std::vector<TSDFEntry> &>(box), true); }
+  // true if the map holds data for this chunk (in memory or in the file): a chunk never seen is all default
+  bool has_chunk(const Key &c)
+  {
+    std::lock_guard<std::recursive_mutex> g(mutex_);
+    return chunks_.count(c) != 0 || in_file_.count(c) != 0;
+  }
+  // dense world-voxel box [lo, hi] (inclusive, x major / z fastest) <-> chunks.  Thread safe per chunk: the map-shift
+  // worker files slabs while the scan thread writes poses (the HDF5 library is used by one thread at a time).
+  void save_box(const rm::Pointi &lo, const rm::Pointi &hi, const std::vector<TSDFEntry> &box) { move_box(lo, hi, const_cast<TSDFEntry *>(box.data()), true); }
+  void save_box(const rm::Pointi &lo, const rm::Pointi &hi, const TSDFEntry *box) { move_box(lo, hi, const_cast<TSDFEntry *>(box), true); }
   void load_box(const rm::Pointi &lo, const rm::Pointi &hi, std::vector<TSDFEntry> &box)
   {
     box.resize((size_t)(hi.x - lo.x + 1) * (size_t)(hi.y - lo.y + 1) * (size_t)(hi.z - lo.z + 1));
-    move_box(lo, hi, box, false);
+    move_box(lo, hi, box.data(), false);
   }
   void write_back() // :160-176
   {
 #ifdef WARPSENSE_HIP_WITH_H5
+    std::lock_guard<std::recursive_mutex> g(mutex_);
     if (!file_) return;
     for (auto &kv : chunks_) write_chunk(kv.first, kv.second);
     ws_h5_flush(file_);
@@ -128,6 +140,7 @@ public:
   {
     std::array<float, 7> v = pose_values(pose, scale);
 #ifdef WARPSENSE_HIP_WITH_H5
+    std::lock_guard<std::recursive_mutex> g(mutex_);
     if (file_ && ws_h5_write_pose(file_, v.data()) != 0) throw std::runtime_error(ws_h5_last_error());
 #endif
     return v;
@@ -192,11 +205,12 @@ private:
   {
 #ifdef WARPSENSE_HIP_WITH_H5
     if (ws_h5_write_chunk(file_, c[0], c[1], c[2], data.data()) != 0) throw std::runtime_error(ws_h5_last_error());
+    in_file_.insert(c);
 #else
     (void)c; (void)data;
 #endif
   }
-  void move_box(const rm::Pointi &lo, const rm::Pointi &hi, std::vector<TSDFEntry> &box, bool save)
+  void move_box(const rm::Pointi &lo, const rm::Pointi &hi, TSDFEntry *box, bool save)
   {
     const int cs = CHUNK_SIZE;
     const size_t ey = (size_t)(hi.y - lo.y + 1), ez = (size_t)(hi.z - lo.z + 1);
@@ -205,6 +219,7 @@ private:
         for (int cz = floor_div(lo.z, cs); cz <= floor_div(hi.z, cs); ++cz)
         {
           const Key c{cx, cy, cz};
+          std::lock_guard<std::recursive_mutex> g(mutex_);
           auto &chunk = activate_chunk(c);
           const int ax = std::max(lo.x, cx * cs), bx = std::min(hi.x, cx * cs + cs - 1);
           const int ay = std::max(lo.y, cy * cs), by = std::min(hi.y, cy * cs + cs - 1);
@@ -229,6 +244,8 @@ private:
   std::string filename_;
   std::map<Key, std::vector<TSDFEntry::RawType>> chunks_;
   std::list<Key> lru_;
+  std::set<Key> in_file_; // chunks written to the file by this object
+  std::recursive_mutex mutex_;
 #ifdef WARPSENSE_HIP_WITH_H5
   ws_h5 *file_ = nullptr;
 #else
@@ -285,6 +302,7 @@ public:
   // save the slab that leaves, move pos/offset, load the slab that enters -- each slab packed / unpacked by the GPU.
   void shift_map(const rm::Pointi &new_pos)
   {
+    wait_shift();
     auto &avg = gpu_.tsdf().avg_map();
     auto &fresh = gpu_.tsdf().new_map();
     rm::Pointi &size = local_map_.get_size(), &pos = local_map_.get_pos(), &off = local_map_.get_offset();
@@ -326,9 +344,98 @@ public:
     }
   }
 
+  // The same shift the way the reference runs it — off the scan path (its own thread, tsdf_mapping.cpp:97-136): the
+  // window moves by device kernels inside this call (ws_shift_begin: pack the leaving slabs, move pos/offset, fill the
+  // entering slabs with the default entry; nothing waits), chunks the global map already holds for the entering slabs are
+  // uploaded (revisits only), and a worker thread files the leaving slabs into the global map once their copy to pinned
+  // memory has landed.  Same maps as shift_map().
+  void shift_map_async(const rm::Pointi &new_pos)
+  {
+    wait_shift();
+    auto &avg = gpu_.tsdf().avg_map();
+    rm::Pointi &size = local_map_.get_size(), &pos = local_map_.get_pos(), &off = local_map_.get_offset();
+    int *sz = &size.x, *ps = &pos.x, *of = &off.x;
+    const int np[3] = {new_pos.x, new_pos.y, new_pos.z};
+    ws_shift *ticket = nullptr;
+    WS_CHECK(ws_shift_begin(gpu_.tsdf().handle(), np, local_map_.global_map().get_default_tsdf_entry().raw(), &ticket));
+    for (int axis = 0; axis < 3; ++axis)
+    {
+      const int d = np[axis] - ps[axis];
+      ps[axis] += d;
+      of[axis] = ((of[axis] + d) % sz[axis] + sz[axis]) % sz[axis];
+    }
+    const int n = ws_shift_count(ticket), cs = GlobalMap::CHUNK_SIZE;
+    std::vector<TSDFEntry> part;
+    for (int i = 0; i < n; ++i)
+    {
+      int lo[3], hi[3];
+      WS_CHECK(ws_shift_entering(ticket, i, lo, hi));
+      for (int k = 0; k < 3; ++k) // only what is still inside the final window
+      {
+        lo[k] = std::max(lo[k], ps[k] - sz[k] / 2);
+        hi[k] = std::min(hi[k], ps[k] + sz[k] / 2);
+      }
+      if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) continue;
+      for (int cx = floor_div(lo[0], cs); cx <= floor_div(hi[0], cs); ++cx)
+        for (int cy = floor_div(lo[1], cs); cy <= floor_div(hi[1], cs); ++cy)
+          for (int cz = floor_div(lo[2], cs); cz <= floor_div(hi[2], cs); ++cz)
+          {
+            if (!local_map_.global_map().has_chunk(GlobalMap::Key{cx, cy, cz})) continue;
+            const rm::Pointi a(std::max(lo[0], cx * cs), std::max(lo[1], cy * cs), std::max(lo[2], cz * cs)),
+                b(std::min(hi[0], cx * cs + cs - 1), std::min(hi[1], cy * cs + cs - 1), std::min(hi[2], cz * cs + cs - 1));
+            local_map_.global_map().load_box(a, b, part);
+            avg.insert_box(a, b, part);
+          }
+    }
+    GlobalMap *gm = &local_map_.global_map();
+    shift_worker_ = std::thread([ticket, n, gm]() {
+      if (ws_shift_wait(ticket) != WS_OK) return;
+      std::vector<TSDFEntry> own;
+      for (int i = 0; i < n; ++i)
+      {
+        int lo[3], hi[3];
+        const uint32_t *data = nullptr;
+        if (ws_shift_slab(ticket, i, lo, hi, &data) != WS_OK) continue;
+        TSDFEntry *box = reinterpret_cast<TSDFEntry *>(const_cast<uint32_t *>(data));
+        const size_t ey = (size_t)(hi[1] - lo[1] + 1), ez = (size_t)(hi[2] - lo[2] + 1);
+        // a corner that entered with an earlier axis of this shift and leaves with this one was packed as default fill:
+        // put the global map's own data there, so that saving the slab changes nothing for it
+        for (int j = 0; j < i; ++j)
+        {
+          int elo[3], ehi[3];
+          if (ws_shift_entering(ticket, j, elo, ehi) != WS_OK) continue;
+          int a[3], b[3];
+          bool any = true;
+          for (int k = 0; k < 3; ++k)
+          {
+            a[k] = std::max(lo[k], elo[k]);
+            b[k] = std::min(hi[k], ehi[k]);
+            any = any && a[k] <= b[k];
+          }
+          if (!any) continue;
+          gm->load_box(rm::Pointi(a[0], a[1], a[2]), rm::Pointi(b[0], b[1], b[2]), own);
+          const size_t oy = (size_t)(b[1] - a[1] + 1), oz = (size_t)(b[2] - a[2] + 1);
+          for (int x = a[0]; x <= b[0]; ++x)
+            for (int y = a[1]; y <= b[1]; ++y)
+              for (int z = a[2]; z <= b[2]; ++z)
+                box[((size_t)(x - lo[0]) * ey + (size_t)(y - lo[1])) * ez + (size_t)(z - lo[2])] =
+                    own[((size_t)(x - a[0]) * oy + (size_t)(y - a[1])) * oz + (size_t)(z - a[2])];
+        }
+        gm->save_box(rm::Pointi(lo[0], lo[1], lo[2]), rm::Pointi(hi[0], hi[1], hi[2]), box);
+      }
+      ws_shift_end(ticket);
+    });
+  }
+  void wait_shift()
+  {
+    if (shift_worker_.joinable()) shift_worker_.join();
+  }
+  ~MappingNode() { wait_shift(); }
+
   // HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:215-221) from the device map
   void write_back()
   {
+    wait_shift();
     auto &avg = gpu_.tsdf().avg_map();
     const rm::Pointi &size = local_map_.get_size(), &pos = local_map_.get_pos();
     const int cs = GlobalMap::CHUNK_SIZE;
@@ -350,6 +457,7 @@ private:
   LocalMap &local_map_;
   cuda::DeviceMap view_;
   cuda::TSDFRegistration gpu_;
+  std::thread shift_worker_;
 };
 
 // ---------------------------------------------------------------------------------------------------- App
@@ -360,6 +468,7 @@ struct AppParams
   float shift = 10.0f;       // map/shift (m)
   int map_size[3] = {513, 513, 513}; // voxels
   int initial_weight = 0;
+  bool async_shift = false; // MappingNode::shift_map_async: the map shift off the scan path
 };
 
 class App
@@ -427,8 +536,12 @@ public:
     {
       last_shift_pose_ = pose_;
       const int res = params_.hot.map_resolution;
-      node_.shift_map(rm::Pointi((int)std::floor(pose_.at(0, 3) / (float)res), (int)std::floor(pose_.at(1, 3) / (float)res),
-                                 (int)std::floor(pose_.at(2, 3) / (float)res))); // to_map, util/util.h:52-56
+      const rm::Pointi target((int)std::floor(pose_.at(0, 3) / (float)res), (int)std::floor(pose_.at(1, 3) / (float)res),
+                              (int)std::floor(pose_.at(2, 3) / (float)res)); // to_map, util/util.h:52-56
+      if (params_.async_shift)
+        node_.shift_map_async(target);
+      else
+        node_.shift_map(target);
       shifted_ = true;
       ++n_shifts_;
     }

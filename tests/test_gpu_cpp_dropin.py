@@ -39,8 +39,11 @@ def test_cpp_harness_matches_oracle(tmp_path):
     assert np.abs(T - To).max() < 1e-4
 
 
-def test_cpp_replay_matches_python_app(tmp_path):
-    """examples/replay.cpp (warpsense::App, include/warpsense_hip/app.hpp: device pre-processing, update, registration,
+@pytest.mark.parametrize("async_shift", [False, True])
+def test_cpp_replay_matches_python_app(tmp_path, async_shift):
+    """(async_shift: MappingNode::shift_map_async in C++ against the synchronous Python App — the map shift off the scan
+    path must give the same poses, window and .h5 file.)
+    examples/replay.cpp (warpsense::App, include/warpsense_hip/app.hpp: device pre-processing, update, registration,
     device-side map shift, export) against warpsense_amd.App on the same stream — itself checked against the
     oracle-driven sequence in tests/test_gpu_replay.py.  Same C ABI underneath, so everything must agree exactly."""
     import warpsense_amd as W
@@ -60,7 +63,10 @@ def test_cpp_replay_matches_python_app(tmp_path):
             str(tmp_path / "poses.bin"), str(tmp_path / "map.bin")]
     if with_h5:
         args.append(str(tmp_path / "cpp.h5"))
-    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    if async_shift:
+        env["WS_REPLAY_ASYNC_SHIFT"] = "1"
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr + out.stdout
     lines = out.stdout.strip().splitlines()
 
