@@ -108,7 +108,7 @@ class OracleGnBackend:
         return fin, int(self.st.iterations), np.ctypeslib.as_array(self.st.T).reshape(4, 4).T.copy()
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, drop=0):
     import torch.distributed as dist
     from warpsense_amd import synthetic as S
     from warpsense_amd.dist import sharded_register_cloud
@@ -122,17 +122,22 @@ def _gloo_worker(rank, world, port, q):
         new = avg.copy()
         O.update_tsdf(avg, new, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
         cloud = S.transform_points_mm(pts, S.perturbation(25, -15, 5, 1.2))
+        if drop:
+            cloud = np.ascontiguousarray(cloud[:-drop])  # ragged: the point count is not a multiple of the world size
         backend = OracleGnBackend(avg, cloud, res)
         T, it = sharded_register_cloud(backend, cloud.shape[0], np.eye(4, dtype=np.float32), 60, 0.1, 0.03, batch=7)
         if rank == 0:
+            assert cloud.shape[0] % world != 0 or not drop
             T_ref, it_ref, _ = O.register_cloud(avg, cloud, np.eye(4), 60, 0.1, 0.03, res)
             q.put((it, it_ref, float(np.abs(T - T_ref).max())))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_registration_is_exact_over_gloo():
-    """2 ranks, points sharded by index, all-reduce of the 44 int64 sums each iteration: bit-identical to 1 rank."""
+@pytest.mark.parametrize("world,drop", [(2, 0), (2, 1), (3, 0), (3, 2)])
+def test_sharded_registration_is_exact_over_gloo(world, drop):
+    """2 and 3 ranks, points sharded by index (also when the count is not a multiple of the world size: shard_range
+    gives the ranks unequal, contiguous ranges), all-reduce of the 44 int64 sums each iteration: bit-identical to 1 rank."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -140,7 +145,7 @@ def test_sharded_registration_is_exact_over_gloo():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q, drop)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
