@@ -70,9 +70,12 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
         m.data[:] = O.pack(tau, 0)
         return O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=threads)
 
+    # (the port's per-thread hash maps are merged serially: beyond a few dozen threads it only gets slower — 256 threads
+    # took 37 s per scan on the MI355X host — so "all cores" is capped at 32)
+    many = min(ncpu, 32)
     variants = [("update_1_thread", 1, 3), ("update_8_threads", min(8, ncpu), 2)]
-    if ncpu > 8:
-        variants.append((f"update_{ncpu}_threads", ncpu, 1))
+    if many > 8:
+        variants.append((f"update_{many}_threads", many, 1))
     best_upd = None
     for name, th, runs in variants:
         med, ts = timed(lambda th=th: upd(th), runs, warm=1 if th == 1 else 0)
@@ -88,8 +91,8 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
 
     best_reg = None
     reg_variants = [("register_8_threads", min(8, ncpu), 2)]
-    if ncpu > 8:
-        reg_variants.append((f"register_{ncpu}_threads", ncpu, 2))
+    if many > 8:
+        reg_variants.append((f"register_{many}_threads", many, 2))
     for name, th, runs in reg_variants:
         med, ts = timed(lambda th=th: reg(th), runs, warm=0)
         samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th, "iterations": it_box[-1]}
@@ -104,6 +107,12 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
 
 def main():
     args = parse()
+    # The driver reads ONE JSON line from stdout.  Libraries print there too (RCCL's version banner comes from C code):
+    # keep a private handle on the real stdout for the result and send everything else that is written to fd 1 to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    result_out = os.fdopen(result_fd, "w")
     import torch
     import torch.distributed as dist
 
@@ -150,7 +159,6 @@ def main():
     force_sharded = os.environ.get("WS_BENCH_FORCE_SHARDED") == "1"  # exercise the multi-rank driver on one rank
     reg.prepare_registration(d_pert)
     its = []
-    graph_cache = {}  # HIP graphs of the sharded Gauss-Newton batches, captured on first use
 
     def step():
         tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
@@ -162,7 +170,7 @@ def main():
         if world == 1 and not force_sharded:
             _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
         else:
-            _, it = sharded_register_cloud(backend, n, eye, *reg_params, graphs=graph_cache)
+            _, it = sharded_register_cloud(backend, n, eye, *reg_params)
         its.append(it)
 
     def fence():
@@ -246,6 +254,31 @@ def main():
                                    "us_per_iteration": 1000.0 * ms / max(reg_its, 1), "bytes_per_iteration": 40 * n,
                                    "note": "separate pass; latency-bound (SURVEY.md §8d: no roofline gate)"}
 
+    # the multi-GPU code path (points sharded, RCCL all-reduce of the 44 sums each iteration, HIP-graph batches) on ONE
+    # rank: what the RCCL route costs per scan before any xGMI hop is added (separate from the timed region)
+    sharded_1rank = None
+    if world == 1 and not force_sharded and not args.no_registration and os.environ.get("WS_BENCH_SKIP_SHARDED") != "1":
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            for _ in range(2):
+                tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
+                reg.prepare_registration(d_pert)
+                _, sh_it = sharded_register_cloud(backend, n, eye, *reg_params)
+            fence()
+            n_sh = max(3, min(args.steps, 8))
+            t2 = time.perf_counter()
+            for _ in range(n_sh):
+                tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
+                reg.prepare_registration(d_pert)
+                _, sh_it = sharded_register_cloud(backend, n, eye, *reg_params)
+            fence()
+            sharded_1rank = {"scans_per_s": n_sh / (time.perf_counter() - t2), "iterations": sh_it}
+            dist.destroy_process_group()
+        except Exception as exc:  # RCCL unavailable on this box: report why, keep the bench line
+            sharded_1rank = {"error": repr(exc)[:200]}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -267,7 +300,10 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get(f"{dom}:{args.integrate}")
+                tj = json.load(fh)
+                mode_key = "dense" if args.integrate == "dense" else "sparse"
+                # HBM bytes of the whole kernel group the achieved figure is computed over (PMC passes, tools/make_traffic.py)
+                traffic = tj.get(f"integrate:{mode_key}") if dom == "integrate" else tj.get(f"scatter_total:{mode_key}")
         except Exception:
             pass
         if dom == "integrate":
@@ -317,6 +353,8 @@ def main():
                    "record_runs": stats["runs"]},
         "roofline": roofline,
         "kernels": kernels,
+        "sharded_1rank_scans_per_s": sharded_1rank["scans_per_s"] if sharded_1rank and "scans_per_s" in sharded_1rank else None,
+        "sharded_1rank": sharded_1rank,
     }
     if roofline is not None and dense_eq is not None:
         roofline["dense_equivalent"] = dense_eq
@@ -324,7 +362,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(points, perturbed, size, tau, mw, res, reg_params)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    result_out.write(json.dumps(out) + "\n")
+    result_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

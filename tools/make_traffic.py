@@ -1,39 +1,54 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json: HBM bytes per launch of the kernels bench.py reports a roofline for, from the
-separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (values are KB).
+separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (values are KB, summed over the hardware instances of a
+dispatch, averaged over the dispatches of a kernel).
 
-Corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts a wide coalesced stream at half its bytes on gfx950 —
-doubled for integrate_dense (128-bit streaming loads, verified: 2 x 527 MB + 1055 MB written == 16 B/voxel).
-For the scattered 8-byte accesses of the march kernels the counter is uncalibrated: recorded as is.
+Corrections (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE counts a wide coalesced stream (16 B per lane) at half
+its bytes — doubled for integrate_dense (128-bit streaming loads; verified: 2 x 527 MB + 1055 MB written == 16 B/voxel).
+For the other kernels (16-byte record streams mixed with scattered bytes / dwords) the counters are uncalibrated and
+recorded as they are.
 
-    python tools/make_traffic.py gpurun_out/prof_r01e
+    python tools/make_traffic.py gpurun_out/prof_r02  ->  profiles/pmc_traffic.json
 """
+import glob
 import json
 import os
 import sqlite3
 import sys
 
 
-def per_kernel(db):
-    con = sqlite3.connect(db)
-    return {name: avg for name, avg in con.execute("select name, avg(counter_value) from pmc_events group by name")}
+def per_kernel(pattern):
+    dbs = sorted(glob.glob(pattern + "/*.db") + glob.glob(pattern + "/*/*.db"))
+    if not dbs:
+        return {}
+    con = sqlite3.connect(dbs[0])
+    q = ("select name, avg(v) from (select name, dispatch_id, sum(counter_value) as v from pmc_events group by name, dispatch_id) "
+         "group by name")
+    return {name: avg for name, avg in con.execute(q)}
 
 
 def main(prefix):
     out = {}
     for mode in ("sparse", "dense"):
-        f = per_kernel(f"{prefix}_pmc_fetch_{mode}/pmc_results.db")
-        w = per_kernel(f"{prefix}_pmc_write_{mode}/pmc_results.db")
+        f = per_kernel(f"{prefix}_pmc_FETCH_SIZE_{mode}")
+        w = per_kernel(f"{prefix}_pmc_WRITE_SIZE_{mode}")
+        if not f or not w:
+            continue
 
         def kb(d, frag):
             return sum(v for k, v in d.items() if frag in k)
-        march = (kb(f, "march_kernel<2") + kb(f, "march_kernel<3") + kb(w, "march_kernel<2") + kb(w, "march_kernel<3") +
-                 kb(f, "ray_") + kb(w, "ray_")) * 1024
-        out[f"march_emit:{mode}:global"] = int(march)
+        for name, frag in (("march_tails", "march_tail_kernel"), ("march_free", "march_free_kernel"), ("tile_resolve", "tile_resolve_kernel"),
+                           ("ray_setup", "ray_s"), ("tile_bin", "tile_")):
+            if name == "tile_bin":
+                val = (kb(f, "tile_count") + kb(f, "tile_blockscan") + kb(f, "tile_list") + kb(f, "desc_place") + kb(w, "tile_count") +
+                       kb(w, "tile_blockscan") + kb(w, "tile_list") + kb(w, "desc_place")) * 1024
+            else:
+                val = (kb(f, frag) + kb(w, frag)) * 1024
+            out[f"{name}:{mode}"] = int(val)
+        scatter = sum(out[f"{k}:{mode}"] for k in ("march_tails", "march_free", "tile_resolve", "ray_setup", "tile_bin"))
+        out[f"scatter_total:{mode}"] = int(scatter)
         if mode == "dense":
-            out["integrate:dense:global"] = int((2 * kb(f, "integrate_dense") + kb(w, "integrate_dense")) * 1024)
-        else:
-            out["integrate:sparse:global"] = int((kb(f, "integrate_sparse") + kb(w, "integrate_sparse")) * 1024)
+            out["integrate:dense"] = int((2 * kb(f, "integrate_dense") + kb(w, "integrate_dense")) * 1024)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)

@@ -876,34 +876,48 @@ struct AccArgs
   int64_t *partials;    // [REG_BLOCKS][REG_SLOTS] (buffer 0)
 };
 
+// The three kernels of the sharded path hand small results to each other through HBM.  When they are replayed as nodes of a
+// HIP graph, the runtime (ROCm 7.0) does not give a later node the cache maintenance a stream gives a later kernel: a
+// batch of 16 iterations converged after ~25 instead of 178 because nodes read stale lines of their XCD's L2 (measured;
+// one iteration per graph was fine).  So everything that crosses a kernel boundary here is written and read at agent
+// scope (sc1: performed at the coherent level, like the exchange inside the resident loop).
+__device__ __forceinline__ int32_t coherent_i32(const int32_t *p) { return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coherent_f32(const float *p) { return __hip_atomic_load(const_cast<float *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int64_t coherent_i64(const int64_t *p) { return __hip_atomic_load(const_cast<int64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_i64(int64_t *p, int64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool loop_over(const GnState *state)
+{
+  return coherent_i32(&state->core.finished) != 0 || coherent_i32(&state->core.iterations) >= coherent_i32(&state->core.max_iterations);
+}
+
 __global__ __launch_bounds__(REG_THREADS) void reg_accumulate_kernel(AccArgs a)
 {
   __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
   __shared__ int64_t red[REG_SLOTS];
-  if (a.state != nullptr && (a.state->core.finished || a.state->core.iterations >= a.state->core.max_iterations)) return;
+  if (a.state != nullptr && loop_over(a.state)) return;
   float T[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) T[i] = a.T[i];
+  for (int i = 0; i < 16; ++i) T[i] = coherent_f32(&a.T[i]);
   int64_t acc[REG_SLOTS];
 #pragma unroll
   for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
   accumulate_points(a.pts, T, prefetch_points(a.pts), acc);
   block_reduce32(acc, wave_part, red);
-  if (threadIdx.x < REG_SLOTS) a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x] = red[threadIdx.x];
+  if (threadIdx.x < REG_SLOTS) publish_i64(&a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *partials, const GnState *state, int64_t *sums_out)
 {
   __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
   __shared__ int64_t red[REG_SLOTS];
-  if (state != nullptr && (state->core.finished || state->core.iterations >= state->core.max_iterations)) return;
-  sum_partials(partials, wave_part, red);
+  if (state != nullptr && loop_over(state)) return;
+  sum_partials<true>(partials, wave_part, red);
   if (threadIdx.x == 0)
   {
     int64_t sums[44];
     expand_sums(red, sums);
 #pragma unroll
-    for (int k = 0; k < 44; ++k) sums_out[k] = sums[k];
+    for (int k = 0; k < 44; ++k) publish_i64(&sums_out[k], sums[k]);
   }
 }
 
@@ -911,17 +925,29 @@ __global__ __launch_bounds__(REG_THREADS) void reg_sum_kernel(const int64_t *par
 __global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int64_t *sums_dev)
 {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-  GnCore st = state->core;
+  GnCore st;
+  {
+    // the state the previous solve (or ws_reg_begin) left: read and written word by word at agent scope
+    int32_t *w = reinterpret_cast<int32_t *>(&st);
+    const int32_t *src = reinterpret_cast<const int32_t *>(&state->core);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) w[i] = coherent_i32(&src[i]);
+  }
+  __shared__ int64_t s[44];
+  if (threadIdx.x < 44) s[threadIdx.x] = coherent_i64(&sums_dev[threadIdx.x]);
+  __syncthreads();
   gn_update(
-      st, [sums_dev](int r, int c) { return sums_dev[c * 6 + r]; }, [sums_dev](int r) { return sums_dev[36 + r]; }, (int32_t)sums_dev[42],
-      (int32_t)sums_dev[43]);
+      st, [](int r, int c) { return s[c * 6 + r]; }, [](int r) { return s[36 + r]; }, (int32_t)s[42], (int32_t)s[43]);
   if (threadIdx.x == 0)
   {
-    state->core = st;
+    const int32_t *w = reinterpret_cast<const int32_t *>(&st);
+    int32_t *dst = reinterpret_cast<int32_t *>(&state->core);
 #pragma unroll
-    for (int k = 0; k < 42; ++k) state->sums[k] = sums_dev[k];
-    state->sums[42] = (int64_t)(int32_t)sums_dev[42];
-    state->sums[43] = (int64_t)(int32_t)sums_dev[43];
+    for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) __hip_atomic_store(&dst[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 42; ++k) publish_i64(&state->sums[k], s[k]);
+    publish_i64(&state->sums[42], (int64_t)(int32_t)s[42]);
+    publish_i64(&state->sums[43], (int64_t)(int32_t)s[43]);
   }
 }
 

@@ -126,6 +126,37 @@ class _GraphBatch:
     def run(self):
         self._run()
 
+    def validate(self, backend, first, count, group, T_in, it_weight_gradient, epsilon) -> bool:
+        """A captured batch must do exactly what the same launches do on a stream (integer sums: bit for bit).  ROCm 7.0
+        replays consecutive kernel nodes without the cache maintenance a stream gives consecutive kernels; the kernels
+        here exchange their results at agent scope because of that, and this check catches a runtime where even that is
+        not enough: on a mismatch the batch falls back to eager launches (all ranks together)."""
+        if self.graph is None:
+            return True
+        import torch
+        import torch.distributed as dist
+        ok = True
+        for _ in range(2):
+            backend.begin(T_in, self.batch, it_weight_gradient, epsilon)
+            self._eager(backend, first, count, group, self.batch)
+            a = backend.poll()
+            backend.begin(T_in, self.batch, it_weight_gradient, epsilon)
+            self.graph.replay()
+            b = backend.poll()
+            ok = ok and a[1] == b[1] and np.array_equal(a[2], b[2])
+        if dist.is_initialized():
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(int(flag.item()))
+        if not ok:
+            import sys
+            print("[warpsense_amd.dist] a replayed HIP graph of Gauss-Newton iterations differs from the same launches on a "
+                  "stream: staying with eager launches", file=sys.stderr)
+            self.graph = None
+            batch = self.batch
+            self._run = lambda: self._eager(backend, first, count, group, batch)
+        return ok
+
 
 def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it_weight_gradient: float, epsilon: float,
                            group=None, batch: int = 16, graphs: dict | None = None):
@@ -147,6 +178,8 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
         if runner is None:
             backend.begin(T_in, 1, it_weight_gradient, epsilon)  # a throw-away state for the warm-up / capture launches
             runner = _GraphBatch(backend, first, count, group, batch)
+            if hasattr(backend, "reg"):
+                runner.validate(backend, first, count, group, T_in, it_weight_gradient, epsilon)
         graphs[key] = runner  # most recently used last
         while len(graphs) > GRAPH_CACHE_MAX:
             graphs.pop(next(iter(graphs)))
