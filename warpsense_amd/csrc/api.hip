@@ -213,7 +213,7 @@ static int map_free(ws_map *m)
       break;
     }
   map_free_records(m);
-  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_order, m->rays, m->scan_dev, m->counters, m->tile_nruns,
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->az_cur, m->ray_order, m->rays, m->scan_dev, m->counters, m->tile_nruns,
                   m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -296,10 +296,10 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   m->nty = (size[1] + (1 << TILE_YB) - 1) >> TILE_YB;
   m->ntz = (size[2] + (1 << TILE_ZB) - 1) >> TILE_ZB;
   m->n_tiles = (int64_t)m->ntx * m->nty * m->ntz;
-  if (m->n_tiles >= 0xffffffffll)
+  if (m->n_tiles >= 0x7fffffffll)
   {
     delete m;
-    return invalid("ws_map_create: more than 2^32 tiles");
+    return invalid("ws_map_create: more than 2^31 tiles");
   }
   m->scan_blocks = tile_scan_blocks(m->n_tiles);
   m->tau = tau;
@@ -329,6 +329,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->az_cur, AZ_ALLOC * sizeof(uint32_t)));
+  TRY(hipMemsetAsync(m->az_cur, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->az_hist, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->az_off, 0, AZ_ALLOC * sizeof(uint32_t), s));
@@ -744,7 +746,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   out->tiles = c->last_listed;
   out->runs = c->last_runs;
   out->free_space_hits = c->last_free_keyed;
-  out->record_slots = c->raw_cursor;
+  out->record_slots = c->last_slots;
   out->record_capacity = m->rec_cap;
   const int rc = map_take_error(m);
   out->error_flags = (int32_t)m->last_error_bits;

@@ -50,7 +50,8 @@ struct ScatterArgs
   int32_t keyed_slack;   // see ray_setup_kernel
   RaySetup *rays;
   uint32_t *az_hist;   // [AZ_BINS + 1] rays per direction bin (last bin: rays that contribute nothing)
-  uint32_t *az_off;    // [AZ_BINS + 2] exclusive scan of az_hist
+  uint32_t *az_off;    // [AZ_BINS]: number of rays that contribute (written by the direction sort)
+  uint32_t *az_cur;    // [AZ_BINS + 1] placement cursors of the direction sort (zero at the start of a scan)
   uint32_t *ray_order; // ray indices sorted by direction bin
   uint8_t *vstate;     // one byte per voxel: VOX_*
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
@@ -111,15 +112,32 @@ __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
 }
 
 // everything the scatter expects to be zero / empty, in ONE launch (five memsets cost five launch gaps)
-__global__ __launch_bounds__(256) void scatter_prep_kernel(TsdfCounters *counters, uint32_t *az_hist, uint32_t n_hist, uint32_t *tile_nruns, int64_t n_tiles,
-                                                           unsigned long long *fk, int64_t n_fk)
+struct PrepArgs
+{
+  TsdfCounters *counters;
+  uint32_t *az_hist, *az_cur;
+  uint32_t n_hist;
+  uint32_t *tile_nruns;
+  int64_t n_tiles;
+  unsigned long long *fk; // keys and values: one allocation
+  int64_t n_fk;
+  unsigned long long *look; // look-back words of the tile scan
+  uint32_t n_look;
+};
+__device__ __forceinline__ void scatter_prep(const PrepArgs &p, bool counters_too)
 {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-  if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(counters)[tid] = 0;
-  for (int64_t i = tid; i < n_hist; i += stride) az_hist[i] = 0;
-  for (int64_t i = tid; i < n_tiles; i += stride) tile_nruns[i] = 0;
-  for (int64_t i = tid; i < n_fk; i += stride) fk[i] = KEY_INF; // keys and values: one allocation
+  if (counters_too && tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
+  for (int64_t i = tid; i < p.n_hist; i += stride)
+  {
+    p.az_hist[i] = 0;
+    p.az_cur[i] = 0;
+  }
+  for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nruns[i] = 0;
+  for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
+  for (int64_t i = tid; i < p.n_look; i += stride) p.look[i] = 0;
 }
+__global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter_prep(p, true); }
 
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
 __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
@@ -290,16 +308,18 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
   }
 }
 
-// exclusive scan of the AZ_BINS + 1 histogram entries (one workgroup), histogram reset for use as cursors
-__global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t *off)
+// Counting sort of the rays by direction bin.  Every workgroup scans the 8193-entry histogram itself (32 KB from L2,
+// one block scan) instead of waiting for a one-workgroup scan kernel in between: one launch less on the critical path.
+__global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
 {
-  __shared__ uint32_t wave_sums[16];
+  __shared__ uint32_t s_off[AZ_BINS + 2];
+  __shared__ uint32_t wave_sums[4];
   constexpr int TOTAL = AZ_BINS + 1;
-  constexpr int PER = (TOTAL + 1023) / 1024;
+  constexpr int PER = (TOTAL + 255) / 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lo = threadIdx.x * PER, hi = min(lo + PER, TOTAL);
   uint32_t v = 0;
-  for (int i = lo; i < hi; ++i) v += hist[i];
+  for (int i = lo; i < hi; ++i) v += a.az_hist[i];
   uint32_t x = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1)
@@ -313,20 +333,16 @@ __global__ __launch_bounds__(1024) void ray_scan_kernel(uint32_t *hist, uint32_t
   for (int w = 0; w < wave; ++w) run += wave_sums[w];
   for (int i = lo; i < hi; ++i)
   {
-    const uint32_t c = hist[i];
-    off[i] = run;
-    hist[i] = 0;
-    run += c;
+    s_off[i] = run;
+    run += a.az_hist[i];
   }
-  if (hi == TOTAL && lo < hi) off[TOTAL] = run; // off[AZ_BINS] = rays that contribute, off[AZ_BINS + 1] = all rays
-}
-
-__global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
-{
+  if (hi == TOTAL && lo < hi) s_off[TOTAL] = run;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.az_off[AZ_BINS] = s_off[AZ_BINS]; // rays that contribute: the tail march's grid
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix >= a.n) return;
   const uint32_t bin = ((uint32_t)a.rays[ix].pad >> 1) & 0x3fffu;
-  a.ray_order[a.az_off[bin] + atomicAdd(&a.az_hist[bin], 1u)] = ix;
+  a.ray_order[s_off[bin] + atomicAdd(&a.az_cur[bin], 1u)] = ix;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1079,6 +1095,91 @@ __global__ __launch_bounds__(256) void tile_list_kernel(TileScanArgs a)
   }
 }
 
+// The three kernels above as ONE launch for maps whose scan fits the chip (every workgroup resident: no workgroup waits for
+// one that has not started): each workgroup publishes the (runs, listed) total of its 4096 tiles in a single 64-bit word
+// — status in the top two bits, so value and flag cannot be seen apart — and looks back over its predecessors' words
+// (aggregate or inclusive prefix) for its own exclusive prefix.  `look` is zero at the start of a scan (prep).
+constexpr unsigned long long LOOK_AGG = 1ull << 62, LOOK_INCL = 2ull << 62, LOOK_MASK = 3ull << 62;
+constexpr uint32_t LOOKBACK_MAX_BLOCKS = 2048;
+__device__ __forceinline__ unsigned long long look_pack(unsigned long long v) { return (v & 0x7fffffffull) | ((v >> 32) << 31); } // runs(31) | listed(31)
+__device__ __forceinline__ unsigned long long look_unpack(unsigned long long w) { return (w & 0x7fffffffull) | (((w >> 31) & 0x7fffffffull) << 32); }
+
+__global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned long long *look)
+{
+  __shared__ unsigned long long wave_sums[4];
+  __shared__ unsigned long long s_prefix;
+  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
+  uint32_t nr[SCAN_TILES_PER_THREAD];
+  uint32_t listed = 0; // bit mask
+  unsigned long long mine = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+  {
+    const int64_t t = t0 + j;
+    nr[j] = 0;
+    if (t < a.n_tiles)
+    {
+      nr[j] = a.tile_nruns[t];
+      const bool dirty = a.tile_dirty[t] != 0;
+      if (dirty) a.tile_dirty[t] = 0;
+      mine += nr[j];
+      if (nr[j] || dirty)
+      {
+        mine += 1ull << 32;
+        listed |= 1u << j;
+      }
+    }
+  }
+  unsigned long long total;
+  const unsigned long long excl = block_scan_u64(mine, wave_sums, total);
+  if (threadIdx.x == 0)
+  {
+    const uint32_t b = blockIdx.x;
+    unsigned long long prefix = 0;
+    if (b > 0)
+    {
+      __hip_atomic_store(&look[b], LOOK_AGG | look_pack(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t j = (int64_t)b - 1; j >= 0; --j)
+      {
+        unsigned long long w;
+        do
+          w = __hip_atomic_load(&look[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((w & LOOK_MASK) == 0);
+        prefix += look_unpack(w & ~LOOK_MASK);
+        if ((w & LOOK_MASK) == LOOK_INCL) break;
+      }
+    }
+    __hip_atomic_store(&look[b], LOOK_INCL | look_pack(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_prefix = prefix;
+    if (b == gridDim.x - 1)
+    {
+      a.counters->n_desc_sorted = (uint32_t)(prefix + total);
+      a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
+    }
+  }
+  __syncthreads();
+  uint32_t run_off = (uint32_t)excl + (uint32_t)s_prefix;
+  uint32_t list_off = (uint32_t)(excl >> 32) + (uint32_t)(s_prefix >> 32);
+#pragma unroll
+  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+  {
+    if (!(listed & (1u << j))) continue;
+    const int64_t t = t0 + j;
+    if (nr[j]) a.tile_begin[t] = run_off;
+    TileEntry e;
+    e.tile = (uint32_t)t;
+    e.desc_begin = run_off;
+    e.nruns = nr[j];
+    e.tz = (int32_t)((uint32_t)t % (uint32_t)a.ntz);
+    e.ty = (int32_t)(((uint32_t)t / (uint32_t)a.ntz) % (uint32_t)a.nty);
+    e.tx = (int32_t)((uint32_t)t / ((uint32_t)a.ntz * (uint32_t)a.nty));
+    e.pad[0] = e.pad[1] = 0;
+    a.tile_list[list_off] = e;
+    run_off += nr[j];
+    list_off += 1;
+  }
+}
+
 // run descriptors grouped by tile: the tile's counter of runs doubles as its placement cursor (and ends at zero)
 __global__ __launch_bounds__(256) void desc_place_kernel(const RunDesc *desc, uint32_t desc_cap, uint32_t *tile_nruns, const uint32_t *tile_begin,
                                                          uint32_t *sorted_desc, const TsdfCounters *counters)
@@ -1743,8 +1844,11 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 
 // bookkeeping after an update: statistics of the scan (no shared counters in the hot kernels: per-workgroup slots)
 __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, const uint32_t *tail_stats, uint32_t n_tail, const uint32_t *resolve_stats,
-                                                            uint32_t n_resolve, uint32_t *status)
+                                                            uint32_t n_resolve, uint32_t *status, PrepArgs prep)
 {
+  // every workgroup: leave the scatter's scratch zero / empty for the NEXT scan (it then starts without a prep launch)
+  scatter_prep(prep, false);
+  if (blockIdx.x != 0) return;
   __shared__ uint32_t part[12];
   uint32_t rec = 0, con = 0, fh = 0;
   for (uint32_t i = threadIdx.x; i < n_tail; i += 256) rec += tail_stats[i];
@@ -1773,9 +1877,14 @@ __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, con
     c->last_free_keyed = part[2] + part[5] + part[8] + part[11];
     c->last_listed = c->n_listed;
     c->last_runs = c->desc_cursor;
+    c->last_slots = c->raw_cursor;
     // capacity hint for the host (read without synchronisation before the next scan)
     *reinterpret_cast<volatile unsigned long long *>(status + 2) = c->ub_total;
   }
+  __syncthreads();
+  // the per-scan counters: zero for the next scan (n_listed stays: a separate integrate pass may still follow)
+  if (threadIdx.x < offsetof(TsdfCounters, last_records) / 4 && threadIdx.x != offsetof(TsdfCounters, n_listed) / 4)
+    reinterpret_cast<uint32_t *>(c)[threadIdx.x] = 0;
 }
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
@@ -1907,6 +2016,30 @@ int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
   return WS_OK;
 }
 
+constexpr int PREP_GRID = 512;
+static PrepArgs make_prep_args(ws_map *m)
+{
+  PrepArgs p;
+  p.counters = m->counters;
+  p.az_hist = m->az_hist;
+  p.az_cur = m->az_cur;
+  p.n_hist = (uint32_t)(AZ_BINS + 1);
+  p.tile_nruns = m->tile_nruns;
+  p.n_tiles = m->n_tiles;
+  p.fk = m->fk_keys;
+  p.n_fk = (int64_t)2 * m->fk_slots;
+  p.look = reinterpret_cast<unsigned long long *>(m->block_sums);
+  p.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
+  return p;
+}
+int launch_scatter_prep(ws_map *m)
+{
+  hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), dim3(256), 0, m->ctx->stream, make_prep_args(m));
+  WS_HIP(hipGetLastError());
+  m->prepped = true;
+  return WS_OK;
+}
+
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
   ws_context *ctx = m->ctx;
@@ -1916,7 +2049,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   if (n == 0)
   {
     WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, last_records), s));
-    return WS_OK;
+    return WS_OK; // (nothing listed: a following integrate pass has nothing to do)
   }
 
   const bool s0 = !m->new_is_default;
@@ -1946,6 +2079,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.rays = (RaySetup *)m->rays;
   sa.az_hist = m->az_hist;
   sa.az_off = m->az_off;
+  sa.az_cur = m->az_cur;
   sa.ray_order = m->ray_order;
   sa.vstate = m->vstate;
   sa.tile_dirty = m->tile_dirty;
@@ -1974,11 +2108,10 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   m->tail_blocks = grid_tail.x;
 
   prof_begin(ctx, WS_K_SETUP);
-  // (az_hist: the direction sort leaves its cursors there; fk: keys followed by values in one allocation)
-  hipLaunchKernelGGL(scatter_prep_kernel, dim3(512), block, 0, s, m->counters, m->az_hist, (uint32_t)(AZ_BINS + 1), m->tile_nruns, m->n_tiles,
-                     m->fk_keys, s0 ? (int64_t)0 : (int64_t)2 * m->fk_slots);
+  // normally the previous update's finish pass has already left everything zero / empty (m->prepped)
+  if (!m->prepped) hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), block, 0, s, make_prep_args(m));
+  m->prepped = false;
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
-  hipLaunchKernelGGL(ray_scan_kernel, dim3(1), dim3(1024), 0, s, m->az_hist, m->az_off);
   hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
   prof_end(ctx, WS_K_SETUP);
   if (!m->capacity_known)
@@ -2024,9 +2157,16 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ta.nty = m->nty;
   ta.ntz = m->ntz;
   ta.counters = m->counters;
-  hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
-  hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
-  hipLaunchKernelGGL(tile_list_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+  if (m->scan_blocks <= LOOKBACK_MAX_BLOCKS)
+  {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums));
+  }
+  else
+  {
+    hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+    hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
+    hipLaunchKernelGGL(tile_list_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+  }
   hipLaunchKernelGGL(desc_place_kernel, dim3(256), block, 0, s, (const RunDesc *)m->desc, m->desc_cap, m->tile_nruns, (const uint32_t *)m->tile_begin,
                      m->sorted_desc, (const TsdfCounters *)m->counters);
   prof_end(ctx, WS_K_TILE_BIN);
@@ -2104,9 +2244,10 @@ int launch_tsdf_integrate(ws_map *m)
     }
     prof_end(ctx, WS_K_INTEGRATE);
   }
-  hipLaunchKernelGGL(finish_update_kernel, dim3(1), block, 0, s, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
-                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev);
+  hipLaunchKernelGGL(finish_update_kernel, dim3(PREP_GRID), block, 0, s, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
+                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev, make_prep_args(m));
   WS_HIP(hipGetLastError());
+  m->prepped = true;
   m->fused_done = false;
   m->new_is_default = true;
   return WS_OK;

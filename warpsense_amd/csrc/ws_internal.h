@@ -90,7 +90,8 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t last_listed;
   uint32_t last_runs;
   uint32_t last_free_keyed;
-  uint32_t pad1[3];
+  uint32_t last_slots; // record slots the last scan reserved
+  uint32_t pad1[2];
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -142,7 +143,8 @@ struct ws_map
   uint32_t *data[2] = {nullptr, nullptr};
   uint8_t *vstate = nullptr; // one byte per voxel: keyed / touched by free space / free-space hit on a keyed voxel
   void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
-  uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
+  uint32_t *az_hist = nullptr, *az_off = nullptr, *az_cur = nullptr, *ray_order = nullptr; // rays grouped by direction bin
+  bool prepped = false; // the scatter's scratch (histograms, tile counters, free-space hash) is zero / empty
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
   int integrate_mode = WS_INTEGRATE_SPARSE;
@@ -255,6 +257,7 @@ void prof_end(ws_context *ctx, int cls);
 // launchers implemented in the .hip files
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
+int launch_scatter_prep(ws_map *m);
 int resize_records(ws_map *m, uint64_t records); // api.hip: (re)allocate the candidate-record buffers
 uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
