@@ -808,15 +808,19 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
 }
 
 constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
+#ifndef WS_FREE_LANES
+#define WS_FREE_LANES 8
+#endif
+constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space part of one ray
 
-// 8 rays per workgroup, 32 lanes per ray: lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
+// 32 rays per workgroup, 8 lanes per ray (measured: 32 lanes 163 us, 16: 146, 8: 141, 4: 147, 1: 280): lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
 // so every lane has the same amount of work whatever the ray length.  Waves whose rays are all RAY_SIMPLE use the
 // compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
 __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 {
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
-  const uint32_t ix = blockIdx.x * 8u + (threadIdx.x >> 5);
-  const int32_t c = (int32_t)(threadIdx.x & 31u);
+  const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
+  const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
   const int lane = threadIdx.x & 63;
   RaySetup r;
   r.steps = 0;
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
   r.pad = 0;
   if (ix < a.n) r = a.rays[ix];
   const int32_t kend = min(r.steps, r.kfirst);
-  const int32_t ch = (kend + 31) / 32;
+  const int32_t ch = (kend + FREE_LANES - 1) / FREE_LANES;
   const int32_t k0 = c * ch;
   const int32_t k1 = min(k0 + ch, kend);
   const bool work = k0 < k1;
@@ -1235,13 +1239,13 @@ __device__ __forceinline__ uint64_t neg_key(uint64_t key, int32_t av, int32_t va
 }
 
 template <class F>
-__device__ __forceinline__ void for_each_record(const TileEntry &te, const uint32_t *sorted_desc, const CandRecord *recs, F &&f)
+__device__ __forceinline__ void for_each_record(uint32_t desc_begin, uint32_t nruns, const uint32_t *sorted_desc, const CandRecord *recs, F &&f)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t r = (uint32_t)wave; r < te.nruns; r += 4)
+  for (uint32_t r = (uint32_t)wave; r < nruns; r += 4)
   {
-    const uint32_t start = sorted_desc[2 * (size_t)(te.desc_begin + r)];
-    const uint32_t count = sorted_desc[2 * (size_t)(te.desc_begin + r) + 1];
+    const uint32_t start = sorted_desc[2 * (size_t)(desc_begin + r)];
+    const uint32_t count = sorted_desc[2 * (size_t)(desc_begin + r) + 1];
     for (uint32_t i = (uint32_t)lane; i < count; i += 64)
     {
       const u32x4 rec = *reinterpret_cast<const u32x4 *>(&recs[start + i]);
@@ -1252,7 +1256,6 @@ __device__ __forceinline__ void for_each_record(const TileEntry &te, const uint3
   }
 }
 
-constexpr int RES_MAXD = 256; // runs whose descriptors are staged in LDS (up to 64: held by the lanes of every wave)
 constexpr int RES_MAXR = 8;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
@@ -1260,10 +1263,14 @@ struct TilePre
 {
   int64_t idx0;
   int nz;
-  uint32_t my_start, my_count; // run descriptor of this lane (nruns <= 64) or of this thread (nruns <= RES_MAXD)
+  uint32_t my_start, my_count; // run descriptor `lane` of the tile (nruns <= 64)
   uint32_t vs;                 // four vstate bytes
   uint32_t s0[4];              // new_map entries (HAS_S0)
-  uint32_t existing[4];        // avg_map entries (FUSED)
+};
+// what stays of a list entry once its voxel bytes and descriptors have been requested
+struct TileRef
+{
+  uint32_t nruns, desc_begin;
 };
 // the result of a tile, written back one tile later (behind the next tile's wait for its records)
 struct TilePost
@@ -1302,8 +1309,6 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
   __shared__ unsigned long long klast[TILE_VOXELS]; // the positive candidate that was blocked last
   __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
-  __shared__ uint32_t d_start[RES_MAXD], d_prefix[RES_MAXD];
-  __shared__ unsigned long long scan_tmp[4];
   __shared__ uint32_t s_unres[2];
   const uint32_t n_list = a.counters->n_listed;
   const int32_t weight_epsilon = a.tau / 10;
@@ -1334,8 +1339,8 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
     int nz = a.map.size[2] - sz;
     p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
     p.idx0 = p.nz ? storage_index(a.map, sx, sy, sz) : 0;
-    const uint32_t which = te.nruns <= 64 ? (uint32_t)lane : threadIdx.x;
-    const bool mine = which < te.nruns && te.nruns <= RES_MAXD;
+    const uint32_t which = (uint32_t)lane;
+    const bool mine = which < te.nruns && te.nruns <= 64;
     uint32_t di = te.desc_begin + (mine ? which : 0u);
     di = di < a.desc_cap ? di : a.desc_cap - 1;
     const uint2 d = *reinterpret_cast<const uint2 *>(&a.sorted_desc[2 * (size_t)di]);
@@ -1346,11 +1351,9 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
     p.vs = 0;
     if (!HAS_S0) p.vs = *reinterpret_cast<const u32_a1 *>(a.vstate + p.idx0) & keep;
     const u32x4 z4 = {reset, reset, reset, reset};
-    u32x4 s4 = z4, e4 = z4;
+    u32x4 s4 = z4;
     if (HAS_S0) s4 = *reinterpret_cast<const u32x4_a4 *>(a.new_data + p.idx0);
-    if (FUSED) e4 = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
     p.s0[0] = s4.x; p.s0[1] = s4.y; p.s0[2] = s4.z; p.s0[3] = s4.w;
-    p.existing[0] = e4.x; p.existing[1] = e4.y; p.existing[2] = e4.z; p.existing[3] = e4.w;
   };
   // weight ramp of update_tsdf.cu:90-94; 64 * (tau + value) >= 0 is below 2^31
   auto weight_of = [&](int32_t value) -> int32_t {
@@ -1367,50 +1370,49 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
       mstate[l0 + j] = M_NONE;
     }
   };
-  // the records of a tile with at most 64 runs: every wave holds all descriptors in its lanes (prefix by a wave scan,
-  // run of a record by counting).  Returns false when the tile has more runs or more records than the registers hold.
+  // The records of a tile, in registers: every lane of every wave holds descriptor `lane` of the tile (nruns <= 64), the
+  // records are dealt out to the 256 threads round robin, up to RES_MAXR per thread, all loads in flight together.
+  // Returns false (uniform over the workgroup) when the tile has more than 64 runs or more than 256 * RES_MAXR records:
+  // the waves then stream the runs from memory in every pass (wave w the runs w, w + 4, ...).
+  // The loads are UNCONDITIONAL (clamped address) and all issued before the first result is touched: a load under a branch,
+  // or a use right behind it, makes the compiler wait for each of them in turn (eight serial round trips instead of one).
+  // (Keeping the raw 16-byte records in registers across the decide phase, to defer that one wait as well, spills.)
   unsigned long long rkey[RES_MAXR];
-  uint32_t rloc[RES_MAXR];
-  auto fetch_records = [&](const TileEntry &te, const TilePre &p) -> bool {
+  uint32_t rloc[RES_MAXR]; // voxel in the tile, 0xffffffff: no record
+  u32x4 ex_next = {0, 0, 0, 0}; // FUSED: the avg_map entries of the tile whose records are in flight
+  auto fetch_records = [&](const TileRef &te, const TilePre &p) -> bool {
+    if (FUSED) ex_next = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
 #pragma unroll
-    for (int k = 0; k < RES_MAXR; ++k)
-    {
-      rkey[k] = 0;
-      rloc[k] = 0xffffffffu;
-    }
+    for (int k = 0; k < RES_MAXR; ++k) rloc[k] = 0xffffffffu;
     if (te.nruns == 0 || te.nruns > 64) return false;
-    uint32_t incl = p.my_count;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      const uint32_t y = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += y;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    const uint32_t prefix = incl - p.my_count;
-    if (total > RES_MAXR * 256) return false;
-    uint32_t run[RES_MAXR];
-#pragma unroll
-    for (int k = 0; k < RES_MAXR; ++k) run[k] = 0;
     const int nruns = (int)te.nruns;
-    for (int i = 1; i < nruns; ++i)
-    {
-      const uint32_t pi = (uint32_t)__builtin_amdgcn_readlane((int)prefix, i);
+    // the tile's runs back to back: thread t takes the records t, t + 256, ... of that sequence.  Every wave walks ALL
+    // descriptors (scalar reads from its lanes), so all of them see the same total and take the same route.
+    uint32_t addr[RES_MAXR];
 #pragma unroll
-      for (int k = 0; k < RES_MAXR; ++k) run[k] += (pi <= (uint32_t)(k * 256) + threadIdx.x) ? 1u : 0u;
+    for (int k = 0; k < RES_MAXR; ++k) addr[k] = 0xffffffffu;
+    uint32_t pref = 0; // uniform
+    for (int r = 0; r < nruns; ++r)
+    {
+      const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)p.my_start, r);
+      const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)p.my_count, r);
+#pragma unroll
+      for (int k = 0; k < RES_MAXR; ++k)
+      {
+        const uint32_t rel = (uint32_t)(256 * k) + threadIdx.x - pref; // wraps for positions before this run
+        if (rel < count) addr[k] = start + rel;
+      }
+      pref += count;
     }
+    if (pref > (uint32_t)(256 * RES_MAXR)) return false;
+    u32x4 raw[RES_MAXR];
+#pragma unroll
+    for (int k = 0; k < RES_MAXR; ++k) raw[k] = *reinterpret_cast<const u32x4 *>(&a.recs[addr[k] != 0xffffffffu ? addr[k] : 0u]);
 #pragma unroll
     for (int k = 0; k < RES_MAXR; ++k)
     {
-      const uint32_t f = (uint32_t)(k * 256) + threadIdx.x;
-      const uint32_t rs = (uint32_t)__shfl((int)p.my_start, (int)run[k], 64);
-      const uint32_t rp = (uint32_t)__shfl((int)prefix, (int)run[k], 64);
-      if (f < total)
-      {
-        const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.recs[rs + (f - rp)]);
-        rkey[k] = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
-        rloc[k] = rec.w & (TILE_VOXELS - 1);
-      }
+      rkey[k] = (unsigned long long)raw[k].x | ((unsigned long long)raw[k].y << 32);
+      rloc[k] = addr[k] != 0xffffffffu ? (raw[k].w & (TILE_VOXELS - 1)) : 0xffffffffu;
     }
     return true;
   };
@@ -1440,11 +1442,27 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
     return;
   }
   const uint32_t last = n_list - 1;
-  TileEntry te_cur = a.tile_list[e0], te_n1 = a.tile_list[min(e0 + G, last)], te_n2 = a.tile_list[min(e0 + 2 * G, last)];
-  TilePre p_cur, p_n1;
-  request(te_cur, p_cur);
-  bool cached = fetch_records(te_cur, p_cur);
-  request(te_n1, p_n1);
+  // pipeline: tile i is processed while the voxel bytes / descriptors of tiles i+1 and i+2, the list entries up to i+3
+  // and (from the middle of the iteration on) the records of tile i+1 are in flight
+  TileEntry te_n2 = a.tile_list[min(e0 + 2 * G, last)], te_n3 = te_n2;
+  TileRef te_cur, te_n1;
+  TilePre p_cur, p_n1, p_n2;
+  {
+    const TileEntry t0 = a.tile_list[e0], t1 = a.tile_list[min(e0 + G, last)];
+    request(t0, p_cur);
+    request(t1, p_n1);
+    te_cur.nruns = t0.nruns;
+    te_cur.desc_begin = t0.desc_begin;
+    te_n1.nruns = t1.nruns;
+    te_n1.desc_begin = t1.desc_begin;
+  }
+  bool cached = fetch_records(te_cur, p_cur), cached_next = false;
+  u32x4 ex_cur = ex_next;
+  auto issue_next = [&](uint32_t e) {
+    te_n3 = a.tile_list[min(e + 3 * G, last)];
+    request(te_n2, p_n2);
+    cached_next = fetch_records(te_n1, p_n1);
+  };
   TilePost post;
   post.nz = 0;
   post.idx0 = 0;
@@ -1455,7 +1473,7 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
 
   for (uint32_t e = e0; e < n_list; e += G)
   {
-    const TileEntry te = te_cur;
+    const TileRef te = te_cur;
     const TilePre p = p_cur;
     const int nz = p.nz;
     const int64_t idx0 = p.idx0;
@@ -1470,6 +1488,7 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
 
     if (te.nruns == 0)
     {
+      issue_next(e);
       // free space only
       if (!HAS_S0)
       {
@@ -1494,42 +1513,10 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
         }
         __syncthreads();
       }
-      if (!cached && te.nruns <= RES_MAXD)
-      {
-        // 65 .. 256 runs: descriptors staged in LDS, records in registers if they fit
-        unsigned long long total64;
-        const uint32_t excl = (uint32_t)block_scan_u64(p.my_count, scan_tmp, total64);
-        d_start[threadIdx.x] = p.my_start;
-        d_prefix[threadIdx.x] = excl;
-        __syncthreads();
-        const uint32_t total = (uint32_t)total64;
-        if (te.nruns > 64 && total <= RES_MAXR * 256)
-        {
-          cached = true;
-          const int nruns = (int)te.nruns;
-#pragma unroll
-          for (int k = 0; k < RES_MAXR; ++k)
-          {
-            const uint32_t f = (uint32_t)(k * 256) + threadIdx.x;
-            if (f < total)
-            {
-              int r = 0;
-#pragma unroll
-              for (int step = RES_MAXD / 2; step > 0; step >>= 1)
-              {
-                const int c = r + step;
-                if (c < nruns && d_prefix[c] <= f) r = c;
-              }
-              const u32x4 rec = *reinterpret_cast<const u32x4 *>(&a.recs[d_start[r] + (f - d_prefix[r])]);
-              rkey[k] = (unsigned long long)rec.x | ((unsigned long long)rec.y << 32);
-              rloc[k] = rec.w & (TILE_VOXELS - 1);
-            }
-          }
-        }
-      }
       WS_TP(1)
+      bool from_regs = cached; // pass 1 and scan A; the rounds stream (the registers then hold the next tile's records)
       auto scan_records = [&](auto &&f) {
-        if (cached)
+        if (from_regs)
         {
 #pragma unroll
           for (int k = 0; k < RES_MAXR; ++k)
@@ -1543,7 +1530,7 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
         }
         else
         {
-          for_each_record(te, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+          for_each_record(te.desc_begin, te.nruns, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
             if (HAS_S0 && av >= (int32_t)bound0[l]) return;
             f(key, value, av, l);
           });
@@ -1608,6 +1595,11 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
       scan_a();
       __syncthreads();
       WS_TP(3)
+      // this tile's records are not needed again (unless it needs ordered rounds, which stream): everything the next
+      // iterations need is requested NOW and arrives under the decide phase, the barrier and the write-back
+      from_regs = false;
+      issue_next(e);
+      WS_TP(6)
 
       // ---- decide
       uint32_t unres = 0; // bit j: voxel j is still open
@@ -1740,7 +1732,7 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
 #endif
     }
 
-    // ---- this tile's result waits in registers; request what the next iterations need, all together
+    // ---- this tile's result waits in registers until the next iteration's loads have arrived
     post.idx0 = idx0;
     post.nz = nz;
     post.vs = p.vs;
@@ -1749,15 +1741,16 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
     for (int j = 0; j < 4; ++j)
     {
       post.value[j] = entry[j];
-      post.existing[j] = p.existing[j];
     }
+    post.existing[0] = ex_cur.x; post.existing[1] = ex_cur.y; post.existing[2] = ex_cur.z; post.existing[3] = ex_cur.w;
     te_cur = te_n1;
     p_cur = p_n1;
-    te_n1 = te_n2;
-    te_n2 = a.tile_list[min(e + 3 * G, last)];
-    request(te_n1, p_n1);
-    cached = fetch_records(te_cur, p_cur);
-    WS_TP(6)
+    cached = cached_next;
+    ex_cur = ex_next;
+    te_n1.nruns = te_n2.nruns;
+    te_n1.desc_begin = te_n2.desc_begin;
+    p_n1 = p_n2;
+    te_n2 = te_n3;
   }
   write_back(post);
 #ifdef WS_RESOLVE_TIMING
@@ -2104,7 +2097,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
   const dim3 grid_tail((unsigned)((n + 63) / 64));
-  const dim3 grid_free((unsigned)((n + 7) / 8));
+  const dim3 grid_free((unsigned)((n + 256 / FREE_LANES - 1) / (256 / FREE_LANES)));
   m->tail_blocks = grid_tail.x;
 
   prof_begin(ctx, WS_K_SETUP);
