@@ -139,6 +139,27 @@ __device__ __forceinline__ void scatter_prep(const PrepArgs &p, bool counters_to
 }
 __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter_prep(p, true); }
 
+// Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
+// = (k1 - k0) + sum_j #{steps with delta_z >= ceil(j*res/2)}.  Exact when every sample is a candidate; additive over ranges.
+__device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1, int64_t len_end, int32_t res)
+{
+  if (k1 <= k0) return 0;
+  unsigned long long ub = (unsigned long long)(k1 - k0);
+  if ((int64_t)DZ_PER_DISTANCE * len_end >= (1ll << 31)) return ub * 256; // DZ * len wraps in the reference's int: any fan width the key admits
+  const int64_t half = res / 2;
+  const int64_t len_last = 1 + (k1 - 1) * half;
+  for (int64_t j = 1; j < 256; ++j)
+  {
+    const int64_t cj = (j * res + 1) / 2;
+    const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
+    if (Lj > len_last) break;
+    const int64_t kj = (Lj - 1 + half - 1) / half;
+    const int64_t first = kj > k0 ? kj : k0;
+    if (first < k1) ub += (unsigned long long)(k1 - first);
+  }
+  return ub;
+}
+
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
 __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
 {
@@ -251,26 +272,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
             if (kfirst > (int32_t)steps) kfirst = (int32_t)steps;
           }
           r.kfirst = kfirst;
-          // upper bound of the tail's scatter targets: sum over its steps of iter_steps = 2*delta_z/res + 1
-          // (update_tsdf.cu:101-102) = steps + sum_j #{steps with delta_z >= ceil(j*res/2)}
-          unsigned long long ub = (unsigned long long)(steps - kfirst);
-          if ((int64_t)DZ_PER_DISTANCE * len_end >= (1ll << 31))
-          {
-            ub *= 256; // DZ * len wraps in the reference's int: any fan width the key admits
-          }
-          else
-          {
-            const int64_t len_last = 1 + (steps - 1) * half;
-            for (int64_t j = 1; j < 256; ++j)
-            {
-              const int64_t cj = (j * res + 1) / 2;
-              const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
-              if (Lj > len_last) break;
-              const int64_t kj = (Lj - 1 + half - 1) / half;
-              const int64_t first = kj > kfirst ? kj : kfirst;
-              if (first < steps) ub += (unsigned long long)(steps - first);
-            }
-          }
+          const unsigned long long ub = tail_bound(kfirst, steps, len_end, res);
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
@@ -349,6 +351,10 @@ __global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
 // ray tails -> records, sorted by tile inside the workgroup
 // ---------------------------------------------------------------------------------------------------------
 constexpr int HT_BITS = 10, HT_SLOTS = 1 << HT_BITS;
+#ifndef WS_TAIL_SPLIT
+#define WS_TAIL_SPLIT 2
+#endif
+constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
 constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DONE = 0xffffffffu;
 
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   __shared__ u32x4 s_queue[4 * TAIL_QCAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n_sorted = a.az_off[AZ_BINS];
-  const uint32_t slot = blockIdx.x * 64u + (uint32_t)lane;
+  const uint32_t slot = (blockIdx.x / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
+  const int part0 = (int)(blockIdx.x % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
   const bool has_ray = slot < n_sorted;
   uint32_t ix = 0;
   RaySetup r;
@@ -433,7 +440,13 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   }
   if (wave == 0)
   {
-    unsigned long long ub = has_ray ? r.ub : 0u;
+    unsigned long long ub = 0;
+    if (has_ray && r.steps > 0 && r.kfirst < r.steps)
+    {
+      const int32_t chp = (r.steps - r.kfirst + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
+      const int32_t ka = min(r.kfirst + part0 * chp, r.steps), kb = min(r.kfirst + (part0 + 4) * chp, r.steps);
+      ub = TAIL_SPLIT == 1 ? (unsigned long long)r.ub : tail_bound(ka, kb, (int64_t)r.distance + a.tau, a.res);
+    }
     for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
     if (lane == 0)
     {
@@ -455,6 +468,9 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   if (base == 0xffffffffu) return; // record buffer exhausted: this workgroup's candidates are lost, the error is sticky
   const uint32_t ub_total = s_ub;
 
+#ifdef WS_TAIL_TIMING
+  const long long tt0 = clock64();
+#endif
   // ---- phase 1: march, one record per scatter target
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
   const bool mark = !a.all_keyed;
@@ -491,8 +507,8 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   if (has_ray && r.steps > 0 && r.kfirst < r.steps)
   {
     const int32_t kbeg = r.kfirst, kend = r.steps;
-    const int32_t ch = (kend - kbeg + 3) / 4;
-    k0 = kbeg + wave * ch;
+    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
+    k0 = min(kbeg + (part0 + wave) * ch, kend);
     k1 = min(k0 + ch, kend);
   }
   const bool work = k0 < k1;
@@ -621,7 +637,13 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
       if (!any_alive && qtail == qhead) break;
     }
   }
+#ifdef WS_TAIL_TIMING
+  const long long tt1 = clock64();
+#endif
   __syncthreads();
+#ifdef WS_TAIL_TIMING
+  const long long tt2 = clock64();
+#endif
   const uint32_t total = min(s_cursor, ub_total);
   if (threadIdx.x == 0) a.tail_stats[blockIdx.x] = total;
   if (total == 0) return;
@@ -733,11 +755,10 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
       {
+        // unconditional (clamped) loads: four in flight; a load under a branch would be waited for on the spot
         const uint32_t i = i0 + (uint32_t)u * 256u;
-        if (i < total)
-          rec[u] = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + i]);
-        else
-          rec[u].z = REC_DONE;
+        rec[u] = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + (i < total ? i : total - 1)]);
+        if (i >= total) rec[u].z = REC_DONE;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -762,6 +783,11 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
     __syncthreads();
     if (threadIdx.x == 0) s_overflow = 0;
   }
+#ifdef WS_TAIL_TIMING
+  if ((threadIdx.x & 63) == 0 && (blockIdx.x % 97) == 5)
+    printf("tail wg %u wave %d: records %u | march %lld wait-for-others %lld phase2 %lld cycles\n", blockIdx.x, wave, total, tt1 - tt0, tt2 - tt1,
+           clock64() - tt2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2096,7 +2122,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
-  const dim3 grid_tail((unsigned)((n + 63) / 64));
+  const dim3 grid_tail((unsigned)((n + 63) / 64) * TAIL_SPLIT);
   const dim3 grid_free((unsigned)((n + 256 / FREE_LANES - 1) / (256 / FREE_LANES)));
   m->tail_blocks = grid_tail.x;
 

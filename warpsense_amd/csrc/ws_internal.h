@@ -32,7 +32,7 @@ constexpr int TILE_XB = WS_TILE_XB, TILE_YB = WS_TILE_YB, TILE_ZB = WS_TILE_ZB;
 static_assert(TILE_XB + TILE_YB + TILE_ZB == 10 && TILE_ZB >= 2, "a tile is 1024 voxels: 256 threads x 4 consecutive z");
 constexpr int TILE_VOXELS = 1 << (TILE_XB + TILE_YB + TILE_ZB); // 1024
 constexpr uint64_t KEY_INF = ~0ull;
-constexpr uint32_t WS_TAIL_STATS = 16384; // per-workgroup slots of the tail march (1 000 000 points / 64 rays), then 2 per resolve workgroup
+constexpr uint32_t WS_TAIL_STATS = 65536; // per-workgroup slots of the tail march (1 000 000 points / 64 rays x up to 4 workgroups), then 2 per resolve workgroup
 constexpr uint32_t WS_BLOCK_STATS = WS_TAIL_STATS + 2 * 4096;
 
 // ring-buffer parameters passed BY VALUE to kernels (the reference chases three device pointers per
