@@ -295,6 +295,320 @@ int run3(const char *name, uint32_t *bar, int64_t *accum, int64_t *sink)
   return 0;
 }
 
+// variant: NO arrival counter at all.  A 64-bit value travels as two words (low / high 32 bits) whose top byte counts
+// the additions: word += (1 << 56) | half.  A reader knows the word it saw two iterations ago (same parity buffer), so
+// (now - then) >> 56 is the number of workgroups that have added since and the low 56 bits are their exact sum
+// (16 x 2^32 per group never reaches bit 56): it polls the DATA until the count is complete.  Removes the wait for the
+// adds' acknowledgement, the arrival atomic and the separate read from the critical path.
+template <int NG, bool WAVE0_ONLY>
+__global__ __launch_bounds__(THREADS) void bar4_kernel(uint64_t *accum /* [2][NG][64] */, int iters, int64_t *sink)
+{
+  __shared__ uint64_t part[THREADS / 64][64];
+  constexpr int POLLERS = WAVE0_ONLY ? 64 : THREADS;
+  constexpr int PER = NG * 64 / POLLERS;
+  static_assert(PER >= 1, "words per lane");
+  constexpr uint64_t MASK = (1ull << 56) - 1;
+  uint64_t p0[PER], p1[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) p0[j] = p1[j] = 0;
+  int64_t bad = 0;
+  const int lane = threadIdx.x & 63;
+  for (int k = 1; k <= iters; ++k)
+  {
+    uint64_t *buf = accum + (size_t)(k & 1) * NG * 64;
+    const int slot = lane & 31;
+    const int64_t v = (int64_t)(k + slot) * ((slot & 1) ? -0x123456789ll : 0x123456789ll);
+    if (threadIdx.x < 64)
+    {
+      const uint32_t half = lane < 32 ? (uint32_t)(uint64_t)v : (uint32_t)((uint64_t)v >> 32);
+      __hip_atomic_fetch_add(&buf[(size_t)(blockIdx.x % NG) * 64 + lane], (1ull << 56) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint64_t s = 0;
+    if (!WAVE0_ONLY || threadIdx.x < 64)
+    {
+      uint64_t w[PER];
+      int guard = 0;
+      for (;;)
+      {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+        {
+          const int g = WAVE0_ONLY ? j : (int)(threadIdx.x >> 6) + (THREADS / 64) * j;
+          w[j] = __hip_atomic_load(&buf[(size_t)g * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((w[j] - p0[j]) >> 56) == (uint64_t)(BLOCKS / NG);
+        }
+        if (__all(ok) || ++guard > 100000000) break;
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+      {
+        s += (w[j] - p0[j]) & MASK;
+        const uint64_t t = p1[j]; // rotate the two parities
+        p1[j] = w[j];
+        p0[j] = t;
+      }
+    }
+    part[threadIdx.x >> 6][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < SLOTS)
+    {
+      uint64_t lo = 0, hi = 0;
+      for (int wv = 0; wv < THREADS / 64; ++wv)
+      {
+        lo += part[wv][threadIdx.x];
+        hi += part[wv][threadIdx.x + 32];
+      }
+      const uint64_t total = lo + (hi << 32);
+      if (total != (uint64_t)BLOCKS * (uint64_t)v) bad += 1;
+    }
+    __syncthreads();
+  }
+  if (bad != 0) atomicAdd((unsigned long long *)&sink[1], (unsigned long long)bad);
+}
+
+template <int NG, bool WAVE0_ONLY>
+int run4(const char *name, uint64_t *accum, int64_t *sink)
+{
+  const int iters = 2000;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep)
+  {
+    CK(hipMemset(accum, 0, 2 * 64 * 64 * 8));
+    CK(hipMemset(sink, 0, 16));
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((bar4_kernel<NG, WAVE0_ONLY>), dim3(BLOCKS), dim3(THREADS), 0, 0, accum, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep == 1)
+    {
+      int64_t h[2] = {0, 0};
+      CK(hipMemcpy(h, sink, 16, hipMemcpyDeviceToHost));
+      printf("%-58s %8.3f us per barrier   (wrong totals: %lld)\n", name, ms * 1000.0 / iters, (long long)h[1]);
+    }
+  }
+  return 0;
+}
+
+// counted words, polled by wave 0 only.  MODE 0: re-read only the groups that are still incomplete; MODE 1: the same
+// with s_sleep between polls; MODE 2: wave w < NW polls NG / NW groups (NW waves share the polling).
+template <int NG, int MODE, int NW>
+__global__ __launch_bounds__(THREADS) void bar5_kernel(uint64_t *accum /* [2][NG][64] */, int iters, int64_t *sink)
+{
+  __shared__ uint64_t part[THREADS / 64][64];
+  constexpr int PER = NG / NW;
+  constexpr uint64_t MASK = (1ull << 56) - 1;
+  uint64_t p0[PER], p1[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) p0[j] = p1[j] = 0;
+  int64_t bad = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 1; k <= iters; ++k)
+  {
+    uint64_t *buf = accum + (size_t)(k & 1) * NG * 64;
+    const int slot = lane & 31;
+    const int64_t v = (int64_t)(k + slot) * ((slot & 1) ? -0x123456789ll : 0x123456789ll);
+    if (threadIdx.x < 64)
+    {
+      const uint32_t half = lane < 32 ? (uint32_t)(uint64_t)v : (uint32_t)((uint64_t)v >> 32);
+      __hip_atomic_fetch_add(&buf[(size_t)(blockIdx.x % NG) * 64 + lane], (1ull << 56) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint64_t s = 0;
+    if (wave < NW)
+    {
+      uint64_t w[PER];
+      bool done[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) done[j] = false;
+      int guard = 0;
+      for (;;)
+      {
+        bool all_done = true;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+          if (!done[j]) w[j] = __hip_atomic_load(&buf[(size_t)(wave * PER + j) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+          if (!done[j])
+          {
+            done[j] = __all(((w[j] - p0[j]) >> 56) == (uint64_t)(BLOCKS / NG));
+            all_done = all_done && done[j];
+          }
+        if (all_done || ++guard > 100000000) break;
+        if (MODE == 1) __builtin_amdgcn_s_sleep(2);
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+      {
+        s += (w[j] - p0[j]) & MASK;
+        const uint64_t t = p1[j];
+        p1[j] = w[j];
+        p0[j] = t;
+      }
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < SLOTS)
+    {
+      uint64_t lo = 0, hi = 0;
+      for (int wv = 0; wv < NW; ++wv)
+      {
+        lo += part[wv][threadIdx.x];
+        hi += part[wv][threadIdx.x + 32];
+      }
+      const uint64_t total = lo + (hi << 32);
+      if (total != (uint64_t)BLOCKS * (uint64_t)v) bad += 1;
+    }
+    __syncthreads();
+  }
+  if (bad != 0) atomicAdd((unsigned long long *)&sink[1], (unsigned long long)bad);
+}
+
+template <int NG, int MODE, int NW>
+int run5(const char *name, uint64_t *accum, int64_t *sink)
+{
+  const int iters = 2000;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep)
+  {
+    CK(hipMemset(accum, 0, 2 * 64 * 64 * 8));
+    CK(hipMemset(sink, 0, 16));
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((bar5_kernel<NG, MODE, NW>), dim3(BLOCKS), dim3(THREADS), 0, 0, accum, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep == 1)
+    {
+      int64_t h[2] = {0, 0};
+      CK(hipMemcpy(h, sink, 16, hipMemcpyDeviceToHost));
+      printf("%-58s %8.3f us per barrier   (wrong totals: %lld)\n", name, ms * 1000.0 / iters, (long long)h[1]);
+    }
+  }
+  return 0;
+}
+
+// counted words, wave 0 polls with 128-bit loads: accumulators laid out [NG / 2][64 lanes][2 groups]
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int NG, int NW>
+__global__ __launch_bounds__(THREADS) void bar6_kernel(uint64_t *accum, int iters, int64_t *sink)
+{
+  __shared__ uint64_t part[THREADS / 64][64];
+  constexpr int PER = NG / 2 / NW; // 128-bit loads per lane
+  constexpr uint64_t MASK = (1ull << 56) - 1;
+  uint64_t p0[2 * PER], p1[2 * PER];
+#pragma unroll
+  for (int j = 0; j < 2 * PER; ++j) p0[j] = p1[j] = 0;
+  int64_t bad = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 1; k <= iters; ++k)
+  {
+    uint64_t *buf = accum + (size_t)(k & 1) * NG * 64;
+    const int slot = lane & 31;
+    const int64_t v = (int64_t)(k + slot) * ((slot & 1) ? -0x123456789ll : 0x123456789ll);
+    if (threadIdx.x < 64)
+    {
+      const uint32_t half = lane < 32 ? (uint32_t)(uint64_t)v : (uint32_t)((uint64_t)v >> 32);
+      const int g = blockIdx.x % NG;
+      __hip_atomic_fetch_add(&buf[((size_t)(g >> 1) * 64 + lane) * 2 + (g & 1)], (1ull << 56) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint64_t s = 0;
+    if (wave < NW)
+    {
+      uint64_t w[2 * PER];
+      int guard = 0;
+      for (;;)
+      {
+        u32x4_t q[PER];
+        const uint64_t *src = &buf[((size_t)(wave * PER) * 64 + lane) * 2]; // + j KB
+        if constexpr (PER == 2)
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q[0]), "=&v"(q[1]) : "v"(src) : "memory");
+        else if constexpr (PER == 4)
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                       "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(src) : "memory");
+        else
+        {
+          static_assert(PER == 8, "PER");
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                       "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(src) : "memory");
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                       "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]) : "v"(src + 512) : "memory");
+        }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+        {
+          w[2 * j] = (uint64_t)q[j].x | ((uint64_t)q[j].y << 32);
+          w[2 * j + 1] = (uint64_t)q[j].z | ((uint64_t)q[j].w << 32);
+          ok = ok && ((w[2 * j] - p0[2 * j]) >> 56) == (uint64_t)(BLOCKS / NG) && ((w[2 * j + 1] - p0[2 * j + 1]) >> 56) == (uint64_t)(BLOCKS / NG);
+        }
+        if (__all(ok) || ++guard > 2000000) break;
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * PER; ++j)
+      {
+        s += (w[j] - p0[j]) & MASK;
+        const uint64_t t = p1[j];
+        p1[j] = w[j];
+        p0[j] = t;
+      }
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < SLOTS)
+    {
+      uint64_t lo = 0, hi = 0;
+      for (int wv = 0; wv < NW; ++wv)
+      {
+        lo += part[wv][threadIdx.x];
+        hi += part[wv][threadIdx.x + 32];
+      }
+      const uint64_t total = lo + (hi << 32);
+      if (total != (uint64_t)BLOCKS * (uint64_t)v) bad += 1;
+    }
+    __syncthreads();
+  }
+  if (bad != 0) atomicAdd((unsigned long long *)&sink[1], (unsigned long long)bad);
+}
+
+template <int NG, int NW>
+int run6(const char *name, uint64_t *accum, int64_t *sink)
+{
+  const int iters = 2000;
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int rep = 0; rep < 2; ++rep)
+  {
+    CK(hipMemset(accum, 0, 2 * 64 * 64 * 8));
+    CK(hipMemset(sink, 0, 16));
+    CK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((bar6_kernel<NG, NW>), dim3(BLOCKS), dim3(THREADS), 0, 0, accum, iters, sink);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep == 1)
+    {
+      int64_t h[2] = {0, 0};
+      CK(hipMemcpy(h, sink, 16, hipMemcpyDeviceToHost));
+      printf("%-58s %8.3f us per barrier   (wrong totals: %lld)\n", name, ms * 1000.0 / iters, (long long)h[1]);
+    }
+  }
+  return 0;
+}
+
 int main()
 {
   uint32_t *bar, *flags;
@@ -325,5 +639,28 @@ int main()
   if (run3<16>("atomic adds into 16 group accumulators, 16 counters", bar, accum, sink)) return 1;
   if (run3<32>("atomic adds into 32 group accumulators, 16 counters", bar, accum, sink)) return 1;
   if (run3<64>("atomic adds into 64 group accumulators, 16 counters", bar, accum, sink)) return 1;
+  uint64_t *counted;
+  CK(hipMalloc((void **)&counted, 2 * 64 * 64 * 8));
+  if (run4<4, false>("counted words, 4 groups, all waves poll", counted, sink)) return 1;
+  if (run4<8, false>("counted words, 8 groups, all waves poll", counted, sink)) return 1;
+  if (run4<16, false>("counted words, 16 groups, all waves poll", counted, sink)) return 1;
+  if (run4<32, false>("counted words, 32 groups, all waves poll", counted, sink)) return 1;
+  if (run4<64, false>("counted words, 64 groups, all waves poll", counted, sink)) return 1;
+  if (run4<4, true>("counted words, 4 groups, wave 0 polls", counted, sink)) return 1;
+  if (run4<8, true>("counted words, 8 groups, wave 0 polls", counted, sink)) return 1;
+  if (run4<16, true>("counted words, 16 groups, wave 0 polls", counted, sink)) return 1;
+  if (run6<8, 1>("counted, 8 groups, wave 0, 128-bit loads", counted, sink)) return 1;
+  if (run6<8, 2>("counted, 8 groups, 2 waves, 128-bit loads", counted, sink)) return 1;
+  if (run6<16, 1>("counted, 16 groups, wave 0, 128-bit loads", counted, sink)) return 1;
+  if (run6<4, 1>("counted, 4 groups, wave 0, 128-bit loads", counted, sink)) return 1;
+  if (run4<8, true>("counted words, 8 groups, wave 0 polls (again)", counted, sink)) return 1;
+  if (run5<8, 0, 1>("counted, 8 groups, wave 0, re-read incomplete only", counted, sink)) return 1;
+  if (run5<8, 1, 1>("counted, 8 groups, wave 0, incomplete only + sleep", counted, sink)) return 1;
+  if (run5<8, 0, 2>("counted, 8 groups, 2 waves, incomplete only", counted, sink)) return 1;
+  if (run5<16, 0, 1>("counted, 16 groups, wave 0, incomplete only", counted, sink)) return 1;
+  if (run5<16, 0, 2>("counted, 16 groups, 2 waves, incomplete only", counted, sink)) return 1;
+  if (run5<16, 1, 2>("counted, 16 groups, 2 waves, incomplete only + sleep", counted, sink)) return 1;
+  if (run5<4, 0, 1>("counted, 4 groups, wave 0, incomplete only", counted, sink)) return 1;
+  if (run5<2, 0, 1>("counted, 2 groups, wave 0, incomplete only", counted, sink)) return 1;
   return 0;
 }

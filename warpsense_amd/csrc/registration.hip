@@ -15,8 +15,8 @@
 //            LDS across the waves, one 29-word partial per workgroup.
 // No Jacobian / value / mask arrays ever reach HBM (the reference writes and re-reads 51 B per point).
 //
-// reg_loop_kernel (default) runs ALL iterations in one launch: resident workgroups, a grid barrier between the
-// iterations, partial sums exchanged through wrapping group accumulators, a per-lane voxel cache.
+// reg_loop_kernel (default) runs ALL iterations in one launch: resident workgroups, partial sums exchanged through
+// wrapping group accumulators whose words count their additions (the exchange is the barrier), a per-lane voxel cache.
 // reg_iter_kernel is one launch per iteration (state and 256 x 32 partials double buffered by launch parity, so no
 // fences or atomics are needed); it is the fallback when the grid cannot be resident, and the A/B reference.
 #include "ws_device.h"
@@ -649,50 +649,95 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
 // The launch boundary between two iterations above costs ~5.5 us (dispatch of 256 workgroups, end-of-kernel
 // cache write-back, the gap to the next launch) for ~10 us of work.  reg_loop_kernel keeps the 256
 // workgroups resident (one per CU, checked on the host before the launch) and replaces the boundary by a
-// grid barrier: a monotonic arrival counter in HBM, release/acquire at agent scope around it.  The
+// grid-wide exchange of the partial sums that is its own barrier (below).  The
 // per-iteration structure (and every arithmetic step) is the one of reg_iter_kernel; the points of a
 // lane stay in registers for the whole loop.
-// Exchange of the workgroups' partial sums inside the resident loop: every workgroup ADDS its 32 values into one of
-// REG_GROUPS accumulators (agent-scope atomic add, no return), readers fetch REG_GROUPS x 32 values instead of
-// 256 x 32 (tools/barrier_bench.hip: 3.1 vs 3.7 us per barrier + exchange).  The accumulators are never reset:
-// int64 arithmetic wraps, so "sum now - sum two iterations ago" (same parity buffer) is the exact total.
-constexpr int REG_GROUPS = 32;
-static_assert(REG_THREADS % REG_SLOTS == 0 && REG_GROUPS % (REG_THREADS / REG_SLOTS) == 0 && REG_BLOCKS % REG_GROUPS == 0, "group exchange");
+// Exchange of the workgroups' partial sums inside the resident loop, WITHOUT a separate barrier.  Every workgroup ADDS
+// its 32 values into one of REG_GROUPS accumulators (agent-scope atomic add, no return); a 64-bit value travels as two
+// words -- its low and its high 32 bits -- whose top byte counts the additions: word += (1 << 56) | half.  The
+// accumulators are never reset: a reader remembers the word it completed two iterations ago (same parity buffer), so
+// (now - then) >> 56 is the number of workgroups that have added since, and the low 56 bits are the exact sum of their
+// halves (32 workgroups x 2^32 never reaches bit 56; the differences are taken modulo 2^64, so wrapping is harmless).
+// A reader therefore polls the DATA until every word's count is complete: no wait for the adds' acknowledgement, no
+// arrival counter, no second read.  tools/barrier_bench.hip (256 workgroups, no work in between): counter + group sums
+// 3.1 us per exchange, counted words polled by one wave 2.3 us -- and polling by all waves, more groups or 128-bit
+// loads are all slower: the polling reads queue in front of the adds in the same memory channels.
+// In the loop itself the polling matters even more than in the microbenchmark: a workgroup that starts to poll right
+// after its own adds keeps 256 x 4 KB of coherent reads per round in flight while the adds of the others are still on
+// their way, and the exchange takes 3.2 us; sleeping ~0.9 us (the time the adds need anyway) before the FIRST poll makes
+// it 1.4 us, because that poll then usually succeeds (measured with -DWS_REG_TIMING, sleeps of 12 / 20 / 26 / 34 / 40 / 50
+// x 64 clocks: 2.09 / 1.48 / 1.47 / 1.52 / 1.62 / 1.88 us).  Before: counter barrier + group sums 2.95 us.
+// Safe against overtaking: a workgroup can only complete the poll of iteration i + 1 after every workgroup has added
+// for i + 1, i.e. after every workgroup has finished reading iteration i, so nobody adds into a parity buffer (i + 2)
+// that is still being read.
+constexpr int REG_GROUPS = 8;
+constexpr int REG_WORDS = 2 * REG_SLOTS; // low halves, then high halves
+constexpr uint64_t REG_COUNT_ONE = 1ull << 56;
+constexpr uint64_t REG_SUM_MASK = REG_COUNT_ONE - 1;
+static_assert(REG_WORDS == 64 && REG_BLOCKS % REG_GROUPS == 0 && REG_BLOCKS / REG_GROUPS < 256, "counted exchange");
+constexpr int REG_FIRST_POLL_SLEEP = 28; // x 64 clocks before the first poll
+constexpr int REG_POLL_SLEEP = 2;        // between polls
+constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
 
-// first wave, after wave_reduce32: workgroup total of every slot straight into the group accumulator
-__device__ __forceinline__ void group_publish(int64_t *accum /* [REG_GROUPS][REG_SLOTS] of this parity */, int64_t (*wave_part)[REG_SLOTS])
+// first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
+__device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, int64_t (*wave_part)[REG_SLOTS])
 {
-  if (threadIdx.x < REG_SLOTS)
-  {
-    int64_t s = 0;
-#pragma unroll
-    for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, wave_part[w][threadIdx.x]);
-    __hip_atomic_fetch_add(&accum[(size_t)(blockIdx.x % REG_GROUPS) * REG_SLOTS + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// all lanes: totals of the iteration -> red[0..31] (valid after the trailing barrier); prev: this parity's last reading
-__device__ __forceinline__ void group_collect(int64_t *accum, int64_t (*wave_part)[REG_SLOTS], int64_t *prev, int64_t *red)
-{
-  constexpr int WAVES = REG_THREADS / 64;
-  constexpr int PER_PASS = REG_THREADS / REG_SLOTS; // groups read at once
-  const int slot = threadIdx.x % REG_SLOTS;
+  const int lane = threadIdx.x & 63, slot = lane & (REG_SLOTS - 1);
   int64_t s = 0;
 #pragma unroll
-  for (int g = 0; g < REG_GROUPS; g += PER_PASS)
-    s = wadd64(s, __hip_atomic_load(&accum[(size_t)(g + threadIdx.x / REG_SLOTS) * REG_SLOTS + slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  s = wadd64(s, shfl_xor_i64(s, 32)); // lanes l and l + 32 of a wave hold the same slot
-  if ((threadIdx.x & 63) < REG_SLOTS) wave_part[threadIdx.x >> 6][slot] = s;
-  __syncthreads();
-  if (threadIdx.x < REG_SLOTS)
+  for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, wave_part[w][slot]);
+  const uint32_t half = lane < REG_SLOTS ? (uint32_t)((uint64_t)s & 0xffffffffull) : (uint32_t)((uint64_t)s >> 32);
+  const int group = blockIdx.x / (REG_BLOCKS / REG_GROUPS);
+  __hip_atomic_fetch_add(&accum[(size_t)group * REG_WORDS + lane], REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// first wave: poll the accumulators of one parity until all workgroups have added, then red[0..31] = the totals of the
+// iteration (read by the same wave afterwards).  then_cur / then_other: this lane's words as they stood when this / the
+// other parity was last complete (rotated here).  false: gave up (another kernel is holding CUs this grid needs, or
+// another workgroup gave up) -- every workgroup then leaves the loop.
+__device__ __forceinline__ bool counted_collect(uint64_t *accum, uint32_t *abort_flag, uint64_t (&then_cur)[REG_GROUPS], uint64_t (&then_other)[REG_GROUPS],
+                                                int64_t *red)
+{
+  const int lane = threadIdx.x & 63;
+  uint64_t w[REG_GROUPS];
+  uint32_t spins = 0;
+  long long t0 = 0;
+  __builtin_amdgcn_s_sleep(REG_FIRST_POLL_SLEEP); // see above: a poll that fails is worse than a poll that starts late
+  for (;;)
   {
-    int64_t now = 0;
+    bool ok = true;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) now = wadd64(now, wave_part[w][threadIdx.x]);
-    red[threadIdx.x] = (int64_t)((uint64_t)now - (uint64_t)prev[threadIdx.x]);
-    prev[threadIdx.x] = now;
+    for (int g = 0; g < REG_GROUPS; ++g)
+    {
+      w[g] = __hip_atomic_load(&accum[(size_t)g * REG_WORDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = ok && ((w[g] - then_cur[g]) >> 56) == (uint64_t)(REG_BLOCKS / REG_GROUPS);
+    }
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(REG_POLL_SLEEP);
+    if ((++spins & 1023u) == 0)
+    {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      const bool give_up = now - t0 > REG_BARRIER_TIMEOUT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (__any(give_up))
+      {
+        if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
   }
-  __syncthreads();
+  uint64_t s = 0;
+#pragma unroll
+  for (int g = 0; g < REG_GROUPS; ++g)
+  {
+    s += (w[g] - then_cur[g]) & REG_SUM_MASK;
+    const uint64_t t = then_other[g]; // the other parity is read next
+    then_other[g] = w[g];
+    then_cur[g] = t;
+  }
+  const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)s, 32);
+  if (lane < REG_SLOTS) red[lane] = (int64_t)(s + (high << 32));
+  return true;
 }
 
 struct LoopArgs
@@ -701,61 +746,10 @@ struct LoopArgs
   GnCore init;       // the state the loop starts from (by value: no staging copy, no host synchronisation before the launch)
   GnState *state;    // out: state[0] (device copy for ws_reg_poll)
   GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
-  int64_t *partials; // [2][REG_GROUPS][REG_SLOTS] group accumulators, zeroed before the launch
-  uint32_t *bar;     // REG_BAR_COUNTERS monotonic arrival counters + abort flag; zeroed before the launch
+  uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch
+  uint32_t *abort_flag; // zeroed before the launch
   int32_t *host_flag;
 };
-
-// Grid barrier, measured with tools/barrier_bench.hip on MI355X (256 workgroups, 8 XCDs):
-//   * agent-scope release/acquire FENCES walk the XCD's L2 (buffer_wbl2 / buffer_inv): 16 us per barrier;
-//   * without them a barrier is 3.7 us, of which 2.6 us is 256 atomics queueing on one address.
-// So the data the workgroups exchange (group_publish / group_collect above) moves with agent-scope atomic adds and
-// loads (`sc1`: performed at the coherent level, 8 bytes each), the arrival is ordered after them by waiting for
-// their completion (s_waitcnt vmcnt(0): gfx9 counts stores and atomics in vmcnt), and arrivals are spread over 16
-// counters in different memory channels: 3.1 us per barrier INCLUDING the exchange.  Nothing else is communicated
-// inside the launch (the map is read-only here).
-constexpr int REG_BAR_COUNTERS = 16;
-constexpr int REG_BAR_STRIDE = 64; // uint32 words between counters (256 B)
-constexpr int REG_BAR_ABORT = REG_BAR_COUNTERS * REG_BAR_STRIDE;
-constexpr size_t REG_BAR_BYTES = (REG_BAR_ABORT + REG_BAR_STRIDE) * sizeof(uint32_t);
-static_assert(REG_BLOCKS % REG_BAR_COUNTERS == 0 && REG_BAR_COUNTERS <= 64, "arrival counters");
-constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
-
-__device__ __forceinline__ void grid_arrive(uint32_t *bar)
-{
-  // executed by wave 0, which also issued the partial stores
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // compiler ordering
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through stores have been acknowledged
-  if (threadIdx.x == 0)
-    __hip_atomic_fetch_add(&bar[(blockIdx.x % REG_BAR_COUNTERS) * REG_BAR_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// wave 0: wait until every counter has reached `target` (= iteration x workgroups per counter).
-// false: gave up (another kernel is holding CUs this grid needs) -- every workgroup then leaves the loop.
-__device__ __forceinline__ bool grid_wait(uint32_t *bar, uint32_t target)
-{
-  const int lane = threadIdx.x;
-  uint32_t spins = 0;
-  long long t0 = 0;
-  for (;;)
-  {
-    const bool ok = lane >= REG_BAR_COUNTERS ||
-                    __hip_atomic_load(&bar[(lane % REG_BAR_COUNTERS) * REG_BAR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
-    if (__all(ok)) return true;
-    if ((++spins & 1023u) == 0)
-    {
-      const long long now = wall_clock64();
-      if (t0 == 0) t0 = now;
-      const bool give_up = now - t0 > REG_BARRIER_TIMEOUT_TICKS ||
-                           __hip_atomic_load(&bar[REG_BAR_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      if (__any(give_up))
-      {
-        if (lane == 0) __hip_atomic_store(&bar[REG_BAR_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-      }
-    }
-  }
-}
 
 __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
@@ -763,13 +757,13 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   __shared__ int64_t red[REG_SLOTS];
   __shared__ float T_sh[16];
   __shared__ int stop_sh;
-  __shared__ int abort_sh;
-  __shared__ int64_t prev_sh[2][REG_SLOTS];
-  if (threadIdx.x < 2 * REG_SLOTS) prev_sh[threadIdx.x / REG_SLOTS][threadIdx.x % REG_SLOTS] = 0;
 
   const Prefetched pref = prefetch_points(a.pts);
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
+  uint64_t then_cur[REG_GROUPS], then_other[REG_GROUPS]; // first wave: the accumulator words of both parities when last complete
+#pragma unroll
+  for (int g = 0; g < REG_GROUPS; ++g) then_cur[g] = then_other[g] = 0;
   VoxelCache cache[2];
   cache[0].filled = cache[1].filled = false;
 #ifdef WS_REG_TIMING
@@ -781,31 +775,24 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   uint32_t k = 0;
   for (;; ++k)
   {
-    bool aborted = false;
     WS_LSTAMP(0);
     WS_LSTAMP(1);
-    if (k > 0)
-    {
-      if (threadIdx.x < 64)
-      {
-        const bool ok = grid_wait(a.bar, k * (uint32_t)(REG_BLOCKS / REG_BAR_COUNTERS));
-        if (threadIdx.x == 0) abort_sh = ok ? 0 : 1;
-      }
-      __syncthreads();
-      WS_LSTAMP(1);
-      aborted = abort_sh != 0;
-      if (!aborted) group_collect(a.partials + (size_t)((k + 1) & 1) * REG_SLOTS * REG_GROUPS, wave_part, prev_sh[(k + 1) & 1], red);
-    }
     WS_LSTAMP(2);
     if (threadIdx.x < 64)
     {
-      if (aborted)
+      if (k > 0)
       {
-        st.finished = 1;
-        st.error = 1; // reported by the host
+        // totals of iteration k - 1 (parity (k + 1) & 1) straight from the counted accumulators: this IS the grid barrier
+        const bool ok = counted_collect(a.accum + (size_t)((k + 1) & 1) * REG_GROUPS * REG_WORDS, a.abort_flag, then_cur, then_other, red);
+        WS_LSTAMP(2);
+        if (!ok)
+        {
+          st.finished = 1;
+          st.error = 1; // reported by the host
+        }
+        else
+          gn_update_terms(st, red);
       }
-      else if (k > 0)
-        gn_update_terms(st, red);
       if (threadIdx.x == 0)
       {
 #pragma unroll
@@ -829,8 +816,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     WS_LSTAMP(5);
     if (threadIdx.x < 64)
     {
-      group_publish(a.partials + (size_t)(k & 1) * REG_SLOTS * REG_GROUPS, wave_part);
-      grid_arrive(a.bar);
+      counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wave_part);
     }
 #ifdef WS_REG_TIMING
     WS_LSTAMP(6);
@@ -1052,8 +1038,8 @@ int reg_loop_supported(int device)
   return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
 }
 
-constexpr size_t REG_ACCUM_OFFSET = (REG_BAR_BYTES + 255) & ~(size_t)255; // group accumulators behind the counters: one memset
-constexpr size_t REG_ACCUM_BYTES = sizeof(int64_t) * 2 * REG_GROUPS * REG_SLOTS;
+constexpr size_t REG_ACCUM_OFFSET = 256; // counted accumulators behind the abort flag: one memset
+constexpr size_t REG_ACCUM_BYTES = sizeof(uint64_t) * 2 * REG_GROUPS * REG_WORDS;
 
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const GnCore &init)
 {
@@ -1063,8 +1049,8 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   a.init = init;
   a.state = r->state;
   a.result_host = r->result_host_dev;
-  a.partials = reinterpret_cast<int64_t *>(reinterpret_cast<char *>(r->grid_bar) + REG_ACCUM_OFFSET);
-  a.bar = r->grid_bar;
+  a.accum = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(r->grid_bar) + REG_ACCUM_OFFSET);
+  a.abort_flag = r->grid_bar;
   a.host_flag = r->host_flag_dev;
   WS_HIP(hipMemsetAsync(r->grid_bar, 0, REG_ACCUM_OFFSET + REG_ACCUM_BYTES, ctx->stream));
   prof_begin(ctx, WS_K_REG);
