@@ -162,7 +162,16 @@ __device__ __forceinline__ void expand_sums(const int64_t *terms, int64_t *sums)
 // to a serial solve.  Lane 8*r + c holds element (r, c) of the augmented matrix [A | b] (c == 6 is b): the 5
 // divisions and the rank-1 update of an elimination step are one instruction each instead of 5 / 35, and no
 // element ever needs a dynamic register index (a serial version spills the matrix to scratch for the row swap:
-// 2.9 us per solve on one lane; this one ~1 us).  All 64 lanes of the wave must be active.
+// 2.9 us per solve on one lane).  All 64 lanes of the wave must be active.
+//
+// The solve is one wave's chain of ~500 instructions in the middle of every Gauss-Newton iteration.  Measured with
+// tools/solve_bench.hip (cycles per solve on one wave): what costs is every hop through the scalar unit.  The pivot
+// candidates are uniform, so the compiler compares them into an SGPR mask, selects with s_cselect and moves the winner
+// back with v_mov -- 70 cycles per candidate, 1050 of 3360 per solve.  Copied into VGPRs behind an opaque asm the
+// same search is v_cmp + v_cndmask, ~20 cycles per candidate: 2660 cycles per solve.  (Tried and slower: rows that
+// stay in place + DPP instead of two of the three gathers (4130), the reciprocal half of each division hoisted off the
+// dependency chain (2860-3150), a tournament instead of the chain (3690): the wave is bound by instruction issue, not
+// by the length of the chain.)
 __device__ __forceinline__ double lane_read(double v, int src_lane /* uniform */)
 {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -175,30 +184,33 @@ __device__ __forceinline__ double lane_gather(double v, int src_lane /* per lane
   const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// the same value in a vector register the compiler knows nothing about (keeps what follows out of the scalar unit)
+__device__ __forceinline__ double in_vgpr(double v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // a: this lane's element of [A | b].  Returns 0 and x (identical in every lane), or -1 for a singular matrix.
 __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
 {
   const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+  int singular = 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k)
   {
     // pivot: first row of maximal |A[i][k]|, i >= k
     int piv = k;
-    double pv = lane_read(a, 8 * k + k);
-    double best = fabs(pv);
+    double pv = in_vgpr(lane_read(a, 8 * k + k));
 #pragma unroll
     for (int i = k + 1; i < 6; ++i)
     {
-      const double v = lane_read(a, 8 * i + k);
-      if (fabs(v) > best)
-      {
-        best = fabs(v);
-        pv = v;
-        piv = i;
-      }
+      const double v = in_vgpr(lane_read(a, 8 * i + k));
+      const bool larger = fabs(v) > fabs(pv);
+      pv = larger ? v : pv;
+      piv = larger ? i : piv;
     }
-    if (best == 0.0) return -1;
+    singular |= pv == 0.0 ? 1 : 0; // the exit is taken once, below (x is not used then)
     if (k == 5) break;
     // rows k and piv change places; fetch the swapped element, the pivot row and the k-th column in one go
     const int rr = r == k ? piv : (r == piv ? k : r);
@@ -208,6 +220,7 @@ __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
     const double f = colk / pv;
     a = (r > k && c >= k) ? an - f * rowk : an;
   }
+  if (__builtin_amdgcn_readfirstlane(singular) != 0) return -1;
   double U[6][6], b[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
