@@ -421,25 +421,28 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
   g.cur = g.xn = g.xl = g.yn = g.yl = g.zn = g.zl = 0;
   if (CACHED)
   {
-    if (g.ok)
+    VoxelCache &c = *cache;
+#ifdef WS_EXP_NOMISS
+    const bool refill = g.ok && !c.filled;
+#else
+    const bool refill = g.ok && !(c.filled && c.bx == bx && c.by == by && c.bz == bz);
+#endif
+    if (refill) // one exec-mask region; everything else is selects
     {
-      VoxelCache &c = *cache;
-      if (!(c.filled && c.bx == bx && c.by == by && c.bz == bz))
-      {
-        c.cur = a.map_data[get_index(a.map, bx, by, bz)];
-        c.xn = a.map_data[get_index(a.map, bx + 1, by, bz)];
-        c.xl = a.map_data[get_index(a.map, bx - 1, by, bz)];
-        c.yn = a.map_data[get_index(a.map, bx, by + 1, bz)];
-        c.yl = a.map_data[get_index(a.map, bx, by - 1, bz)];
-        c.zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
-        c.zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
-        c.bx = bx;
-        c.by = by;
-        c.bz = bz;
-        c.filled = true;
-      }
-      g.cur = c.cur; g.xn = c.xn; g.xl = c.xl; g.yn = c.yn; g.yl = c.yl; g.zn = c.zn; g.zl = c.zl;
+      c.cur = a.map_data[get_index(a.map, bx, by, bz)];
+      c.xn = a.map_data[get_index(a.map, bx + 1, by, bz)];
+      c.xl = a.map_data[get_index(a.map, bx - 1, by, bz)];
+      c.yn = a.map_data[get_index(a.map, bx, by + 1, bz)];
+      c.yl = a.map_data[get_index(a.map, bx, by - 1, bz)];
+      c.zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
+      c.zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
+      c.bx = bx;
+      c.by = by;
+      c.bz = bz;
+      c.filled = true;
     }
+    const uint32_t keep = g.ok ? 0xffffffffu : 0u;
+    g.cur = c.cur & keep; g.xn = c.xn & keep; g.xl = c.xl & keep; g.yn = c.yn & keep; g.yl = c.yl & keep; g.zn = c.zn & keep; g.zl = c.zl & keep;
     return g;
   }
   if (g.ok)
@@ -456,18 +459,25 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
   return g;
 }
 
+// Both functions below are written without branches on purpose: nested `if`s over three gradients became nine exec-mask
+// regions with a round trip through the scalar unit each (v_cmp -> SGPR -> s_and_saveexec -> s_cbranch), which cost more
+// than the arithmetic they skipped; masks keep the whole point in the vector unit.
 __device__ __forceinline__ int32_t central_gradient(uint32_t next, uint32_t last)
 {
   // registration.cu:233-246: both neighbours observed and not of strictly opposite sign
   const int32_t nv = entry_value(next), lv = entry_value(last);
-  if (entry_weight(next) != 0 && entry_weight(last) != 0 && !((nv > 0 && lv < 0) || (nv < 0 && lv > 0))) return (nv - lv) / 2;
-  return 0;
+  const int32_t observed = ((next >> 16) != 0u) & ((last >> 16) != 0u);
+  const int32_t opposite = (nv * lv) < 0; // 16-bit values: the product is negative iff the signs are strictly opposite
+  const int32_t keep = -(observed & (opposite ^ 1));
+  return ((nv - lv) / 2) & keep;
 }
 
 __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[REG_SLOTS])
 {
-  if (!g.ok || entry_weight(g.cur) == 0) return;
-  const int32_t gx = central_gradient(g.xn, g.xl), gy = central_gradient(g.yn, g.yl), gz = central_gradient(g.zn, g.zl);
+  // a point outside the map or in an unobserved voxel (registration.cu:217-222) contributes zeros
+  const int32_t used = (g.ok ? 1 : 0) & ((g.cur >> 16) != 0u);
+  const int32_t keep = -used;
+  const int32_t gx = central_gradient(g.xn, g.xl) & keep, gy = central_gradient(g.yn, g.yl) & keep, gz = central_gradient(g.zn, g.zl) & keep;
   // point.cross(gradient) in int (math/vector3.h:269-277); J = (cross, gradient) as long
   int32_t J[6];
   J[0] = wsub(wmul(g.qy, gz), wmul(g.qz, gy));
@@ -476,7 +486,7 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
   J[3] = gx;
   J[4] = gy;
   J[5] = gz;
-  const int32_t v = entry_value(g.cur);
+  const int32_t v = entry_value(g.cur) & keep;
   // 21 unique terms of J J^T (registration.cu:55-97); int32 x int32 + int64 maps onto v_mad_i64_i32
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -485,7 +495,7 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], (int64_t)J[i] * (int64_t)v);
   acc[27] += (v < 0 ? -v : v);
-  acc[28] += 1;
+  acc[28] += used;
 }
 
 constexpr uint32_t REG_STRIDE = REG_BLOCKS * REG_THREADS; // points covered by one pass of the grid
@@ -778,9 +788,16 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #pragma unroll
   for (int g = 0; g < REG_GROUPS; ++g) then_cur[g] = then_other[g] = 0;
   VoxelCache cache[2];
-  cache[0].filled = cache[1].filled = false;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+  {
+    cache[u].bx = cache[u].by = cache[u].bz = 0;
+    cache[u].cur = cache[u].xn = cache[u].xl = cache[u].yn = cache[u].yl = cache[u].zn = cache[u].zl = 0;
+    cache[u].filled = false;
+  }
 #ifdef WS_REG_TIMING
-  long long ts[7], tot[6] = {0, 0, 0, 0, 0, 0};
+  long long ts[7], tot[6] = {0, 0, 0, 0, 0, 0}, miss_ticks = 0, hit_ticks = 0;
+  int miss_its = 0, miss_lanes = 0;
 #define WS_LSTAMP(i) ts[i] = wall_clock64()
 #else
 #define WS_LSTAMP(i)
@@ -823,8 +840,26 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     int64_t acc[REG_SLOTS];
 #pragma unroll
     for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+#ifdef WS_REG_TIMING
+    const int32_t obx = cache[0].bx, oby = cache[0].by, obz = cache[0].bz;
+    const bool ofilled = cache[0].filled;
+#endif
     accumulate_points<true>(a.pts, T, pref, acc, cache);
     WS_LSTAMP(4);
+#ifdef WS_REG_TIMING
+    {
+      const bool changed = ofilled && cache[0].filled && (obx != cache[0].bx || oby != cache[0].by || obz != cache[0].bz);
+      const int n_changed = __syncthreads_count(changed ? 1 : 0);
+      if (n_changed > 0)
+      {
+        miss_its += 1;
+        miss_ticks += ts[4] - ts[3];
+        miss_lanes += n_changed;
+      }
+      else
+        hit_ticks += ts[4] - ts[3];
+    }
+#endif
     wave_reduce32(acc, wave_part);
     WS_LSTAMP(5);
     if (threadIdx.x < 64)
@@ -845,6 +880,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   if ((blockIdx.x % 37) == 0 && threadIdx.x == 0)
     printf("reg_loop wg %d iterations %u, 10ns ticks per phase: wait %lld sum %lld solve %lld accumulate %lld reduce %lld arrive %lld\n", (int)blockIdx.x, k,
            tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+  if ((blockIdx.x % 37) == 0 && threadIdx.x == 0)
+    printf("  wg %d: iterations with a moved point %d (%d lanes), accumulate ticks in those %lld, in the others %lld\n", (int)blockIdx.x, miss_its, miss_lanes,
+           miss_ticks, hit_ticks);
 #endif
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {

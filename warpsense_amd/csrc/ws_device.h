@@ -17,7 +17,7 @@ __device__ __forceinline__ int64_t wsub64(int64_t a, int64_t b) { return (int64_
 __device__ __forceinline__ int32_t iabs32(int32_t a) { return a < 0 ? wsub(0, a) : a; }
 
 // exact floor(x / d) for 0 <= x < 2^31 by multiply-shift: M = ceil(2^k / d), k = 31 + ceil(log2 d)
-// (error e = M*d - 2^k < d <= 2^(k-31), so x*e < 2^k for every x < 2^31)
+// (error e = M*d - 2^k < d <= 2^(k-31), so x*e < 2^k for every x <= 2^31)
 struct FastDiv
 {
   uint64_t M;
@@ -38,12 +38,10 @@ __host__ __device__ inline FastDiv make_fastdiv(int32_t d)
 // C-style truncating division of any int32 by the prepared positive divisor
 __device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, int32_t d)
 {
+  // ax <= 2^31 (|INT_MIN| included: e < d <= 2^(k-31) gives ax * e < 2^k for ax = 2^31 as well) and M < 2^32, so the
+  // product fits 64 bits and the quotient is exact: no special case, no branch
   const uint32_t ax = x < 0 ? (uint32_t)0 - (uint32_t)x : (uint32_t)x;
-  uint32_t q;
-  if (ax == 0x80000000u)
-    q = ax / (uint32_t)d; // |INT_MIN| is outside the multiply-shift range
-  else
-    q = (uint32_t)(((uint64_t)ax * M) >> k); // ax < 2^31, M <= 2^32
+  const uint32_t q = (uint32_t)(((uint64_t)ax * M) >> k);
   return x < 0 ? (int32_t)((uint32_t)0 - q) : (int32_t)q;
 }
 __device__ __forceinline__ int32_t div_trunc(int32_t x, const FastDiv &f) { return div_trunc(x, f.M, f.k, f.d); }
