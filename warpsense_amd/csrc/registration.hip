@@ -249,15 +249,17 @@ __device__ long long g_gn_ticks[5];
 #define WS_GN_STAMP(i)
 #endif
 
+// First half: solve for xi and build the incremental transform `tr` (column-major 4x4).  false: no update this time
+// (loop already over, no correspondences, singular matrix).
 template <typename HF, typename GF>
-__device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int32_t c)
+__device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, float (&tr)[16])
 {
-  if (st.finished || st.iterations >= st.max_iterations) return;
+  if (st.finished || st.iterations >= st.max_iterations) return false;
   st.iterations += 1;
   if (c == 0)
   {
     st.finished = 1; // guard: the reference would divide by zero (tsdf_registration.cpp:80)
-    return;
+    return false;
   }
   WS_GN_STAMP(0);
   const double w = (double)(st.alpha * (float)c);
@@ -270,7 +272,7 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
   if (solve6_wave(a, xi) != 0)
   {
     st.finished = 1;
-    return;
+    return false;
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) xi[r] = -xi[r];
@@ -300,7 +302,6 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
       for (int k = 0; k < 3; ++k) ll = __fadd_rn(ll, __fmul_rn(__fmul_rn(omc, L[i][k]), L[k][j]));
       R[i][j] = __fadd_rn(__fadd_rn((i == j ? 1.f : 0.f), __fmul_rn(s, L[i][j])), ll);
     }
-  float tr[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tr[i] = 0.f;
   tr[15] = 1.f;
@@ -315,6 +316,32 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
   }
   WS_GN_STAMP(3);
   st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
+#ifdef WS_REG_TIMING_GN
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    g_gn_ticks[0] += gn_t1 - gn_t0;
+    g_gn_ticks[1] += gn_t2 - gn_t1;
+    g_gn_ticks[2] += gn_t3 - gn_t2;
+    g_gn_ticks[4] += 1;
+  }
+#endif
+  return true;
+}
+
+// Second half: convergence test on the mean error (tsdf_registration.cpp:80-92)
+__device__ __forceinline__ void gn_convergence(GnCore &st, int32_t e, int32_t c)
+{
+  const float err = __fdiv_rn((float)e, (float)c);
+  if (fabsf(err - st.prev[2]) < st.epsilon && fabsf(err - st.prev[0]) < st.epsilon) st.finished = 1;
+  st.prev[0] = st.prev[1];
+  st.prev[1] = st.prev[2];
+  st.prev[2] = st.prev[3];
+  st.prev[3] = err;
+}
+
+// T = tr * T with every lane computing all 16 elements (uniform state)
+__device__ __forceinline__ void pose_product(float (&T)[16], const float (&tr)[16])
+{
   float out[16];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -323,28 +350,40 @@ __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int
     {
       float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(tr[k * 4 + i], st.T[j * 4 + k]));
+      for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(tr[k * 4 + i], T[j * 4 + k]));
       out[j * 4 + i] = acc;
     }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) st.T[i] = out[i];
+  for (int i = 0; i < 16; ++i) T[i] = out[i];
+}
 
-  const float err = __fdiv_rn((float)e, (float)c);
-  if (fabsf(err - st.prev[2]) < st.epsilon && fabsf(err - st.prev[0]) < st.epsilon) st.finished = 1;
-  st.prev[0] = st.prev[1];
-  st.prev[1] = st.prev[2];
-  st.prev[2] = st.prev[3];
-  st.prev[3] = err;
-#ifdef WS_REG_TIMING_GN
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+// The same product with the pose kept in LDS (reg_loop_kernel): lane 4*j + i of the first wave computes element (i, j)
+// -- one 128-bit LDS read for its column of T, twelve selects for its row of tr, 4 multiply-adds, one LDS write --
+// instead of 112 multiplies and adds in every lane.  Same operations in the same order per element.
+__device__ __forceinline__ void pose_product_lds(float *T_sh, const float (&tr)[16])
+{
+  const int lane = threadIdx.x & 63, i = lane & 3, j = (lane >> 2) & 3;
+  const float4 col = *reinterpret_cast<const float4 *>(T_sh + 4 * j); // T[j*4 + k], k = 0..3 (old pose: read before any lane writes)
+  const float tk[4] = {col.x, col.y, col.z, col.w};
+  const bool i1 = (i & 1) != 0, i2 = (i & 2) != 0;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
   {
-    g_gn_ticks[0] += gn_t1 - gn_t0;
-    g_gn_ticks[1] += gn_t2 - gn_t1;
-    g_gn_ticks[2] += gn_t3 - gn_t2;
-    g_gn_ticks[3] += wall_clock64() - gn_t3;
-    g_gn_ticks[4] += 1;
+    const float lo = i1 ? tr[k * 4 + 1] : tr[k * 4 + 0], hi = i1 ? tr[k * 4 + 3] : tr[k * 4 + 2];
+    acc = __fadd_rn(acc, __fmul_rn(i2 ? hi : lo, tk[k]));
   }
-#endif
+  if (lane < 16) T_sh[lane] = acc;
+}
+
+// One Gauss-Newton update with the whole state in registers, identical in every lane of the wave
+template <typename HF, typename GF>
+__device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int32_t c)
+{
+  float tr[16];
+  if (!gn_increment(st, H, G, c, tr)) return;
+  pose_product(st.T, tr);
+  gn_convergence(st, e, c);
 }
 
 // the update fed from the 29 reduced terms in LDS (e and c are `int` in the reference, registration.cu:16-21)
@@ -353,6 +392,18 @@ __device__ __forceinline__ void gn_update_terms(GnCore &st, const int64_t *terms
   gn_update(
       st, [terms](int r, int c) { return terms[r <= c ? tri_index(r, c) : tri_index(c, r)]; }, [terms](int r) { return terms[21 + r]; },
       (int32_t)terms[27], (int32_t)terms[28]);
+}
+
+// the same for reg_loop_kernel, whose pose lives in LDS (T_sh); st.T is not touched
+__device__ __forceinline__ void gn_update_terms_lds(GnCore &st, const int64_t *terms, float *T_sh)
+{
+  float tr[16];
+  const int32_t e = (int32_t)terms[27], c = (int32_t)terms[28];
+  if (!gn_increment(
+          st, [terms](int r, int cc) { return terms[r <= cc ? tri_index(r, cc) : tri_index(cc, r)]; }, [terms](int r) { return terms[21 + r]; }, c, tr))
+    return;
+  pose_product_lds(T_sh, tr);
+  gn_convergence(st, e, c);
 }
 
 struct PointArgs
@@ -778,7 +829,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
   __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
   __shared__ int64_t red[REG_SLOTS];
-  __shared__ float T_sh[16];
+  __shared__ alignas(16) float T_sh[16];
   __shared__ int stop_sh;
 
   const Prefetched pref = prefetch_points(a.pts);
@@ -802,6 +853,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #else
 #define WS_LSTAMP(i)
 #endif
+  if (threadIdx.x < 16) T_sh[threadIdx.x] = a.init.T[threadIdx.x];
   uint32_t k = 0;
   for (;; ++k)
   {
@@ -821,14 +873,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
           st.error = 1; // reported by the host
         }
         else
-          gn_update_terms(st, red);
+          gn_update_terms_lds(st, red, T_sh); // the pose itself stays in T_sh
       }
-      if (threadIdx.x == 0)
-      {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
-        stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
-      }
+      if (threadIdx.x == 0) stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
     }
     __syncthreads();
     WS_LSTAMP(3);
@@ -886,6 +933,8 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #endif
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.T[i] = T_sh[i];
     a.state[0].core = st;
     a.result_host->core = st;
     if (k > 0 && !st.error)
