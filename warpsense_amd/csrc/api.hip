@@ -213,7 +213,7 @@ static int map_free(ws_map *m)
       break;
     }
   map_free_records(m);
-  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->az_cur, m->ray_order, m->rays, m->scan_dev, m->counters, m->tile_nruns,
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->az_cur, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nruns,
                   m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -332,6 +332,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->az_cur, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->az_cur, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->fan_steps, 256 * sizeof(int32_t)));
+  ws::fill_fan_steps(m->fan_steps_host, m->res);
+  TRY(hipMemcpyAsync(m->fan_steps, m->fan_steps_host, 256 * sizeof(int32_t), hipMemcpyHostToDevice, s));
   TRY(hipMemsetAsync(m->az_hist, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->az_off, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));

@@ -53,6 +53,7 @@ struct ScatterArgs
   uint32_t *az_off;    // [AZ_BINS]: number of rays that contribute (written by the direction sort)
   uint32_t *az_cur;    // [AZ_BINS + 1] placement cursors of the direction sort (zero at the start of a scan)
   uint32_t *ray_order; // ray indices sorted by direction bin
+  const int32_t *fan_steps; // [256], see tail_bound
   uint8_t *vstate;     // one byte per voxel: VOX_*
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
   uint32_t *tile_nruns;
@@ -141,21 +142,18 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter
 
 // Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
 // = (k1 - k0) + sum_j #{steps with delta_z >= ceil(j*res/2)}.  Exact when every sample is a candidate; additive over ranges.
-__device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1, int64_t len_end, int32_t res)
+// fan_steps[j] = first step k with delta_z(len_k) >= ceil(j*res/2), len_k = 1 + k*(res/2): a function of res alone, tabulated
+// on the host when the map is created (fill_fan_steps) -- two 64-bit divisions per j and ray otherwise.
+__device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1, int64_t len_end, const int32_t *fan_steps)
 {
   if (k1 <= k0) return 0;
   unsigned long long ub = (unsigned long long)(k1 - k0);
   if ((int64_t)DZ_PER_DISTANCE * len_end >= (1ll << 31)) return ub * 256; // DZ * len wraps in the reference's int: any fan width the key admits
-  const int64_t half = res / 2;
-  const int64_t len_last = 1 + (k1 - 1) * half;
-  for (int64_t j = 1; j < 256; ++j)
+  for (int j = 1; j < 256; ++j)
   {
-    const int64_t cj = (j * res + 1) / 2;
-    const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;
-    if (Lj > len_last) break;
-    const int64_t kj = (Lj - 1 + half - 1) / half;
-    const int64_t first = kj > k0 ? kj : k0;
-    if (first < k1) ub += (unsigned long long)(k1 - first);
+    const int64_t kj = fan_steps[j];
+    if (kj >= k1) break; // non-decreasing in j
+    ub += (unsigned long long)(k1 - (kj > k0 ? kj : k0));
   }
   return ub;
 }
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
     {
       // update_tsdf.cu:59-63, in int64 like the reference's `long`
       const int64_t MR = MATRIX_RESOLUTION;
-      const int64_t ndx = wmul64(dx, MR) / distance, ndy = wmul64(dy, MR) / distance, ndz = wmul64(dz, MR) / distance;
+      const int64_t ndx = div_trunc_i64(wmul64(dx, MR), distance), ndy = div_trunc_i64(wmul64(dy, MR), distance), ndz = div_trunc_i64(wmul64(dz, MR), distance);
       const int64_t ux = a.up[0], uy = a.up[1], uz = a.up[2];
       const int64_t c1x = wsub64(wmul64(ndy, uz), wmul64(ndz, uy)) / MR;
       const int64_t c1y = wsub64(wmul64(ndz, ux), wmul64(ndx, uz)) / MR;
@@ -211,11 +209,11 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
       const int64_t inorm = l2norm_l(ivx, ivy, ivz);
       if (inorm != 0) // guard (src/cpu/update_tsdf.cpp:602)
       {
-        ivx = wmul64(ivx, MR) / inorm;
-        ivy = wmul64(ivy, MR) / inorm;
-        ivz = wmul64(ivz, MR) / inorm;
+        ivx = div_trunc_i64(wmul64(ivx, MR), inorm);
+        ivy = div_trunc_i64(wmul64(ivy, MR), inorm);
+        ivz = div_trunc_i64(wmul64(ivz, MR), inorm);
         const int64_t len_end = (int64_t)distance + tau;
-        const int64_t steps = (len_end - 1) / half + 1;
+        const int64_t steps = div_trunc_i64(len_end - 1, half) + 1;
         const int64_t max_delta_z = (int64_t)DZ_PER_DISTANCE * len_end / MATRIX_RESOLUTION;
         const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
         if (steps > 65536 || (max_delta_z * 2) / res + 1 > 256 || !small_iv)
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
           r.distance = distance;
           r.ivx = (int32_t)ivx; r.ivy = (int32_t)ivy; r.ivz = (int32_t)ivz;
           r.steps = (int32_t)steps;
-          const FastDiv fd = make_fastdiv(distance);
+          const FastDiv fd = make_fastdiv_dev(distance);
           r.div_m = fd.M;
           r.div_k = fd.k;
           // conditions of march_steps_fast (ws_march.h): no int32 wrap in d*len, pos + d, voxel centres,
@@ -246,9 +244,9 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
             // the whole ray, its fans included, inside the window with room to spare: the per-candidate in_bounds tests
             // (update_tsdf.cu:73,113) cannot fail.  Both ends inside a box shrunk by the fan reach (convexity does the rest).
             const int64_t margin = 4 + (max_delta_z + res) / res;
-            const int64_t endx = (int64_t)posx + (int64_t)dx * len_end / distance, endy = (int64_t)posy + (int64_t)dy * len_end / distance,
-                          endz = (int64_t)posz + (int64_t)dz * len_end / distance;
-            const int64_t ev[3] = {endx / res, endy / res, endz / res};
+            const int64_t endx = (int64_t)posx + div_trunc_i64((int64_t)dx * len_end, distance), endy = (int64_t)posy + div_trunc_i64((int64_t)dy * len_end, distance),
+                          endz = (int64_t)posz + div_trunc_i64((int64_t)dz * len_end, distance);
+            const int64_t ev[3] = {div_trunc_i64(endx, res), div_trunc_i64(endy, res), div_trunc_i64(endz, res)};
             bool inside = fast;
             for (int k = 0; k < 3; ++k)
             {
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
             if (kfirst > (int32_t)steps) kfirst = (int32_t)steps;
           }
           r.kfirst = kfirst;
-          const unsigned long long ub = tail_bound(kfirst, steps, len_end, res);
+          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps);
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
@@ -445,7 +443,7 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
     {
       const int32_t chp = (r.steps - r.kfirst + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
       const int32_t ka = min(r.kfirst + part0 * chp, r.steps), kb = min(r.kfirst + (part0 + 4) * chp, r.steps);
-      ub = TAIL_SPLIT == 1 ? (unsigned long long)r.ub : tail_bound(ka, kb, (int64_t)r.distance + a.tau, a.res);
+      ub = TAIL_SPLIT == 1 ? (unsigned long long)r.ub : tail_bound(ka, kb, (int64_t)r.distance + a.tau, a.fan_steps);
     }
     for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
     if (lane == 0)
@@ -2059,6 +2057,20 @@ int launch_scatter_prep(ws_map *m)
   return WS_OK;
 }
 
+// fan_steps[j] of tail_bound for one resolution (host side, once per map).  j = 0 is unused.
+void fill_fan_steps(int32_t *fan_steps, int32_t res)
+{
+  const int64_t half = res / 2 > 0 ? res / 2 : 1;
+  fan_steps[0] = 0;
+  for (int64_t j = 1; j < 256; ++j)
+  {
+    const int64_t cj = (j * res + 1) / 2;                                                   // delta_z that gives 2*delta_z/res >= j
+    const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;   // first length with that delta_z
+    const int64_t kj = (Lj - 1 + half - 1) / half;                                          // first step with len_k >= Lj
+    fan_steps[j] = (int32_t)(kj > (1ll << 30) ? (1ll << 30) : kj);                          // beyond the 65 536 steps the order key admits anyway
+  }
+}
+
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
   ws_context *ctx = m->ctx;
@@ -2100,6 +2112,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.az_off = m->az_off;
   sa.az_cur = m->az_cur;
   sa.ray_order = m->ray_order;
+  sa.fan_steps = m->fan_steps;
   sa.vstate = m->vstate;
   sa.tile_dirty = m->tile_dirty;
   sa.tile_nruns = m->tile_nruns;

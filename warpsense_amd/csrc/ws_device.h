@@ -35,6 +35,38 @@ __host__ __device__ inline FastDiv make_fastdiv(int32_t d)
   f.M = p / (uint64_t)d + ((p % (uint64_t)d) ? 1 : 0);
   return f;
 }
+// C-style truncating 64-bit division through one double division when both operands are below 2^53 (always, for the ray
+// set-up's lengths and normalised directions; the plain division otherwise).  Exact: the operands convert exactly, the
+// correctly rounded quotient is off by less than |q| 2^-53 < 1 / |den|, i.e. by less than the distance of a non-integer
+// num / den to the next integer, and an integer quotient is representable -- so truncating the double gives trunc(num / den).
+// ~40 instructions instead of the ~120 of the expanded 64-bit division.
+__device__ __forceinline__ int64_t div_trunc_i64(int64_t num, int64_t den)
+{
+  const uint64_t an = num < 0 ? (uint64_t)0 - (uint64_t)num : (uint64_t)num;
+  const uint64_t ad = den < 0 ? (uint64_t)0 - (uint64_t)den : (uint64_t)den;
+  if (an < (1ull << 53) && ad < (1ull << 53)) return (int64_t)((double)num / (double)den);
+  return num / den;
+}
+
+// make_fastdiv on the device without the 64-bit division and the search loop (same M, k)
+__device__ __forceinline__ FastDiv make_fastdiv_dev(int32_t d)
+{
+  FastDiv f;
+  f.d = d;
+  const int l = d > 1 ? 32 - __clz(d - 1) : 0; // smallest l with 2^l >= d
+  f.k = 31 + l;
+  const uint64_t p = 1ull << f.k; // k <= 62, p / d < 2^32
+  uint64_t q = (uint64_t)((double)p / (double)d); // floor(p / d) or one more
+  int64_t r = (int64_t)(p - q * (uint64_t)d);
+  if (r < 0)
+  {
+    q -= 1;
+    r += d;
+  }
+  f.M = q + (r != 0 ? 1 : 0);
+  return f;
+}
+
 // C-style truncating division of any int32 by the prepared positive divisor
 __device__ __forceinline__ int32_t div_trunc(int32_t x, uint64_t M, int32_t k, int32_t d)
 {

@@ -144,6 +144,8 @@ struct ws_map
   uint8_t *vstate = nullptr; // one byte per voxel: keyed / touched by free space / free-space hit on a keyed voxel
   void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
   uint32_t *az_hist = nullptr, *az_off = nullptr, *az_cur = nullptr, *ray_order = nullptr; // rays grouped by direction bin
+  int32_t *fan_steps = nullptr;       // [256] first ray step whose fan has j + 1 targets (depends on res only), see tail_bound
+  int32_t fan_steps_host[256] = {};   // staging of the same (lives as long as the map: async upload)
   bool prepped = false; // the scatter's scratch (histograms, tile counters, free-space hash) is zero / empty
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
@@ -255,6 +257,7 @@ void prof_begin(ws_context *ctx, int cls);
 void prof_end(ws_context *ctx, int cls);
 
 // launchers implemented in the .hip files
+void fill_fan_steps(int32_t *fan_steps, int32_t res);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
