@@ -31,9 +31,11 @@ WEIGHT_RESOLUTION = 64     # include/warpsense/consts.h:9-10
 
 
 def _ptr(a):
-    """void* of a numpy array or of a torch tensor (host or device)."""
+    """void* of a numpy array, a ctypes array or a torch tensor (host or device)."""
     if a is None:
         return None
+    if isinstance(a, C.Array):
+        return a
     if hasattr(a, "data_ptr"):
         return C.c_void_p(a.data_ptr())
     return a.ctypes.data_as(C.c_void_p)
@@ -43,8 +45,18 @@ def _is_device(a) -> bool:
     return hasattr(a, "is_cuda") and bool(a.is_cuda)
 
 
+_I3 = C.c_int32 * 3
+
+
 def _i3(v) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(v, dtype=np.int32).reshape(3))
+
+
+def _i3c(v):
+    """three int32 for the C ABI only; tuples and lists skip numpy (this sits between two scans of a stream)"""
+    if isinstance(v, (tuple, list)) and len(v) == 3:
+        return _I3(int(v[0]), int(v[1]), int(v[2]))
+    return _i3(v)
 
 
 def _colmajor(T) -> np.ndarray:
@@ -492,7 +504,7 @@ class TSDFCuda:
     # -- the three update_tsdf overloads of the reference (update_tsdf.cu:143-191)
     def update_tsdf(self, scan_points, scanner_pos, up, result: DeviceMap | None = None, latest_map: DeviceMap | None = None):
         n = int(scan_points.shape[0])
-        sp, u = _i3(scanner_pos), _i3(up)
+        sp, u = _i3c(scanner_pos), _i3c(up)
         if _is_device(scan_points):
             rc = self._L.ws_tsdf_update_dev(self.handle, _ptr(scan_points), n, _ptr(sp), _ptr(u))
         else:
@@ -512,7 +524,7 @@ class TSDFCuda:
     def scatter(self, scan_points_dev, scanner_pos, up):
         """cu_min_tsdf_krnl alone (parity tests): leaves the resolved scan in new_map."""
         check(self._L.ws_tsdf_scatter_dev(self.handle, _ptr(scan_points_dev), int(scan_points_dev.shape[0]),
-                                          _ptr(_i3(scanner_pos)), _ptr(_i3(up))), "ws_tsdf_scatter_dev")
+                                          _ptr(_i3c(scanner_pos)), _ptr(_i3c(up))), "ws_tsdf_scatter_dev")
 
     def integrate(self):
         check(self._L.ws_tsdf_integrate(self.handle), "ws_tsdf_integrate")
@@ -587,7 +599,7 @@ class RegistrationCuda:
 
     def register_cloud(self, map_dev, pretransform, max_iterations, it_weight_gradient, epsilon, map_resolution):
         T = _colmajor(pretransform)
-        out = np.zeros(16, dtype=np.float32)
+        out = np.empty(16, dtype=np.float32)
         it = C.c_int32(0)
         check(self._L.ws_register_cloud(self.handle, map_dev, _ptr(T), int(max_iterations), C.c_float(it_weight_gradient),
                                         C.c_float(epsilon), int(map_resolution), self.flags, _ptr(out), C.byref(it)),

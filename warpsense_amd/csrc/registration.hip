@@ -822,6 +822,8 @@ struct LoopArgs
   GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
   uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch
   uint32_t *abort_flag; // zeroed before the launch
+  uint32_t *clear_next; // the set of the NEXT launch (abort flag + accumulators): cleared on the way out
+  uint32_t clear_words;
   int32_t *host_flag;
 };
 
@@ -931,6 +933,8 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     printf("  wg %d: iterations with a moved point %d (%d lanes), accumulate ticks in those %lld, in the others %lld\n", (int)blockIdx.x, miss_its, miss_lanes,
            miss_ticks, hit_ticks);
 #endif
+  if (blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < a.clear_words; i += REG_THREADS) a.clear_next[i] = 0u; // nobody touches that set during this launch
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
 #pragma unroll
@@ -948,7 +952,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
         a.result_host->sums[i] = sums[i];
       }
     }
-    if (a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // release: the result above is visible to the host before the flag (ws_register_cloud spins on the flag instead of
+    // sleeping in hipStreamSynchronize)
+    if (a.host_flag) __hip_atomic_store(a.host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1138,8 +1144,11 @@ int reg_loop_supported(int device)
   return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
 }
 
-constexpr size_t REG_ACCUM_OFFSET = 256; // counted accumulators behind the abort flag: one memset
+// Two sets of {abort flag, counted accumulators}, used by alternate launches: a launch finds its set zero because the
+// launch before it cleared it on its way out (block 0, after its own loop) -- no memset kernel in front of every launch.
+constexpr size_t REG_ACCUM_OFFSET = 256; // accumulators behind the abort flag
 constexpr size_t REG_ACCUM_BYTES = sizeof(uint64_t) * 2 * REG_GROUPS * REG_WORDS;
+constexpr size_t REG_SET_BYTES = REG_ACCUM_OFFSET + REG_ACCUM_BYTES;
 
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const GnCore &init)
 {
@@ -1149,10 +1158,19 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   a.init = init;
   a.state = r->state;
   a.result_host = r->result_host_dev;
-  a.accum = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(r->grid_bar) + REG_ACCUM_OFFSET);
-  a.abort_flag = r->grid_bar;
+  if (!r->loop_sets_clear)
+  {
+    WS_HIP(hipMemsetAsync(r->grid_bar, 0, 2 * REG_SET_BYTES, ctx->stream));
+    r->loop_sets_clear = true;
+  }
+  char *mine = reinterpret_cast<char *>(r->grid_bar) + (r->loop_launches & 1u) * REG_SET_BYTES;
+  char *other = reinterpret_cast<char *>(r->grid_bar) + ((r->loop_launches + 1) & 1u) * REG_SET_BYTES;
+  r->loop_launches += 1;
+  a.accum = reinterpret_cast<uint64_t *>(mine + REG_ACCUM_OFFSET);
+  a.abort_flag = reinterpret_cast<uint32_t *>(mine);
+  a.clear_next = reinterpret_cast<uint32_t *>(other);
+  a.clear_words = (uint32_t)(REG_SET_BYTES / sizeof(uint32_t));
   a.host_flag = r->host_flag_dev;
-  WS_HIP(hipMemsetAsync(r->grid_bar, 0, REG_ACCUM_OFFSET + REG_ACCUM_BYTES, ctx->stream));
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_loop_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
@@ -1160,7 +1178,7 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   return WS_OK;
 }
 
-size_t reg_barrier_bytes() { return REG_ACCUM_OFFSET + REG_ACCUM_BYTES; }
+size_t reg_barrier_bytes() { return 2 * REG_SET_BYTES; }
 
 size_t reg_partials_bytes() { return sizeof(int64_t) * 2 * REG_SLOTS * REG_BLOCKS; }
 

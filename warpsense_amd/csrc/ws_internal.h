@@ -213,7 +213,9 @@ struct ws_reg
   int latest = 0;                    // state buffer holding the newest state
   float *T_dev = nullptr;            // transform for ws_reg_iterate
   int64_t *sums_dev = nullptr;       // 44
-  uint32_t *grid_bar = nullptr;      // abort flag + counted group accumulators of reg_loop_kernel
+  uint32_t *grid_bar = nullptr;      // two sets of {abort flag, counted group accumulators} of reg_loop_kernel (alternate launches)
+  uint32_t loop_launches = 0;
+  bool loop_sets_clear = false;
   int loop_mode = 0;                 // WS_REG_LOOP_*
   int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
   int resident_fallbacks = 0;        // registrations redone with one launch per iteration after a barrier timeout
