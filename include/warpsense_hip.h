@@ -200,6 +200,11 @@ int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out
  * x n x 6, status n (0, or -1 for a singular matrix). Host pointers; synchronises. */
 int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status);
 
+/* Test entry: make the NEXT resident registration of `reg` lose one workgroup's contribution to the first exchange, as if
+ * another kernel kept that workgroup off the chip: the exchange times out (0.25 s) and ws_register_cloud repeats the
+ * registration with one launch per iteration. *fallbacks (may be NULL) receives how often that has happened on `reg`. */
+int ws_debug_reg_stall(ws_reg *reg, int32_t stall_next, int32_t *fallbacks);
+
 /* ------------------------------------------------------------------ scan pre-processing ---- */
 /* App::preprocess — src/warpsense/app.cpp:119-148, on the device: sensor points in float metres
  * (x y z first, `stride_floats` floats per point, e.g. 3, or 4 for PointXYZI) are dropped if x, y and z are all

@@ -106,6 +106,32 @@ def test_register_cloud_loop_modes_identical():
             assert np.array_equal(out[0][0], np.eye(4, dtype=np.float32))
 
 
+def test_resident_loop_times_out_and_the_registration_is_repeated():
+    """One workgroup's contribution never arrives (as if another kernel kept it off the chip): the exchange gives up after
+    0.25 s, ws_register_cloud repeats the registration with one launch per iteration -- same pose, same iteration count --
+    and the next resident registration is clean again (the accumulators of the aborted launch are cleared by its successor)."""
+    import ctypes as C
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    q = S.transform_points_mm(pts, S.perturbation(-45, 25, 5, -2.0))
+    r = reg.reg_
+    r.prepare_registration(q)
+    args = (reg.tsdf().device_map(), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, res)
+    T0, it0 = r.register_cloud(*args)
+    before = C.c_int32(0)
+    assert r._L.ws_debug_reg_stall(r.handle, 1, C.byref(before)) == 0
+    T1, it1 = r.register_cloud(*args)
+    after = C.c_int32(0)
+    assert r._L.ws_debug_reg_stall(r.handle, 0, C.byref(after)) == 0
+    assert after.value == before.value + 1
+    assert it1 == it0 and np.array_equal(T1, T0)
+    for _ in range(3):  # both accumulator sets come round again
+        T2, it2 = r.register_cloud(*args)
+        assert it2 == it0 and np.array_equal(T2, T0)
+    done = C.c_int32(0)
+    r._L.ws_debug_reg_stall(r.handle, 0, C.byref(done))
+    assert done.value == after.value
+
+
 def test_register_cloud_empty_overlap():
     """c == 0 (cloud far outside the map): the loop stops instead of producing NaN."""
     reg, oa, pts, res = build_scene(rings=8, az=64)

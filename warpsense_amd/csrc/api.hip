@@ -990,6 +990,14 @@ int ws_reg_set_loop(ws_reg *r, int mode)
   return WS_OK;
 }
 
+int ws_debug_reg_stall(ws_reg *r, int32_t stall_next, int32_t *fallbacks)
+{
+  if (!r) return invalid("ws_debug_reg_stall: NULL argument");
+  r->debug_stall_next = stall_next ? 1 : 0;
+  if (fallbacks) *fallbacks = r->resident_fallbacks;
+  return WS_OK;
+}
+
 int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status)
 {
   if (!ctx || !A || !b || !x || !status) return invalid("ws_debug_solve6: NULL argument");

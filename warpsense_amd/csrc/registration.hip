@@ -749,7 +749,10 @@ constexpr int REG_WORDS = 2 * REG_SLOTS; // low halves, then high halves
 constexpr uint64_t REG_COUNT_ONE = 1ull << 56;
 constexpr uint64_t REG_SUM_MASK = REG_COUNT_ONE - 1;
 static_assert(REG_WORDS == 64 && REG_BLOCKS % REG_GROUPS == 0 && REG_BLOCKS / REG_GROUPS < 256, "counted exchange");
-constexpr int REG_FIRST_POLL_SLEEP = 28; // x 64 clocks before the first poll
+#ifndef WS_REG_FIRST_POLL_SLEEP
+#define WS_REG_FIRST_POLL_SLEEP 28
+#endif
+constexpr int REG_FIRST_POLL_SLEEP = WS_REG_FIRST_POLL_SLEEP; // x 64 clocks before the first poll
 constexpr int REG_POLL_SLEEP = 2;        // between polls
 constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
 
@@ -822,6 +825,7 @@ struct LoopArgs
   GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
   uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch
   uint32_t *abort_flag; // zeroed before the launch
+  int32_t debug_stall;  // test hook (ws_debug_reg_stall): workgroup 0 keeps its first contribution to itself
   uint32_t *clear_next; // the set of the NEXT launch (abort flag + accumulators): cleared on the way out
   uint32_t clear_words;
   int32_t *host_flag;
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     WS_LSTAMP(5);
     if (threadIdx.x < 64)
     {
-      counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wave_part);
+      if (!(a.debug_stall && blockIdx.x == 0 && k == 0)) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wave_part);
     }
 #ifdef WS_REG_TIMING
     WS_LSTAMP(6);
@@ -1171,6 +1175,8 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   a.clear_next = reinterpret_cast<uint32_t *>(other);
   a.clear_words = (uint32_t)(REG_SET_BYTES / sizeof(uint32_t));
   a.host_flag = r->host_flag_dev;
+  a.debug_stall = r->debug_stall_next;
+  r->debug_stall_next = 0;
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_loop_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);

@@ -218,6 +218,7 @@ struct ws_reg
   bool loop_sets_clear = false;
   int loop_mode = 0;                 // WS_REG_LOOP_*
   int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
+  int debug_stall_next = 0;          // ws_debug_reg_stall
   int resident_fallbacks = 0;        // registrations redone with one launch per iteration after a barrier timeout
 };
 
