@@ -191,6 +191,13 @@ __device__ __forceinline__ double in_vgpr(double v)
   return v;
 }
 
+template <typename V>
+__device__ __forceinline__ void pin_vgpr(V &v)
+{
+  static_assert(sizeof(V) == 4, "32-bit values");
+  asm volatile("" : "+v"(v));
+}
+
 // a: this lane's element of [A | b].  Returns 0 and x (identical in every lane), or -1 for a singular matrix.
 __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
 {
@@ -473,11 +480,7 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
   if (CACHED)
   {
     VoxelCache &c = *cache;
-#ifdef WS_EXP_NOMISS
-    const bool refill = g.ok && !c.filled;
-#else
     const bool refill = g.ok && !(c.filled && c.bx == bx && c.by == by && c.bz == bz);
-#endif
     if (refill) // one exec-mask region; everything else is selects
     {
       c.cur = a.map_data[get_index(a.map, bx, by, bz)];
@@ -825,11 +828,15 @@ struct LoopArgs
   GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
   uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch
   uint32_t *abort_flag; // zeroed before the launch
-  int32_t debug_stall;  // test hook (ws_debug_reg_stall): workgroup 0 keeps its first contribution to itself
   uint32_t *clear_next; // the set of the NEXT launch (abort flag + accumulators): cleared on the way out
   uint32_t clear_words;
+  int32_t debug_stall;  // test hook (ws_debug_reg_stall): workgroup 0 keeps its first contribution to itself.  Sits in the padding
+                        // behind clear_words on purpose: 8 more bytes of kernel arguments made this kernel 30 % slower (1.07 -> 1.39 ms)
   int32_t *host_flag;
 };
+// Measured on MI355X / ROCm 7.0 (tools/reg_fit.py): with 264 bytes of kernel arguments instead of 256 an iteration of this
+// kernel takes 7.86 us instead of 6.03 us -- same instructions, and 192 bytes are no faster than 256.  Keep them within 256.
+static_assert(sizeof(LoopArgs) <= 256, "reg_loop_kernel: more than 256 bytes of kernel arguments");
 
 __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
@@ -841,6 +848,14 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   const Prefetched pref = prefetch_points(a.pts);
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
+  // The loop state is uniform, so the compiler would keep it in scalar registers -- on top of the ~50 the kernel arguments
+  // occupy, i.e. spilled to vector lanes and reloaded (v_readlane) in the middle of the first wave's dependency chain,
+  // and everything the vector unit computes from it (all of it is float arithmetic) would cross between the two register
+  // files.  Pinned to vector registers here it simply stays where it is used.
+  pin_vgpr(st.center[0]); pin_vgpr(st.center[1]); pin_vgpr(st.center[2]);
+  pin_vgpr(st.alpha); pin_vgpr(st.it_weight_gradient); pin_vgpr(st.epsilon);
+  pin_vgpr(st.prev[0]); pin_vgpr(st.prev[1]); pin_vgpr(st.prev[2]); pin_vgpr(st.prev[3]);
+  pin_vgpr(st.max_iterations); pin_vgpr(st.iterations); pin_vgpr(st.finished); pin_vgpr(st.error);
   uint64_t then_cur[REG_GROUPS], then_other[REG_GROUPS]; // first wave: the accumulator words of both parities when last complete
 #pragma unroll
   for (int g = 0; g < REG_GROUPS; ++g) then_cur[g] = then_other[g] = 0;

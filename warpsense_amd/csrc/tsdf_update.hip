@@ -62,14 +62,15 @@ struct ScatterArgs
   uint32_t rec_cap;
   RunDesc *desc;
   uint32_t desc_cap;
-  unsigned long long *fk_keys;
-  unsigned long long *fk_vals;
+  unsigned long long *fk_keys; // the values follow the keys (fk_keys + fk_mask + 1): one allocation, and the arguments stay within 256 bytes
   int32_t fk_shift; // 64 - log2(slots)
   uint32_t fk_mask;
   uint32_t *tail_stats; // records per workgroup of the tail march
   TsdfCounters *counters;
   uint32_t *status; // host-mapped: [0] sticky error bits
 };
+// 264 bytes of kernel arguments instead of 256 cost reg_loop_kernel 30 % (registration.hip); the same bound here
+static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of kernel arguments");
 
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_FREEHIT = 4;
 constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
@@ -815,7 +816,7 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
       if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
       if (old == KEY_INF || old == (unsigned long long)idx)
       {
-        atomicMin(&a.fk_vals[h], t);
+        atomicMin(&a.fk_keys[(size_t)a.fk_mask + 1 + h], t);
         done = true;
       }
       h = (h + 1) & a.fk_mask;
@@ -2122,7 +2123,6 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.desc = m->desc;
   sa.desc_cap = m->desc_cap;
   sa.fk_keys = m->fk_keys;
-  sa.fk_vals = m->fk_vals;
   {
     int l = 0;
     while ((1u << l) < m->fk_slots) ++l;
