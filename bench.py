@@ -187,7 +187,11 @@ def main():
                     _lib.WS_K_INTEGRATE)
     tsdf_mask = sum(1 << k for k in tsdf_classes)
     ctx.prof_reset()
-    ctx.prof_enable(tsdf_mask)  # hipEvents around the TSDF kernel classes of every step, on the stream they run on
+    # In the timed region: ONE hipEvent pair per scan around all kernels of the update, on the stream they run on (plus the
+    # dense integrate's own pair when that is the kernel the roofline is about).  A pair per kernel class -- twelve event
+    # records per scan -- costs 27 us per step (1.6 %); the per-class table comes from a separate pass below.
+    timed_mask = (1 << _lib.WS_K_UPDATE) | ((1 << _lib.WS_K_INTEGRATE) if args.integrate == "dense" else 0)
+    ctx.prof_enable(timed_mask)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -198,14 +202,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms, cnt = ctx.prof_read(_lib.WS_K_UPDATE)
+    update_span_us = 1000.0 * ms / cnt if cnt else None
+    ms, cnt = ctx.prof_read(_lib.WS_K_INTEGRATE)
+    integrate_timed_us = 1000.0 * ms / cnt if cnt else None
+    stats = tsdf.stats()
+    ctx.prof_enable(0)
+
+    # per-class kernel times: the same steps again with an event pair per class (outside the timed region)
     kernels = {}
+    ctx.prof_reset()
+    ctx.prof_enable(tsdf_mask)
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+    fence()
     for k in tsdf_classes:
         name = _lib.KERNEL_CLASSES[k]
         ms, cnt = ctx.prof_read(k)
         if cnt:
             kernels[name] = {"avg_us": 1000.0 * ms / cnt, "launches": cnt}
-    stats = tsdf.stats()
     ctx.prof_enable(0)
+    if integrate_timed_us is not None and "integrate" in kernels:
+        kernels["integrate"]["avg_us"] = integrate_timed_us  # the timed region's own measurement
 
     # dense-equivalent pass: the same steps with the reference-shaped integrate that streams EVERY voxel
     # (16 B/voxel) -- the kernel the survey holds to the HBM roofline.  Separate from the timed region above.
@@ -308,13 +326,20 @@ def main():
             pass
         if dom == "integrate":
             grp_bytes, grp_us, grp = b_integrate, kernels["integrate"]["avg_us"], ["integrate"]
+            timing = "hipEvent pair around the kernel, every scan of the timed region"
+        elif fused and update_span_us:
+            # the scatter's bytes belong to its kernels TOGETHER (set-up, both marches, binning, tile resolve with the fused
+            # integrate, bookkeeping pass): one event pair per scan of the timed region around all of them
+            grp_bytes, grp_us, grp = b_scatter + b_integrate, update_span_us, [k for k in scatter_classes if k in kernels]
+            timing = "one hipEvent pair per scan of the timed region around all kernels of the update (incl. its bookkeeping pass)"
         else:
-            # the scatter's bytes belong to its kernels TOGETHER (set-up, both marches, binning, tile resolve)
-            grp_bytes, grp_us, grp = b_scatter + (b_integrate if fused else 0), t_scatter, [k for k in scatter_classes if k in kernels]
+            grp_bytes, grp_us, grp = b_scatter, t_scatter, [k for k in scatter_classes if k in kernels]
+            timing = "sum of the per-class hipEvent pairs (separate pass)"
         achieved = grp_bytes / (grp_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "kernel_group": grp, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": grp_bytes,
-                    "avg_launch_us": grp_us, "dominant_kernel_us": kernels[dom]["avg_us"],
+                    "avg_launch_us": grp_us, "timing": timing, "dominant_kernel_us": kernels[dom]["avg_us"],
+                    "per_class_sum_us": t_scatter,
                     "note": "VALU-bound ray march (DESIGN.md §5); bytes = SURVEY §8d's scatter term" + (" + fused integrate" if fused else "")}
         if "integrate" in kernels and dom != "integrate":
             ia = b_integrate / (kernels["integrate"]["avg_us"] * 1e-6) / 1e9

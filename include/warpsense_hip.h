@@ -231,7 +231,8 @@ int ws_scan_download(ws_scan *scan, int32_t *xyz_host, size_t capacity_points, s
 #define WS_K_TILE_RESOLVE 4  /* exact per-tile fold in LDS (+ fused integrate)                     */
 #define WS_K_INTEGRATE 5     /* separate sparse or dense weighted-average pass (cu_avg_tsdf_krnl)  */
 #define WS_K_REG 6           /* Gauss-Newton iterations (accumulate + solve)                       */
-#define WS_K_COUNT 7
+#define WS_K_UPDATE 7        /* one span over ALL kernels of a ws_tsdf_update* call (two events per scan)  */
+#define WS_K_COUNT 8
 int ws_prof_enable(ws_context *ctx, uint32_t class_mask); /* 0 disables */
 /* sum of event-measured durations and number of launches per class since the last reset (synchronises) */
 int ws_prof_read(ws_context *ctx, int kernel_class, double *total_ms, int64_t *launches);

@@ -14,8 +14,8 @@ WS_MAP_AVG, WS_MAP_NEW = 0, 1
 WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE, WS_INTEGRATE_SPARSE_SEPARATE = 0, 1, 2
 WS_REG_ALL_POINTS, WS_REG_COMPAT_REFERENCE_LAUNCH = 0, 1
 WS_REG_LOOP_RESIDENT, WS_REG_LOOP_LAUNCHES = 0, 1
-(WS_K_SETUP, WS_K_MARCH_TAILS, WS_K_MARCH_FREE, WS_K_TILE_BIN, WS_K_TILE_RESOLVE, WS_K_INTEGRATE, WS_K_REG) = range(7)
-KERNEL_CLASSES = ["ray_setup", "march_tails", "march_free", "tile_bin", "tile_resolve", "integrate", "reg_iteration"]
+(WS_K_SETUP, WS_K_MARCH_TAILS, WS_K_MARCH_FREE, WS_K_TILE_BIN, WS_K_TILE_RESOLVE, WS_K_INTEGRATE, WS_K_REG, WS_K_UPDATE) = range(8)
+KERNEL_CLASSES = ["ray_setup", "march_tails", "march_free", "tile_bin", "tile_resolve", "integrate", "reg_iteration", "tsdf_update"]
 
 # every symbol include/warpsense_hip.h declares (tests check the library exports all of them)
 EXPORTS = [

@@ -723,9 +723,11 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
   if (rc != WS_OK) return rc;
   // with the default (sparse) integrate the tile resolve folds cu_avg_tsdf_krnl into its write-back (new_map stays
   // (tau, 0)); a non-default new_map is resolved on top of its entries and integrated by the dense pass
+  prof_begin(m->ctx, WS_K_UPDATE);
   rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
-  if (rc != WS_OK) return rc;
-  return launch_tsdf_integrate(m);
+  if (rc == WS_OK) rc = launch_tsdf_integrate(m);
+  prof_end(m->ctx, WS_K_UPDATE);
+  return rc;
 }
 
 int ws_tsdf_update(ws_map *m, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3])
