@@ -350,7 +350,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->block_sums, (size_t)m->scan_blocks * 4 * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->tile_dirty, 0, (size_t)m->n_tiles, s));
-  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * 2 * sizeof(unsigned long long))); // keys, then values
+  // keys, values, then one bit per slot: claimed by the current scan (so that the clean-up clears ~25 000 entries, not 2 x 2^20)
+  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * 2 * sizeof(unsigned long long) + m->fk_slots / 8));
   m->fk_vals = m->fk_keys + m->fk_slots;
   TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));

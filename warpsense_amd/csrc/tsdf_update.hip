@@ -123,6 +123,7 @@ struct PrepArgs
   int64_t n_tiles;
   unsigned long long *fk; // keys and values: one allocation
   int64_t n_fk;
+  uint32_t fk_all; // 1: fill the whole hash (first preparation of a map), 0: only the claimed slots
   unsigned long long *look; // look-back words of the tile scan
   uint32_t n_look;
 };
@@ -136,7 +137,29 @@ __device__ __forceinline__ void scatter_prep(const PrepArgs &p, bool counters_to
     p.az_cur[i] = 0;
   }
   for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nruns[i] = 0;
-  for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
+  // the free-space key hash: only the slots the scan claimed (bitmap behind the hash), or all of it the first time
+  uint32_t *claimed = reinterpret_cast<uint32_t *>(p.fk + p.n_fk);
+  if (p.fk_all)
+  {
+    for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
+    for (int64_t i = tid; i < p.n_fk / 64; i += stride) claimed[i] = 0;
+  }
+  else
+  {
+    for (int64_t i = tid; i < p.n_fk / 64; i += stride)
+    {
+      uint32_t bits = claimed[i];
+      if (bits == 0) continue;
+      claimed[i] = 0;
+      while (bits)
+      {
+        const uint32_t h = (uint32_t)i * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1;
+        p.fk[h] = KEY_INF;
+        p.fk[p.n_fk / 2 + h] = KEY_INF;
+      }
+    }
+  }
   for (int64_t i = tid; i < p.n_look; i += stride) p.look[i] = 0;
 }
 __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter_prep(p, true); }
@@ -783,9 +806,13 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
     if (threadIdx.x == 0) s_overflow = 0;
   }
 #ifdef WS_TAIL_TIMING
-  if ((threadIdx.x & 63) == 0 && (blockIdx.x % 97) == 5)
-    printf("tail wg %u wave %d: records %u | march %lld wait-for-others %lld phase2 %lld cycles\n", blockIdx.x, wave, total, tt1 - tt0, tt2 - tt1,
-           clock64() - tt2);
+  if (threadIdx.x == 0)
+  {
+    // durations (16-cycle units) behind the per-workgroup record counts: summarised once per scan by finish_update_kernel
+    const long long t_end = clock64();
+    a.tail_stats[32768 + blockIdx.x] = (uint32_t)((t_end - tt0) >> 4);
+    a.tail_stats[49152 + blockIdx.x] = (uint32_t)((t_end - tt2) >> 4);
+  }
 #endif
 }
 
@@ -814,6 +841,8 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
       const unsigned long long cur = a.fk_keys[h];
       unsigned long long old = cur;
       if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
+      if (old == KEY_INF) // claimed: one bit per slot behind the hash tells the clean-up after the scan where to look
+        atomicOr(&reinterpret_cast<uint32_t *>(a.fk_keys + 2 * ((size_t)a.fk_mask + 1))[h >> 5], 1u << (h & 31u));
       if (old == KEY_INF || old == (unsigned long long)idx)
       {
         atomicMin(&a.fk_keys[(size_t)a.fk_mask + 1 + h], t);
@@ -1183,7 +1212,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
     if (b == gridDim.x - 1)
     {
       a.counters->n_desc_sorted = (uint32_t)(prefix + total);
-      a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
+        a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
     }
   }
   __syncthreads();
@@ -1900,6 +1929,34 @@ __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, con
     *reinterpret_cast<volatile unsigned long long *>(status + 2) = c->ub_total;
   }
   __syncthreads();
+#ifdef WS_TAIL_TIMING
+  if (blockIdx.x == 0)
+  {
+    __shared__ uint32_t hist[2][24];
+    __shared__ unsigned long long sums[2];
+    if (threadIdx.x < 48) hist[threadIdx.x / 24][threadIdx.x % 24] = 0;
+    if (threadIdx.x < 2) sums[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tail; i += 256)
+    {
+      const uint32_t t = tail_stats[32768 + i] * 16, p2 = tail_stats[49152 + i] * 16;
+      atomicAdd(&hist[0][min(23u, t / 16384u)], 1u);
+      atomicAdd(&hist[1][min(23u, p2 / 16384u)], 1u);
+      atomicAdd(&sums[0], (unsigned long long)t);
+      atomicAdd(&sums[1], (unsigned long long)p2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      printf("tail march: %u workgroups, mean %llu cycles (phase 2 %llu); histogram of totals in 16384-cycle bins:", n_tail, sums[0] / max(n_tail, 1u),
+             sums[1] / max(n_tail, 1u));
+      for (int i = 0; i < 24; ++i) printf(" %u", hist[0][i]);
+      printf(" | phase 2:");
+      for (int i = 0; i < 24; ++i) printf(" %u", hist[1][i]);
+      printf("\n");
+    }
+  }
+#endif
   // the per-scan counters: zero for the next scan (n_listed stays: a separate integrate pass may still follow)
   if (threadIdx.x < offsetof(TsdfCounters, last_records) / 4 && threadIdx.x != offsetof(TsdfCounters, n_listed) / 4)
     reinterpret_cast<uint32_t *>(c)[threadIdx.x] = 0;
@@ -2035,7 +2092,7 @@ int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
 }
 
 constexpr int PREP_GRID = 512;
-static PrepArgs make_prep_args(ws_map *m)
+static PrepArgs make_prep_args(ws_map *m, bool whole_hash = true)
 {
   PrepArgs p;
   p.counters = m->counters;
@@ -2046,6 +2103,7 @@ static PrepArgs make_prep_args(ws_map *m)
   p.n_tiles = m->n_tiles;
   p.fk = m->fk_keys;
   p.n_fk = (int64_t)2 * m->fk_slots;
+  p.fk_all = whole_hash ? 1 : 0; // the stand-alone preparation fills the whole hash; the pass after a scan clears what the scan claimed
   p.look = reinterpret_cast<unsigned long long *>(m->block_sums);
   p.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
   return p;
@@ -2277,7 +2335,7 @@ int launch_tsdf_integrate(ws_map *m)
     prof_end(ctx, WS_K_INTEGRATE);
   }
   hipLaunchKernelGGL(finish_update_kernel, dim3(PREP_GRID), block, 0, s, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
-                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev, make_prep_args(m));
+                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev, make_prep_args(m, false));
   WS_HIP(hipGetLastError());
   m->prepped = true;
   m->fused_done = false;
