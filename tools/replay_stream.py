@@ -58,6 +58,7 @@ def main():
     app.terminate()
     t4 = time.perf_counter()
     print(json.dumps({"workload": f"{args.scans} synthetic OS1-128 scans (131072 pts), {args.map}^3 sliding map @ {args.res} mm, App replay",
+                      "args": {"step_m": args.step, "shift_m": args.shift, "room_m": list(args.room), "h5": bool(args.h5)},
                       "scans_per_s": args.scans / (t2 - t1), "stream_s": t2 - t1, "setup_s": t_setup, **stages,
                       "tsdf_updates": app.n_updates, "map_shifts": app.n_shifts, "async_shift": bool(args.async_shift),
                       "slowest_scan_ms": 1000.0 * float(max(t["total"] for t in app.timings[2:])),
