@@ -669,9 +669,6 @@ __global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
   const uint32_t total = min(s_cursor, ub_total);
   if (threadIdx.x == 0) a.tail_stats[blockIdx.x] = total;
   if (total == 0) return;
-#ifdef WS_EXP_TAIL_NOBIN
-  return;
-#endif
 
   // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
   // publish one run per tile.  If more tiles are touched than the hash holds, the rest is binned in further rounds.
@@ -888,11 +885,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
   const bool work = k0 < k1;
   const int32_t tau = a.tau;
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
-#ifdef WS_EXP_FORCE_OLD
-  if (true)
-#else
   if (!__all(!work || (r.pad & RAY_SIMPLE)))
-#endif
   {
     // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
     if (!work) return;
