@@ -376,6 +376,9 @@ constexpr int HT_BITS = 10, HT_SLOTS = 1 << HT_BITS;
 #ifndef WS_TAIL_SPLIT
 #define WS_TAIL_SPLIT 2
 #endif
+#ifndef WS_TAIL_WGS
+#define WS_TAIL_WGS 6 // workgroups per CU the register budget is set for (80 VGPRs, no spills; 5 -> 6: 184 -> 181 us)
+#endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
 constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DONE = 0xffffffffu;
@@ -428,7 +431,7 @@ typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate 
 
 // A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
 // quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
-__global__ __launch_bounds__(256) void march_tail_kernel(ScatterArgs a)
+__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
 {
   __shared__ uint32_t s_cursor, s_base, s_ub, s_overflow, s_desc_base, s_round_total;
   __shared__ uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_cur[HT_SLOTS];
