@@ -1278,7 +1278,7 @@ struct ResolveArgs
   uint32_t *status;
 };
 
-constexpr int RESOLVE_GRID = 4096;
+constexpr int RESOLVE_GRID = 4096; // 1024 / 2048 / 8192 workgroups: the same 170 us, 3072: 182 (block_stats holds two words per workgroup)
 constexpr uint32_t M_IDLE = 0xffffffffu, M_NONE = 0x10000u; // mstate: voxel not in the ordered rounds / no earlier negative seen
 
 // kneg: smallest |value| wins, the LATEST candidate among equal |value| (a later equal one replaces the entry)
