@@ -126,6 +126,21 @@ __device__ __forceinline__ void wave_reduce32(int64_t (&v)[REG_SLOTS], int64_t (
   __syncthreads();
 }
 
+// The same with the eight wave totals of a slot ADDED into wg_sum[slot] (LDS atomics, zero before) instead of laid side by
+// side: the first wave then reads one value per slot instead of eight (valid after the trailing barrier).
+__device__ __forceinline__ void wave_reduce32_add(int64_t (&v)[REG_SLOTS], unsigned long long *wg_sum)
+{
+  const int lane = threadIdx.x & 63;
+  reduce_stage<16, 32>(v, lane);
+  reduce_stage<8, 16>(v, lane);
+  reduce_stage<4, 8>(v, lane);
+  reduce_stage<2, 4>(v, lane);
+  reduce_stage<1, 2>(v, lane);
+  v[0] = wadd64(v[0], dpp_xor_i64<1>(v[0]));
+  if ((lane & 1) == 0) atomicAdd(&wg_sum[lane >> 1], (unsigned long long)v[0]);
+  __syncthreads();
+}
+
 // Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
 // trailing barrier).
 __device__ __forceinline__ void block_reduce32(int64_t (&v)[REG_SLOTS], int64_t (*wave_part)[REG_SLOTS], int64_t *red)
@@ -760,12 +775,12 @@ constexpr int REG_POLL_SLEEP = 2;        // between polls
 constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
 
 // first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
-__device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, int64_t (*wave_part)[REG_SLOTS])
+__device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, unsigned long long *wg_sum, bool publish)
 {
   const int lane = threadIdx.x & 63, slot = lane & (REG_SLOTS - 1);
-  int64_t s = 0;
-#pragma unroll
-  for (int w = 0; w < REG_THREADS / 64; ++w) s = wadd64(s, wave_part[w][slot]);
+  const unsigned long long s = wg_sum[slot];
+  if (lane < REG_SLOTS) wg_sum[slot] = 0; // for the next iteration (the same wave read it one instruction ago)
+  if (!publish) return;
   const uint32_t half = lane < REG_SLOTS ? (uint32_t)((uint64_t)s & 0xffffffffull) : (uint32_t)((uint64_t)s >> 32);
   const int group = blockIdx.x / (REG_BLOCKS / REG_GROUPS);
   __hip_atomic_fetch_add(&accum[(size_t)group * REG_WORDS + lane], REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -840,7 +855,7 @@ static_assert(sizeof(LoopArgs) <= 256, "reg_loop_kernel: more than 256 bytes of 
 
 __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
-  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ unsigned long long wg_sum[REG_SLOTS]; // the workgroup's totals of an iteration (LDS atomics of the eight waves)
   __shared__ int64_t red[REG_SLOTS];
   __shared__ alignas(16) float T_sh[16];
   __shared__ int stop_sh;
@@ -875,6 +890,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #define WS_LSTAMP(i)
 #endif
   if (threadIdx.x < 16) T_sh[threadIdx.x] = a.init.T[threadIdx.x];
+  if (threadIdx.x < REG_SLOTS) wg_sum[threadIdx.x] = 0;
   uint32_t k = 0;
   for (;; ++k)
   {
@@ -928,12 +944,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
         hit_ticks += ts[4] - ts[3];
     }
 #endif
-    wave_reduce32(acc, wave_part);
+    wave_reduce32_add(acc, wg_sum);
     WS_LSTAMP(5);
-    if (threadIdx.x < 64)
-    {
-      if (!(a.debug_stall && blockIdx.x == 0 && k == 0)) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wave_part);
-    }
+    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0));
 #ifdef WS_REG_TIMING
     WS_LSTAMP(6);
     for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
