@@ -90,6 +90,38 @@ __device__ __forceinline__ int64_t dpp_xor_i64(int64_t v)
   return pack64(dpp_xor<BIT>((int)(uint32_t)((uint64_t)v & 0xffffffffull)), dpp_xor<BIT>((int)(uint32_t)((uint64_t)v >> 32)));
 }
 
+// One pair of a transposing stage inside a 16-lane row (BIT 8 or 4): lanes without the bit end up with a + a(partner),
+// lanes with it with b + b(partner), both in `a`.  Four DPP adds whose bank masks pick the two halves -- the partner comes
+// over the DPP operand of the add itself (row_shl for the lower lanes, row_shr for the upper ones) -- instead of four
+// selects, two to four DPP moves and two adds.  (s_nop: a VGPR written by the instruction before must not be read over DPP
+// at once, and the compiler does not see what the asm reads.)
+template <int BIT>
+__device__ __forceinline__ void dpp_pair_add(int64_t &a, const int64_t b)
+{
+  static_assert(BIT == 8 || BIT == 4, "row-internal stages");
+  uint32_t alo = (uint32_t)((uint64_t)a & 0xffffffffull), ahi = (uint32_t)((uint64_t)a >> 32);
+  const uint32_t blo = (uint32_t)((uint64_t)b & 0xffffffffull), bhi = (uint32_t)((uint64_t)b >> 32);
+  if constexpr (BIT == 8)
+    asm volatile("s_nop 1\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc row_shr:8 row_mask:0xf bank_mask:0xc"
+                 : "+v"(alo), "+v"(ahi)
+                 : "v"(blo), "v"(bhi)
+                 : "vcc");
+  else
+    asm volatile("s_nop 1\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc row_shr:4 row_mask:0xf bank_mask:0xa"
+                 : "+v"(alo), "+v"(ahi)
+                 : "v"(blo), "v"(bhi)
+                 : "vcc");
+  a = (int64_t)(((uint64_t)ahi << 32) | alo);
+}
+
 template <int HALF, int BIT>
 __device__ __forceinline__ void reduce_stage(int64_t (&v)[REG_SLOTS], int lane)
 {
@@ -97,6 +129,11 @@ __device__ __forceinline__ void reduce_stage(int64_t (&v)[REG_SLOTS], int lane)
   {
 #pragma unroll
     for (int i = 0; i < HALF; ++i) swap_add_stage<BIT>(v[i], v[i + HALF]);
+  }
+  else if constexpr (BIT >= 4)
+  {
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) dpp_pair_add<BIT>(v[i], v[i + HALF]);
   }
   else
   {
