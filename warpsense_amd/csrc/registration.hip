@@ -967,8 +967,15 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #endif
     accumulate_points<true>(a.pts, T, pref, acc, cache);
     WS_LSTAMP(4);
+    wave_reduce32_add(acc, wg_sum);
+    WS_LSTAMP(5);
+    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0));
 #ifdef WS_REG_TIMING
-    {
+    WS_LSTAMP(6);
+    for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
+#endif
+#ifdef WS_REG_TIMING
+    { // (after the stamps of the phases: the vote below costs a barrier)
       const bool changed = ofilled && cache[0].filled && (obx != cache[0].bx || oby != cache[0].by || obz != cache[0].bz);
       const int n_changed = __syncthreads_count(changed ? 1 : 0);
       if (n_changed > 0)
@@ -980,13 +987,6 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
       else
         hit_ticks += ts[4] - ts[3];
     }
-#endif
-    wave_reduce32_add(acc, wg_sum);
-    WS_LSTAMP(5);
-    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0));
-#ifdef WS_REG_TIMING
-    WS_LSTAMP(6);
-    for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
 #endif
   }
 #ifdef WS_REG_TIMING_GN
