@@ -193,6 +193,12 @@ int ws_reg_begin(ws_reg *reg, const float T_in[16], int32_t max_iterations, floa
 int ws_reg_accumulate_dev(ws_reg *reg, const ws_map *map, int32_t map_resolution, uint32_t flags, size_t first,
                           size_t count, int64_t *sums_dev /* 44 */);
 int ws_reg_solve_dev(ws_reg *reg, const int64_t *sums_dev /* 44 */);
+/* The same two steps as ONE launch per iteration: if apply_previous != 0, first the Gauss-Newton update from the 44
+ * (all-reduced) sums in sums_dev -- exactly what ws_reg_solve_dev does --, then the accumulation of [first, first+count)
+ * into sums_dev.  A sharded loop is: ws_reg_begin; { ws_reg_iterate_shard_dev(apply_previous = not the first); all-reduce
+ * sums_dev } x n; ws_reg_solve_dev(sums_dev); ws_reg_poll.  Do not touch sums_dev between the all-reduce and the next call. */
+int ws_reg_iterate_shard_dev(ws_reg *reg, const ws_map *map, int32_t map_resolution, uint32_t flags, size_t first, size_t count,
+                             int64_t *sums_dev /* 44 */, int32_t apply_previous);
 int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out[16]); /* synchronises */
 
 /* Test entry: the 6x6 solve of the Gauss-Newton update alone (LU with partial pivoting in double, one wavefront per

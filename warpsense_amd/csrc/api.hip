@@ -777,6 +777,7 @@ int ws_reg_destroy(ws_reg *r)
   if (r->host_flag) (void)hipHostFree(r->host_flag);
   if (r->result_host) (void)hipHostFree(r->result_host);
   if (r->grid_bar) (void)hipFree(r->grid_bar);
+  if (r->shard_arrived) (void)hipFree(r->shard_arrived);
   delete r;
   return WS_OK;
 }
@@ -813,6 +814,8 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->result_host_dev, r->result_host, 0);
   if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, 2 * sizeof(GnState), ctx->stream);
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->grid_bar, reg_barrier_bytes());
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->shard_arrived, 256);
+  if (rc == WS_OK && e == hipSuccess) e = hipMemset(r->shard_arrived, 0, 256);
   if (rc == WS_OK && e == hipSuccess) r->loop_supported = reg_loop_supported(ctx->device);
   if (rc != WS_OK || e != hipSuccess)
   {
@@ -894,6 +897,13 @@ int ws_reg_accumulate_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t flag
 {
   if (!r || !m || !sums_dev) return invalid("ws_reg_accumulate_dev: NULL argument");
   return launch_reg_accumulate(r, m, nullptr, res, flags, first, count, sums_dev);
+}
+
+int ws_reg_iterate_shard_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev,
+                             int32_t apply_previous)
+{
+  if (!r || !m || !sums_dev) return invalid("ws_reg_iterate_shard_dev: NULL argument");
+  return launch_reg_shard(r, m, res, flags, first, count, sums_dev, apply_previous);
 }
 
 int ws_reg_solve_dev(ws_reg *r, const int64_t *sums_dev)

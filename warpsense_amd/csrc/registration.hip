@@ -1127,6 +1127,94 @@ __global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int
   }
 }
 
+// ---- one launch per iteration of the point-sharded (multi-GPU) path -------------------------------------------------
+// [apply the Gauss-Newton update from the all-reduced sums of the previous iteration] -> accumulate this rank's shard ->
+// the 44 sums, in ONE kernel instead of reg_solve + reg_accumulate + reg_sum: every workgroup repeats the (cheap) update
+// from the same sums, like the resident loop does, and the last workgroup to deliver its partials adds them up (an
+// arrival counter, agent-scope accesses as everywhere on this path: no cache-wide fences).  The state is double buffered
+// (workgroup 0 writes the updated state while the others may still be reading the old one).
+struct ShardArgs
+{
+  PointArgs pts;          // first / end: this rank's shard
+  const GnState *state_in;
+  GnState *state_out;     // written when `apply` (by workgroup 0)
+  int64_t *sums;          // in: the all-reduced sums of the previous iteration (if apply); out: this rank's 44 sums
+  int64_t *partials;      // [REG_BLOCKS][REG_SLOTS]
+  uint32_t *arrived;      // zero between launches
+  int32_t apply;
+};
+
+__global__ __launch_bounds__(REG_THREADS) void reg_shard_kernel(ShardArgs a)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  __shared__ int64_t s44[44];
+  __shared__ float T_sh[16];
+  __shared__ int stop_sh, last_sh;
+  const Prefetched pref = prefetch_points(a.pts);
+  if (threadIdx.x < 64)
+  {
+    GnCore st;
+    {
+      int32_t *w = reinterpret_cast<int32_t *>(&st);
+      const int32_t *src = reinterpret_cast<const int32_t *>(&a.state_in->core);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) w[i] = coherent_i32(&src[i]);
+    }
+    if (a.apply)
+    {
+      if (threadIdx.x < 44) s44[threadIdx.x] = coherent_i64(&a.sums[threadIdx.x]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // LDS written and read by this wave only
+      __builtin_amdgcn_wave_barrier();
+      gn_update(
+          st, [&](int r, int c) { return s44[c * 6 + r]; }, [&](int r) { return s44[36 + r]; }, (int32_t)s44[42], (int32_t)s44[43]);
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+      {
+        const int32_t *w = reinterpret_cast<const int32_t *>(&st);
+        int32_t *dst = reinterpret_cast<int32_t *>(&a.state_out->core);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) __hip_atomic_store(&dst[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 42; ++k) publish_i64(&a.state_out->sums[k], s44[k]);
+        publish_i64(&a.state_out->sums[42], (int64_t)(int32_t)s44[42]);
+        publish_i64(&a.state_out->sums[43], (int64_t)(int32_t)s44[43]);
+      }
+    }
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) T_sh[i] = st.T[i];
+      stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (stop_sh) return; // every workgroup alike: nobody arrives, the sums stay as they are
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+  int64_t acc[REG_SLOTS];
+#pragma unroll
+  for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+  accumulate_points(a.pts, T, pref, acc);
+  block_reduce32(acc, wave_part, red);
+  if (threadIdx.x < REG_SLOTS) publish_i64(&a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above have been acknowledged ...
+  __syncthreads();                                  // ... for all 32 lanes that made them
+  if (threadIdx.x == 0)
+    last_sh = __hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!last_sh) return;
+  sum_partials<true>(a.partials, wave_part, red);
+  if (threadIdx.x == 0)
+  {
+    int64_t sums[44];
+    expand_sums(red, sums);
+#pragma unroll
+    for (int k = 0; k < 44; ++k) publish_i64(&a.sums[k], sums[k]);
+    __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // test entry: the wave solver alone, one wave per system (A row-major 6x6, b) -> x, status
 __global__ __launch_bounds__(64) void solve6_test_kernel(const double *A, const double *b, double *x, int32_t *status)
 {
@@ -1185,8 +1273,8 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
   ws_context *ctx = r->ctx;
   AccArgs a;
   a.pts = make_point_args(r, m, res, flags, first, count);
-  a.T = T_dev_or_null ? T_dev_or_null : r->state[0].core.T;
-  a.state = T_dev_or_null ? nullptr : &r->state[0];
+  a.T = T_dev_or_null ? T_dev_or_null : r->state[r->latest].core.T;
+  a.state = T_dev_or_null ? nullptr : &r->state[r->latest];
   a.partials = r->partials;
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_accumulate_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
@@ -1198,8 +1286,27 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
 
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev)
 {
-  hipLaunchKernelGGL(reg_solve_kernel, dim3(1), dim3(64), 0, r->ctx->stream, &r->state[0], sums_dev);
+  hipLaunchKernelGGL(reg_solve_kernel, dim3(1), dim3(64), 0, r->ctx->stream, &r->state[r->latest], sums_dev);
   WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev, int apply)
+{
+  ws_context *ctx = r->ctx;
+  ShardArgs a;
+  a.pts = make_point_args(r, m, res, flags, first, count);
+  a.state_in = &r->state[r->latest];
+  a.state_out = &r->state[r->latest ^ 1];
+  a.sums = sums_dev;
+  a.partials = r->partials;
+  a.arrived = r->shard_arrived;
+  a.apply = apply ? 1 : 0;
+  prof_begin(ctx, WS_K_REG);
+  hipLaunchKernelGGL(reg_shard_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  prof_end(ctx, WS_K_REG);
+  WS_HIP(hipGetLastError());
+  if (apply) r->latest ^= 1;
   return WS_OK;
 }
 

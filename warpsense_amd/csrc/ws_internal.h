@@ -214,6 +214,7 @@ struct ws_reg
   float *T_dev = nullptr;            // transform for ws_reg_iterate
   int64_t *sums_dev = nullptr;       // 44
   uint32_t *grid_bar = nullptr;      // two sets of {abort flag, counted group accumulators} of reg_loop_kernel (alternate launches)
+  uint32_t *shard_arrived = nullptr;  // arrival counter of reg_shard_kernel (zero between launches)
   uint32_t loop_launches = 0;
   bool loop_sets_clear = false;
   int loop_mode = 0;                 // WS_REG_LOOP_*
@@ -275,6 +276,7 @@ int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
 int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags,
                           size_t first, size_t count, int64_t *sums_dev);
 int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k);
+int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev, int apply);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);

@@ -7,7 +7,7 @@ every rank runs the identical 6x6 solve.  Integer sums are exact, so the result 
 number of ranks.
 
 The per-rank compute is behind a small backend interface; the product backend (HipGnBackend) drives the
-C ABI (ws_reg_begin / ws_reg_accumulate_dev / ws_reg_solve_dev / ws_reg_poll).
+C ABI (ws_reg_begin / ws_reg_iterate_shard_dev -- or ws_reg_accumulate_dev + ws_reg_solve_dev -- / ws_reg_poll).
 """
 from __future__ import annotations
 
@@ -36,11 +36,13 @@ class HipGnBackend:
         self.reg, self.tsdf, self.res, self.flags = reg, tsdf, int(map_resolution), int(flags)
         self._L = reg._L
         self.sums = torch.zeros(44, dtype=torch.int64, device="cuda")
+        self._pending = False  # iterate(): sums of an iteration whose update has not been applied yet
 
     def begin(self, T_in, max_iterations, it_weight_gradient, epsilon):
         T = np.ascontiguousarray(np.asarray(T_in, dtype=np.float32).reshape(4, 4).T).reshape(16)
         check(self._L.ws_reg_begin(self.reg.handle, T.ctypes.data_as(C.c_void_p), int(max_iterations),
                                    C.c_float(it_weight_gradient), C.c_float(epsilon)), "ws_reg_begin")
+        self._pending = False
 
     def accumulate(self, first: int, count: int):
         check(self._L.ws_reg_accumulate_dev(self.reg.handle, self.tsdf.device_map(), self.res, self.flags, int(first),
@@ -49,6 +51,16 @@ class HipGnBackend:
 
     def solve(self, sums):
         check(self._L.ws_reg_solve_dev(self.reg.handle, C.c_void_p(sums.data_ptr())), "ws_reg_solve_dev")
+        self._pending = False
+
+    def iterate(self, first: int, count: int):
+        """One launch per iteration: the update from the (all-reduced) sums of the previous iterate(), if there was one
+        since begin() / solve(), then the accumulation of the shard into the same 44 words (ws_reg_iterate_shard_dev).
+        The caller all-reduces the returned tensor and, after the last iteration of a batch, calls solve() on it."""
+        check(self._L.ws_reg_iterate_shard_dev(self.reg.handle, self.tsdf.device_map(), self.res, self.flags, int(first), int(count),
+                                               C.c_void_p(self.sums.data_ptr()), 1 if self._pending else 0), "ws_reg_iterate_shard_dev")
+        self._pending = True
+        return self.sums
 
     def binding(self) -> tuple:
         """Everything a captured kernel launch bakes in by value: the map window (size, pos, offset travel as kernel
@@ -117,6 +129,14 @@ class _GraphBatch:
     @staticmethod
     def _eager(backend, first, count, group, n):
         import torch.distributed as dist
+        if hasattr(backend, "iterate") and n > 0:
+            # one kernel + one all-reduce per iteration (the update of iteration i rides in the launch of iteration i + 1)
+            for _ in range(n):
+                sums = backend.iterate(first, count)
+                if dist.is_initialized():
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            backend.solve(sums)  # the last update of the batch, so that poll() sees the state after n iterations
+            return
         for _ in range(n):
             sums = backend.accumulate(first, count)
             if dist.is_initialized():
