@@ -388,8 +388,24 @@ public:
           }
     }
     GlobalMap *gm = &local_map_.global_map();
-    shift_worker_ = std::thread([ticket, n, gm]() {
-      if (ws_shift_wait(ticket) != WS_OK) return;
+    shift_error_.clear();
+    std::string *err = &shift_error_;
+    shift_worker_ = std::thread([ticket, n, gm, err]() {
+      // the ticket is closed whatever happens (an open ticket makes the next ws_shift_begin fail), and a failure -- a HIP
+      // error while waiting for the slabs, an exception out of the global map -- is kept for wait_shift() instead of being
+      // swallowed or ending the process through std::terminate
+      struct Closer
+      {
+        ws_shift *t;
+        ~Closer() { ws_shift_end(t); }
+      } closer{ticket};
+      try
+      {
+      if (ws_shift_wait(ticket) != WS_OK)
+      {
+        *err = std::string("ws_shift_wait: ") + ws_last_error();
+        return;
+      }
       std::vector<TSDFEntry> own;
       for (int i = 0; i < n; ++i)
       {
@@ -423,14 +439,32 @@ public:
         }
         gm->save_box(rm::Pointi(lo[0], lo[1], lo[2]), rm::Pointi(hi[0], hi[1], hi[2]), box);
       }
-      ws_shift_end(ticket);
+      }
+      catch (const std::exception &e)
+      {
+        *err = std::string("filing the leaving slabs: ") + e.what();
+      }
+      catch (...)
+      {
+        *err = "filing the leaving slabs: unknown exception";
+      }
     });
   }
+  // joins the worker of the last asynchronous shift; throws if its slabs did not reach the global map
   void wait_shift()
   {
     if (shift_worker_.joinable()) shift_worker_.join();
+    if (!shift_error_.empty())
+    {
+      const std::string msg = "asynchronous map shift failed: " + shift_error_;
+      shift_error_.clear();
+      throw std::runtime_error(msg);
+    }
   }
-  ~MappingNode() { wait_shift(); }
+  ~MappingNode()
+  {
+    if (shift_worker_.joinable()) shift_worker_.join(); // (a destructor does not throw; the error was the caller's to collect)
+  }
 
   // HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:215-221) from the device map
   void write_back()
@@ -458,6 +492,7 @@ private:
   cuda::DeviceMap view_;
   cuda::TSDFRegistration gpu_;
   std::thread shift_worker_;
+  std::string shift_error_; // written by the worker, read after join()
 };
 
 // ---------------------------------------------------------------------------------------------------- App

@@ -38,11 +38,14 @@ static inline int32_t l2norm_i(int32_t x, int32_t y, int32_t z)
   if (sq < 0) return 0;
   return (int32_t)sqrtf((float)sq);
 }
-/* Vector3<long>::l2norm(): long(sqrtf(float(long sum))) (math/vector3.h:318-330); NaN -> 0 as above */
+/* Vector3<long>::l2norm(): long(sqrtf(float(long sum))) (math/vector3.h:318-330).  A wrapped, negative sum gives NaN here
+ * too, but the 64-bit conversion of the reference's CUDA path (cvt.rzi.s64.f32, i.e. __float2ll_rz) turns NaN into
+ * 0x8000000000000000, not 0 -- the same value x86's cvttss2si gives, so the host-built reference header (the golden)
+ * agrees with the CUDA kernel for this one.  Stated explicitly, because float -> integer of NaN is undefined in C. */
 static inline int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
 {
   int64_t sq = wadd64(wadd64(wmul64(x, x), wmul64(y, y)), wmul64(z, z));
-  if (sq < 0) return 0;
+  if (sq < 0) return INT64_MIN;
   return (int64_t)sqrtf((float)sq);
 }
 

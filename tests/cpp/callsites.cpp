@@ -1,12 +1,23 @@
 // Compile-only check of the drop-in boundary: the statements below are the reference's own uses of cuda::DeviceMap
-// and the device classes (file:line given per statement) against include/warpsense_hip/compat.hpp.
+// and the device classes (file:line given per statement) against include/warpsense_hip/compat.hpp,
+// reached through the shipped forwarding headers include/warpsense/cuda/{cleanup,device_map,device_map_wrapper,registration,update_tsdf}.h.
 // HDF5LocalMap is replaced by a stand-in with the same accessors (the real one needs HighFive): the point is that the
 // CALL SITES compile unchanged, not that the map does.
 #include <array>
 #include <memory>
 #include <vector>
 
-#include "warpsense_hip/compat.hpp"
+// through the names the reference's sources use (tsdf_mapping.cpp:1, tsdf_mapping.h:7-9, pcd2tsdf.cpp:20): the forwarding
+// headers of include/warpsense/cuda/, found ahead of the reference's own by -I order
+#include "warpsense/cuda/cleanup.h"
+#include "warpsense/cuda/device_map.h"
+#include "warpsense/cuda/device_map_wrapper.h"
+#include "warpsense/cuda/registration.h"
+#include "warpsense/cuda/update_tsdf.h"
+
+#if defined(CALLSITES_EXPECT_REFERENCE_TYPES) && !defined(WARPSENSE_HIP_USE_REFERENCE_TYPES)
+#error "with the reference's include directory on the path the forwarding headers must pick the reference's own math types"
+#endif
 
 struct Vec3iLike // what Eigen::Vector3i offers to device_map.h:42-48
 {

@@ -1,7 +1,10 @@
 """The drop-in boundary compiles the reference's own call sites: tests/cpp/callsites.cpp holds the
 statements of tsdf_mapping.cpp:114,141, app.cpp:218, featsense/mapping.cpp:187, pcd2tsdf.cpp:117 verbatim in meaning and
-is compiled against include/warpsense_hip/compat.hpp, once with compat.hpp's own POD math types and once with the
-reference's math headers (-DWARPSENSE_HIP_USE_REFERENCE_TYPES, only where /root/reference exists)."""
+is compiled through the forwarding headers this repo ships under the reference's own names
+(include/warpsense/cuda/{update_tsdf,registration,device_map,device_map_wrapper,cleanup}.h -> warpsense_hip/compat.hpp), once
+with compat.hpp's own POD math types (only -I<repo>/include) and once exactly as INTEGRATION.md says a maintainer builds:
+-I<repo>/include AHEAD of -I<reference>/include, so the names resolve to the forwarding headers and the rmagine:: math types
+and TSDFEntry are the reference's own (only where /root/reference exists)."""
 import os
 import shutil
 import subprocess
@@ -29,7 +32,14 @@ def test_callsites_compile_with_own_types():
 
 @pytest.mark.skipif(not os.path.isdir(REF_INC), reason="reference tree not present on this box")
 def test_callsites_compile_with_reference_math_types():
-    _compile(["-DWARPSENSE_HIP_USE_REFERENCE_TYPES", f"-I{REF_INC}"])
+    _compile([f"-I{REF_INC}", "-DCALLSITES_EXPECT_REFERENCE_TYPES"])
+
+
+def test_forwarding_headers_exist_for_every_device_header_the_callers_include():
+    for name in ("update_tsdf", "registration", "device_map", "device_map_wrapper", "cleanup"):
+        path = os.path.join(ROOT, "include", "warpsense", "cuda", name + ".h")
+        text = open(path).read()
+        assert '#include "warpsense_hip/compat.hpp"' in text and "#pragma once" in text
 
 
 def test_buffer_bounds_follow_the_reference_size_t_semantics(tmp_path):

@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _free_host_gb():
-    try:
-        import psutil
-        return psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        return 0.0
+    """MemAvailable of /proc/meminfo (no third-party module: a missing psutil must not turn these tests into skips)"""
+    with open("/proc/meminfo") as f:
+        for line in f:
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    raise RuntimeError("/proc/meminfo has no MemAvailable line")
 
 
 def _free_gpu_gb():
@@ -55,13 +56,17 @@ def test_config2_stream_on_the_1025_sliding_map():
     for got, want in zip(app.poses, want_poses):
         assert np.linalg.norm(got[:3, 3] - want[:3, 3]) / 1000.0 < 1e-4
         assert R._angle(got[:3, :3], want[:3, :3]) < 1e-4
-    if all(np.array_equal(g, w) for g, w in zip(app.poses, want_poses)):
-        lm = app.hdf5_local_map_
-        host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
-        app.gpu_.tsdf().avg_map().to_host(host)
-        assert list(host.pos_) == list(om.pos) and list(host.offset_) == list(om.offset)
-        assert np.array_equal(host.data_, om.data)
-        assert int(np.count_nonzero(host.data_ != O.pack(tau, 0))) > 5_000_000
+    # the poses are bit-identical to the oracle's (device Gauss-Newton == wso_gn_update, tools/soak_reg.py), so both
+    # sequences integrate the same scans at the same integer poses and the final windows must agree voxel for voxel.
+    # Hard assertions: a one-ulp pose difference must fail here, not quietly skip the 1.08 G-voxel comparison.
+    for k, (got, want) in enumerate(zip(app.poses, want_poses)):
+        assert np.array_equal(got, want), (k, np.abs(got - want).max())
+    lm = app.hdf5_local_map_
+    host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+    app.gpu_.tsdf().avg_map().to_host(host)
+    assert list(host.pos_) == list(om.pos) and list(host.offset_) == list(om.offset)
+    assert np.array_equal(host.data_, om.data)
+    assert int(np.count_nonzero(host.data_ != O.pack(tau, 0))) > 5_000_000
     st = app.gpu_.tsdf().stats()
     assert st["error_flags"] == 0
 

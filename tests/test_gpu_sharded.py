@@ -1,0 +1,197 @@
+"""SURVEY §8e on real kernels: the point-sharded registration's HIP entry points on PARTIAL ranges (first > 0, count < N).
+
+One GPU is enough to run what G ranks would run: every "rank" is its own ws_reg handle (own Gauss-Newton state, own 44-word
+buffer) holding the whole prepared cloud and accumulating only its range [r*N/G, (r+1)*N/G); the test plays the all-reduce
+(adds the G partials on the host, writes the total back into every rank's buffer) and compares, iteration by iteration,
+with the oracle's loop (registration.cu:347-368 x tsdf_registration.cpp:55-92).  A second test runs the real driver
+(warpsense_amd.dist.sharded_register_cloud, the `iterate` route) in two processes that share cuda:0 and all-reduce over gloo.
+"""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from warpsense_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rings=32, az=256):
+    import test_gpu_registration as R
+    reg, oa, pts, res = R.build_scene(rings=rings, az=az)
+    q = S.transform_points_mm(pts, S.perturbation(30, -22, 7, 1.4))
+    return reg, oa, q, res
+
+
+class _OracleLoop:
+    """the oracle's Gauss-Newton loop, one step at a time (wso_gn_begin / wso_reg_iterate / wso_gn_update)"""
+
+    def __init__(self, omap, points, res, T_in, max_iterations, it_weight_gradient, epsilon):
+        from test_abi_and_host import OracleGnBackend
+        self.b = OracleGnBackend(omap, points, res)
+        self.b.begin(T_in, max_iterations, it_weight_gradient, epsilon)
+        self.n = points.shape[0]
+
+    def finished(self):
+        return self.b.poll()[0]
+
+    def sums(self):
+        return self.b.accumulate(0, self.n).numpy().copy()
+
+    def update(self, sums):
+        import torch
+        self.b.solve(torch.from_numpy(np.ascontiguousarray(sums, dtype=np.int64)))
+
+    def result(self):
+        return self.b.poll()
+
+
+@pytest.mark.parametrize("route", ["iterate", "accumulate"])
+@pytest.mark.parametrize("world,drop", [(2, 1), (3, 0), (3, 2), (8, 5)])
+def test_hip_shard_ranges_sum_to_the_whole(world, drop, route):
+    """G in {2, 3, 8} ranges (ragged: N is not a multiple of G) through ws_reg_iterate_shard_dev (one launch per iteration,
+    the update of iteration i at the head of launch i + 1) and through ws_reg_accumulate_dev + ws_reg_solve_dev: the sum of
+    the ranks' 44 words == the oracle's h, g, e, c in EVERY iteration, and every rank ends with the oracle's iteration count
+    and a bit-identical pose."""
+    import torch
+    import warpsense_amd as W
+    from warpsense_amd.dist import HipGnBackend, shard_range
+    reg, oa, q, res = _scene()
+    if drop:
+        q = np.ascontiguousarray(q[:-drop])
+    n = q.shape[0]
+    assert drop == 0 or n % world != 0
+    T0 = np.eye(4, dtype=np.float32)
+    args = (200, 0.1, 0.03)
+    ranks = []
+    for r in range(world):
+        rc = W.RegistrationCuda(ctx=reg.tsdf().ctx)
+        rc.prepare_registration(q)  # every rank holds the whole cloud and works on its range
+        ranks.append(HipGnBackend(rc, reg.tsdf(), res))
+    spans = [shard_range(n, r, world) for r in range(world)]
+    assert spans[-1][0] > 0 and all(c < n for _, c in spans)
+    for b in ranks:
+        b.begin(T0, *args)
+    oracle = _OracleLoop(oa, q, res, T0, *args)
+    its = 0
+    while not oracle.finished():
+        want = oracle.sums()
+        parts = []
+        for b, (first, count) in zip(ranks, spans):
+            s = b.iterate(first, count) if route == "iterate" else b.accumulate(first, count)
+            parts.append(s.cpu().numpy().copy())
+        total = np.sum(parts, axis=0, dtype=np.int64)
+        assert np.array_equal(total, want), (its, np.nonzero(total != want)[0])
+        assert total[43] > 1000 and all(p[43] > 0 for p in parts)  # every range contributes correspondences
+        tt = torch.from_numpy(total)
+        for b in ranks:
+            b.sums.copy_(tt)  # the all-reduce
+            if route == "accumulate":
+                b.solve(b.sums)
+        oracle.update(total)
+        its += 1
+    if route == "iterate":
+        for b in ranks:
+            b.solve(b.sums)  # the last update of the loop (what sharded_register_cloud does at the end of a batch)
+    fin_o, it_o, T_o = oracle.result()
+    assert fin_o and it_o == its > 5
+    for b in ranks:
+        fin, it, T = b.poll()
+        assert fin and it == it_o
+        assert np.array_equal(T, T_o), np.abs(T - T_o).max()
+    # and the same loop on one rank / one launch for everything: the resident kernel
+    reg.reg_.prepare_registration(q)
+    T1, it1 = reg.reg_.register_cloud(reg.tsdf().device_map(), T0, *args, res)
+    assert it1 == it_o and np.array_equal(T1, T_o)
+    for b in ranks:
+        b.reg.close()
+
+
+def test_shard_launch_after_convergence_changes_nothing():
+    """launches enqueued past convergence (a replayed batch does that) neither move the state nor touch the sums"""
+    import warpsense_amd as W
+    from warpsense_amd.dist import HipGnBackend, sharded_register_cloud
+    reg, oa, q, res = _scene()
+    reg.reg_.prepare_registration(q)
+    b = HipGnBackend(reg.reg_, reg.tsdf(), res)
+    T, it = sharded_register_cloud(b, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, batch=16)
+    sums = b.sums.cpu().numpy().copy()
+    for _ in range(3):
+        b.iterate(0, len(q))
+    fin, it2, T2 = b.poll()
+    assert fin and it2 == it and np.array_equal(T2, T)
+    assert np.array_equal(b.sums.cpu().numpy(), sums)
+    T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+    assert it == it_o and np.array_equal(T, T_o.astype(np.float32))
+
+
+def test_sharded_driver_with_hip_graphs_is_exact_or_falls_back():
+    """the opt-in HIP-graph route of the driver: a captured batch of shard launches replays from whatever state the single
+    state buffer holds (no host-side parity baked in); it validates itself against the same launches on a stream and falls
+    back to them if the runtime replays differently -- either way the result is the oracle's"""
+    from warpsense_amd.dist import HipGnBackend, sharded_register_cloud
+    reg, oa, q, res = _scene()
+    reg.reg_.prepare_registration(q)
+    b = HipGnBackend(reg.reg_, reg.tsdf(), res)
+    graphs = {}
+    T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+    for _ in range(3):
+        T, it = sharded_register_cloud(b, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, batch=16, graphs=graphs)
+        assert it == it_o and np.array_equal(T, T_o.astype(np.float32))
+    runner = next(iter(graphs.values()))
+    print("HIP graph route in use:", runner.graph is not None)
+
+
+def _two_rank_worker(rank, world, port, q_out, drop):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)  # both ranks on the one GPU of the box
+        from warpsense_amd.dist import HipGnBackend, shard_range, sharded_register_cloud
+        reg, oa, q, res = _scene()
+        if drop:
+            q = np.ascontiguousarray(q[:-drop])
+        reg.reg_.prepare_registration(q)
+        backend = HipGnBackend(reg.reg_, reg.tsdf(), res)
+        first, count = shard_range(len(q), rank, world)
+        T, it = sharded_register_cloud(backend, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03, batch=7)
+        T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+        q_out.put((rank, first, count, it, it_o, bool(np.array_equal(T, T_o.astype(np.float32))), float(np.abs(T - T_o).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("drop", [0, 1])
+def test_sharded_register_cloud_two_processes_on_one_gpu(drop):
+    """world = 2: two processes, both on cuda:0, each with its own context, map and ws_reg; sharded_register_cloud's
+    one-launch-per-iteration route (HipGnBackend.iterate -> ws_reg_iterate_shard_dev with first > 0 on rank 1) with the
+    44 words all-reduced over gloo.  Both ranks must end with the oracle's iteration count and pose, bit for bit."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q_out, drop)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    got = sorted(q_out.get(timeout=10) for _ in range(2))
+    assert got[0][1] == 0 and got[1][1] == got[0][2] > 0  # rank 1 starts behind rank 0's range
+    for rank, first, count, it, it_o, same, err in got:
+        assert it == it_o > 5, (rank, it, it_o)
+        assert same, (rank, err)

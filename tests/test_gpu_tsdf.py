@@ -307,33 +307,28 @@ def test_room_larger_than_the_window_with_ring_seam():
     assert int((W_entry_weight(oa.data) < 0).sum()) > 1000
 
 
-def test_capacity_overflow_is_sticky_and_buffers_grow():
-    """A scan that needs more candidate records than the buffers hold cannot be exact.  update_tsdf only enqueues, so the
-    error comes back from the next call that synchronises (ws_sync here) — once — and the buffers have grown before the
-    next scan, which is exact again."""
+def test_record_buffers_are_sized_by_the_scan_itself():
+    """The record buffers never rest on a guess: every scan reports the slots it can need from its set-up pass and
+    the host grows the buffers BEFORE the tail march is enqueued.  A reservation far too small for the scan, and a small
+    scan followed by one that needs ~60x more (a door opens: every step beyond ~3.3 m at 20 mm carries a fan), are both
+    exact, with no error to report afterwards."""
     torch = _torch()
-    import warpsense_amd as W
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
     lm, t, oa, on = make_pair(size, tau, res, mw)
-    t.set_capacity(1 << 20)  # 1 Mi records; this scan reserves ~10 Mi
-    pts = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
-    d = torch.from_numpy(pts).cuda()
-    t.update_tsdf(d, (6, -4, 2), (0, 0, 32768))  # returns WS_OK: nothing is known yet
-    with pytest.raises(W.WsError, match="capacity"):
-        t.ctx.sync()
-    t.ctx.sync()  # reported once
-    st = t.stats()
-    assert st["status"] == 0 and st["record_capacity"] == 1 << 20
-    # start over on a fresh pair of maps: the library has seen what this kind of scan needs
-    blank = W.LocalMap(*size, tau, 0)
-    t.avg_map().to_device(blank.device_map())
-    t.new_map().to_device(blank.device_map())
-    t.update_tsdf(d, (6, -4, 2), (0, 0, 32768))
-    t.ctx.sync()
-    st = t.stats()
-    assert st["error_flags"] == 0 and st["record_capacity"] > st["record_slots"] > 1 << 20
-    O.update_tsdf(oa, on, pts, (6, -4, 2), (0, 0, 32768), tau, mw, res)
-    assert np.array_equal(download(t, lm, 0), oa.data)
+    t.set_capacity(1 << 20)  # 1 Mi records; the second scan reserves ~10 Mi
+    near = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=32, azimuths=256, half_extents_mm=(900.0, 800.0, 500.0), seed=10)
+    far = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    slots = []
+    for pts in (near, far, near):
+        t.update_tsdf(torch.from_numpy(pts).cuda(), (6, -4, 2), (0, 0, 32768))
+        t.ctx.sync()  # would raise a sticky capacity error
+        st = t.stats()
+        assert st["status"] == 0 and st["error_flags"] == 0 and st["record_capacity"] >= st["record_slots"]
+        slots.append(st["record_slots"])
+        O.update_tsdf(oa, on, pts, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+        assert np.array_equal(download(t, lm, 0), oa.data)
+    assert slots[0] < 1 << 20 < slots[1] and slots[1] > 20 * slots[0]
+    assert t.stats()["record_capacity"] > 1 << 20
 
 
 def test_ray_beyond_the_key_range_is_reported():

@@ -178,9 +178,11 @@ def _check_against(get_index, in_bounds, in_pos, in_neg, l2i, l2l, cross, ray_se
     nan = wrapped < 0
     assert nan.sum() > 0 and np.all(g["l2_i"][nan] == -2 ** 31) and np.all(got[nan] == 0)
     assert np.array_equal(got[~nan], g["l2_i"][~nan])
+    # 64-bit: CUDA's cvt.rzi.s64.f32 (__float2ll_rz) gives 0x8000000000000000 for NaN -- the value x86 gives too, so the
+    # golden of the host-built header holds for every vector, the wrapped ones included
     got_l = np.array([L.wso_l2norm_l(int(a), int(b), int(c)) for a, b, c in g["l2l_in"]])
-    nan_l = g["l2_l"] == -2 ** 63
-    assert np.all(got_l[nan_l] == 0) and np.array_equal(got_l[~nan_l], g["l2_l"][~nan_l])
+    assert (g["l2_l"] == -2 ** 63).sum() > 0
+    assert np.array_equal(got_l, g["l2_l"])
     out = np.zeros(3, dtype=np.int32)
     for a, b, want in zip(g["cross_a"], g["cross_b"], g["cross_out"]):
         L.wso_cross_i(O._p(np.ascontiguousarray(a)), O._p(np.ascontiguousarray(b)), O._p(out))

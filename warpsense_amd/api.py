@@ -830,7 +830,19 @@ class TSDFMapping:
                             sa, sb = np.maximum(a, base), np.minimum(b, base + cs - 1)
                             avg.insert_box(sa, sb, lm.map_.load_box(sa, sb))
 
+        self._shift_error = None
+
         def file_slabs():
+            # the ticket is closed whatever happens, and a failure travels to wait_shift() (a daemon thread's traceback
+            # would be the only trace of slabs that never reached the global map)
+            try:
+                file_slabs_body()
+            except BaseException as exc:  # noqa: BLE001 - re-raised by wait_shift()
+                self._shift_error = exc
+            finally:
+                L.ws_shift_end(ticket)
+
+        def file_slabs_body():
             check(L.ws_shift_wait(ticket), "ws_shift_wait")
             slo, shi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
             elo, ehi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
@@ -851,7 +863,6 @@ class TSDFMapping:
                         sl = tuple(slice(int(a[k] - slo[k]), int(b[k] - slo[k]) + 1) for k in range(3))
                         box[sl] = lm.map_.load_box(a, b).reshape(int(e[0]), int(e[1]), int(e[2]))
                 lm.map_.save_box(slo.copy(), shi.copy(), buf)
-            L.ws_shift_end(ticket)
 
         self._shift_worker = threading.Thread(target=file_slabs, name="warpsense-map-shift", daemon=True)
         self._shift_worker.start()
@@ -869,6 +880,9 @@ class TSDFMapping:
         if w is not None:
             w.join()
             self._shift_worker = None
+            err, self._shift_error = getattr(self, "_shift_error", None), None
+            if err is not None:
+                raise WsError(f"asynchronous map shift: the leaving slabs were not filed into the global map ({err!r})") from err
 
     def write_back(self, box_lo=None, box_hi=None):
         """HDF5LocalMap::write_back + HDF5GlobalMap::write_back (hdf5_local_map.cpp:210-217, app.cpp:220) from the

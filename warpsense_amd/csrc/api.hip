@@ -192,7 +192,8 @@ static int map_alloc_records(ws_map *m, uint64_t records)
   if (records < (1u << 20)) records = 1u << 20;
   if (records > 0xfffffff0ull) records = 0xfffffff0ull;
   map_free_records(m);
-  uint64_t descs = records / 8; // a run holds ~100 records on LiDAR scans; 8 leaves room for scattered clouds
+  uint64_t descs = records / 8 * m->desc_scale; // a run holds ~100 records on LiDAR scans; 8 leaves room for scattered clouds
+  if (descs > records) descs = records;          // (one run per record is the most there can be)
   if (descs < (1u << 18)) descs = 1u << 18;
   WS_HIP(hipMalloc((void **)&m->rec_raw, (size_t)records * sizeof(CandRecord)));
   WS_HIP(hipMalloc((void **)&m->rec_sorted, (size_t)records * sizeof(CandRecord)));
@@ -253,8 +254,9 @@ static int map_take_error(ws_map *m)
   }
   if (bits & 1u)
   {
-    set_error("TSDF update: candidate-record capacity exceeded, a TSDF update since the last check is not exact "
-              "(the buffers grow before the next scan; ws_tsdf_set_capacity reserves them up front)");
+    m->grow_aux = true;
+    set_error("TSDF update: run-descriptor / free-space-hash capacity exceeded, a TSDF update since the last check is not exact "
+              "(both are doubled before the next scan)");
     return WS_ERR_CAPACITY;
   }
   set_error("TSDF update: a ray needs more than 65536 steps or 256 fan steps (outside the order-key range) and was dropped");
@@ -466,7 +468,7 @@ int ws_map_extract_box(ws_map *m, int which, const int32_t lo[3], const int32_t 
   size_t n = 0;
   int rc = box_check(m, which, lo, hi, ext, &n);
   if (rc != WS_OK) return rc;
-  rc = launch_box_copy(m, which, lo, ext, m->box_stage, true, m->ctx->stream);
+  rc = launch_box_copy(m, m->par[which], which, lo, ext, m->box_stage, true, m->ctx->stream);
   if (rc != WS_OK) return rc;
   WS_HIP(hipMemcpyAsync(host_out, m->box_stage, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -481,7 +483,7 @@ int ws_map_insert_box(ws_map *m, int which, const int32_t lo[3], const int32_t h
   int rc = box_check(m, which, lo, hi, ext, &n);
   if (rc != WS_OK) return rc;
   WS_HIP(hipMemcpyAsync(m->box_stage, host_in, n * sizeof(uint32_t), hipMemcpyHostToDevice, m->ctx->stream));
-  rc = launch_box_copy(m, which, lo, ext, m->box_stage, false, m->ctx->stream);
+  rc = launch_box_copy(m, m->par[which], which, lo, ext, m->box_stage, false, m->ctx->stream);
   if (rc != WS_OK) return rc;
   WS_HIP(hipStreamSynchronize(m->ctx->stream)); // the host buffer may be reused by the caller
   if (which == WS_MAP_NEW) m->new_is_default = false;
@@ -518,6 +520,9 @@ int ws_shift_begin(ws_map *m, const int32_t new_pos[3], uint32_t fill_entry, ws_
 {
   if (!m || !new_pos || !out) return invalid("ws_shift_begin: NULL argument");
   if (m->shift_open) return invalid("ws_shift_begin: the previous shift of this map has not been ended (ws_shift_end)");
+  // only new_map's WINDOW moves here, which is right iff it holds (tau, 0) everywhere -- not between ws_tsdf_scatter_dev and
+  // ws_tsdf_integrate, nor for a map created from non-default host data that has not been integrated yet
+  if (!m->new_is_default) return invalid("ws_shift_begin: new_map holds entries that have not been integrated (ws_tsdf_integrate first)");
   const MapParams &p0 = m->par[WS_MAP_AVG];
   ws_shift *sh = new (std::nothrow) ws_shift();
   if (!sh) return invalid("ws_shift_begin: out of host memory");
@@ -574,24 +579,27 @@ int ws_shift_begin(ws_map *m, const int32_t new_pos[3], uint32_t fill_entry, ws_
       return rc0;
     }
   }
-  // execute the plan on the map's stream
+  // execute the plan on the map's stream.  The window moves in a COPY of the parameters (the box kernels take them by
+  // value) and is committed only when every launch and copy has been enqueued: a HIP error half-way leaves the host's
+  // view of both maps as it was.
   int rc = WS_OK;
+  MapParams par[2] = {m->par[0], m->par[1]};
   for (int i = 0, axis = 0; i < sh->n && rc == WS_OK; ++i, ++axis)
   {
-    while (new_pos[axis] == m->par[WS_MAP_AVG].pos[axis]) ++axis; // the axis slab i belongs to
+    while (new_pos[axis] == par[WS_MAP_AVG].pos[axis]) ++axis; // the axis slab i belongs to
     int32_t ext[3];
     for (int k = 0; k < 3; ++k) ext[k] = sh->leave_hi[i][k] - sh->leave_lo[i][k] + 1;
-    rc = launch_box_copy(m, WS_MAP_AVG, sh->leave_lo[i], ext, m->shift_stage_dev + sh->offset[i], true, s);
-    const int32_t d = new_pos[axis] - m->par[WS_MAP_AVG].pos[axis];
+    rc = launch_box_copy(m, par[WS_MAP_AVG], WS_MAP_AVG, sh->leave_lo[i], ext, m->shift_stage_dev + sh->offset[i], true, s);
+    const int32_t d = new_pos[axis] - par[WS_MAP_AVG].pos[axis];
     for (int w = 0; w < 2; ++w)
     {
-      MapParams &p = m->par[w];
+      MapParams &p = par[w];
       p.pos[axis] += d;
       p.offset[axis] = (int32_t)((((int64_t)p.offset[axis] + d) % p.size[axis] + p.size[axis]) % p.size[axis]);
     }
     for (int k = 0; k < 3; ++k) ext[k] = sh->enter_hi[i][k] - sh->enter_lo[i][k] + 1;
-    if (rc == WS_OK) rc = launch_box_fill(m, WS_MAP_AVG, sh->enter_lo[i], ext, fill_entry, s);
-    // new_map is (tau, 0) everywhere between updates: only its window moves (DeviceMapMemWrapper::update_params)
+    if (rc == WS_OK) rc = launch_box_fill(m, par[WS_MAP_AVG], WS_MAP_AVG, sh->enter_lo[i], ext, fill_entry, s);
+    // new_map is (tau, 0) everywhere between updates (checked above): only its window moves (DeviceMapMemWrapper::update_params)
   }
   if (rc == WS_OK && total)
   {
@@ -605,6 +613,8 @@ int ws_shift_begin(ws_map *m, const int32_t new_pos[3], uint32_t fill_entry, ws_
     delete sh;
     return rc;
   }
+  m->par[0] = par[0];
+  m->par[1] = par[1];
   m->shift_open = sh;
   *out = sh;
   return WS_OK;
@@ -675,19 +685,32 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  m->capacity_known = true; // the caller decides: no sizing synchronisation on the first scan
   return map_alloc_records(m, records);
 }
 
-// the previous scan left the sum of its per-ray record upper bounds in host-mapped memory: grow the record buffers
-// before a scan that would not fit (a hint read without synchronisation; the first scan of a kind may still overflow,
-// which is reported as WS_ERR_CAPACITY by the next synchronising call)
-static int grow_for_next_scan(ws_map *m)
+// A scan that overflowed the run descriptors or the free-space hash (WS_ERR_CAPACITY, reported by the first call that
+// synchronised afterwards) doubles both before the next scan.  The RECORD buffers never overflow: every scan sizes them
+// itself (launch_tsdf_scatter waits for the bound its set-up pass computes).
+static int grow_aux_for_next_scan(ws_map *m)
 {
-  const uint64_t need = *reinterpret_cast<volatile uint64_t *>(m->status_host + 2);
-  if (need + need / 4 <= m->rec_cap) return WS_OK;
+  if (!m->grow_aux) return WS_OK;
+  m->grow_aux = false;
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  return map_alloc_records(m, need + need / 2);
+  m->desc_scale *= 2;
+  int rc = map_alloc_records(m, m->rec_cap);
+  if (rc != WS_OK) return rc;
+  if (m->fk_slots < (1u << 28))
+  {
+    unsigned long long *fk = nullptr;
+    const uint32_t slots = m->fk_slots * 2;
+    WS_HIP(hipMalloc((void **)&fk, (size_t)slots * 2 * sizeof(unsigned long long) + slots / 8));
+    (void)hipFree(m->fk_keys);
+    m->fk_keys = fk;
+    m->fk_vals = fk + slots;
+    m->fk_slots = slots;
+    m->prepped = false; // the new hash is filled by the stand-alone preparation pass
+  }
+  return WS_OK;
 }
 
 static int too_many_points(size_t n)
@@ -703,7 +726,7 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
-  int rc = grow_for_next_scan(m);
+  int rc = grow_aux_for_next_scan(m);
   if (rc != WS_OK) return rc;
   rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
   if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
@@ -720,7 +743,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_update_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
-  int rc = grow_for_next_scan(m);
+  int rc = grow_aux_for_next_scan(m);
   if (rc != WS_OK) return rc;
   // with the default (sparse) integrate the tile resolve folds cu_avg_tsdf_krnl into its write-back (new_map stays
   // (tau, 0)); a non-default new_map is resolved on top of its entries and integrated by the dense pass
@@ -1181,5 +1204,9 @@ int ws_prof_reset(ws_context *ctx)
 
 namespace ws
 {
-int resize_records(ws_map *m, uint64_t records) { return map_alloc_records(m, records); }
+int resize_records(ws_map *m, uint64_t records)
+{
+  WS_HIP(hipStreamSynchronize(m->ctx->stream)); // nothing enqueued may still use the old buffers
+  return map_alloc_records(m, records);
+}
 } // namespace ws

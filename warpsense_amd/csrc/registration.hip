@@ -1126,14 +1126,15 @@ __global__ __launch_bounds__(64) void reg_solve_kernel(GnState *state, const int
 // ---- one launch per iteration of the point-sharded (multi-GPU) path -------------------------------------------------
 // [apply the Gauss-Newton update from the all-reduced sums of the previous iteration] -> accumulate this rank's shard ->
 // the 44 sums, in ONE kernel instead of reg_solve + reg_accumulate + reg_sum: every workgroup repeats the (cheap) update
-// from the same sums, like the resident loop does, and the last workgroup to deliver its partials adds them up (an
-// arrival counter, agent-scope accesses as everywhere on this path: no cache-wide fences).  The state is double buffered
-// (workgroup 0 writes the updated state while the others may still be reading the old one).
+// from the same sums, like the resident loop does, and the last workgroup to arrive (an arrival counter, agent-scope
+// accesses as everywhere on this path: no cache-wide fences) adds the partials up AND writes the updated state.
+// ONE state buffer, read by every workgroup before it arrives and written by the last one after all have arrived: the
+// launch bakes in no buffer parity, so a batch of these launches captured into a HIP graph replays from whatever state
+// the buffer holds (a host-side parity flip per launch made every replay restart from a stale buffer).
 struct ShardArgs
 {
   PointArgs pts;          // first / end: this rank's shard
-  const GnState *state_in;
-  GnState *state_out;     // written when `apply` (by workgroup 0)
+  GnState *state;         // in: the state before this launch; out (if apply): the state after the update
   int64_t *sums;          // in: the all-reduced sums of the previous iteration (if apply); out: this rank's 44 sums
   int64_t *partials;      // [REG_BLOCKS][REG_SLOTS]
   uint32_t *arrived;      // zero between launches
@@ -1148,12 +1149,12 @@ __global__ __launch_bounds__(REG_THREADS) void reg_shard_kernel(ShardArgs a)
   __shared__ float T_sh[16];
   __shared__ int stop_sh, last_sh;
   const Prefetched pref = prefetch_points(a.pts);
+  GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64)
   {
-    GnCore st;
     {
       int32_t *w = reinterpret_cast<int32_t *>(&st);
-      const int32_t *src = reinterpret_cast<const int32_t *>(&a.state_in->core);
+      const int32_t *src = reinterpret_cast<const int32_t *>(&a.state->core);
 #pragma unroll
       for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) w[i] = coherent_i32(&src[i]);
     }
@@ -1164,17 +1165,6 @@ __global__ __launch_bounds__(REG_THREADS) void reg_shard_kernel(ShardArgs a)
       __builtin_amdgcn_wave_barrier();
       gn_update(
           st, [&](int r, int c) { return s44[c * 6 + r]; }, [&](int r) { return s44[36 + r]; }, (int32_t)s44[42], (int32_t)s44[43]);
-      if (blockIdx.x == 0 && threadIdx.x == 0)
-      {
-        const int32_t *w = reinterpret_cast<const int32_t *>(&st);
-        int32_t *dst = reinterpret_cast<int32_t *>(&a.state_out->core);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) __hip_atomic_store(&dst[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < 42; ++k) publish_i64(&a.state_out->sums[k], s44[k]);
-        publish_i64(&a.state_out->sums[42], (int64_t)(int32_t)s44[42]);
-        publish_i64(&a.state_out->sums[43], (int64_t)(int32_t)s44[43]);
-      }
     }
     if (threadIdx.x == 0)
     {
@@ -1184,31 +1174,51 @@ __global__ __launch_bounds__(REG_THREADS) void reg_shard_kernel(ShardArgs a)
     }
   }
   __syncthreads();
-  if (stop_sh) return; // every workgroup alike: nobody arrives, the sums stay as they are
-  float T[16];
+  const bool stop = stop_sh != 0; // every workgroup alike
+  if (!stop)
+  {
+    float T[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
-  int64_t acc[REG_SLOTS];
+    for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+    int64_t acc[REG_SLOTS];
 #pragma unroll
-  for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-  accumulate_points(a.pts, T, pref, acc);
-  block_reduce32(acc, wave_part, red);
-  if (threadIdx.x < REG_SLOTS) publish_i64(&a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x]);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above have been acknowledged ...
-  __syncthreads();                                  // ... for all 32 lanes that made them
+    for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+    accumulate_points(a.pts, T, pref, acc);
+    block_reduce32(acc, wave_part, red);
+    if (threadIdx.x < REG_SLOTS) publish_i64(&a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above have been acknowledged ...
+  }
+  else if (!a.apply)
+    return; // the loop was over before this launch: nothing to update, nothing to add (the sums stay as they are)
+  __syncthreads(); // ... for all 32 lanes that made them
   if (threadIdx.x == 0)
     last_sh = __hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
   __syncthreads();
   if (!last_sh) return;
-  sum_partials<true>(a.partials, wave_part, red);
-  if (threadIdx.x == 0)
+  // everybody has read the state and the all-reduced sums: both may change now
+  if (a.apply && threadIdx.x == 0)
   {
-    int64_t sums[44];
-    expand_sums(red, sums);
+    const int32_t *w = reinterpret_cast<const int32_t *>(&st);
+    int32_t *dst = reinterpret_cast<int32_t *>(&a.state->core);
 #pragma unroll
-    for (int k = 0; k < 44; ++k) publish_i64(&a.sums[k], sums[k]);
-    __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < (int)(sizeof(GnCore) / 4); ++i) __hip_atomic_store(&dst[i], w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < 42; ++k) publish_i64(&a.state->sums[k], s44[k]);
+    publish_i64(&a.state->sums[42], (int64_t)(int32_t)s44[42]);
+    publish_i64(&a.state->sums[43], (int64_t)(int32_t)s44[43]);
   }
+  if (!stop)
+  {
+    sum_partials<true>(a.partials, wave_part, red);
+    if (threadIdx.x == 0)
+    {
+      int64_t sums[44];
+      expand_sums(red, sums);
+#pragma unroll
+      for (int k = 0; k < 44; ++k) publish_i64(&a.sums[k], sums[k]);
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // test entry: the wave solver alone, one wave per system (A row-major 6x6, b) -> x, status
@@ -1292,8 +1302,7 @@ int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, si
   ws_context *ctx = r->ctx;
   ShardArgs a;
   a.pts = make_point_args(r, m, res, flags, first, count);
-  a.state_in = &r->state[r->latest];
-  a.state_out = &r->state[r->latest ^ 1];
+  a.state = &r->state[r->latest]; // one buffer, no parity: see reg_shard_kernel
   a.sums = sums_dev;
   a.partials = r->partials;
   a.arrived = r->shard_arrived;
@@ -1302,7 +1311,6 @@ int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, si
   hipLaunchKernelGGL(reg_shard_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
-  if (apply) r->latest ^= 1;
   return WS_OK;
 }
 

@@ -28,6 +28,8 @@
 //
 // new_map after the resolve is bit-identical to what the reference kernel leaves there when its threads
 // run one after the other (oracle/ws_oracle.c: wso_update_min).
+#include <atomic>
+#include <chrono>
 #include <cstddef>
 
 #include "ws_march.h"
@@ -60,6 +62,7 @@ struct ScatterArgs
   CandRecord *rec_raw;
   CandRecord *rec_sorted;
   uint32_t rec_cap;
+  uint32_t scan_seq; // sequence number of this scatter (in the padding behind rec_cap: the arguments stay within 256 bytes)
   RunDesc *desc;
   uint32_t desc_cap;
   unsigned long long *fk_keys; // the values follow the keys (fk_keys + fk_mask + 1): one allocation, and the arguments stay within 256 bytes
@@ -67,7 +70,7 @@ struct ScatterArgs
   uint32_t fk_mask;
   uint32_t *tail_stats; // records per workgroup of the tail march
   TsdfCounters *counters;
-  uint32_t *status; // host-mapped: [0] sticky error bits
+  uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number
 };
 // 264 bytes of kernel arguments instead of 256 cost reg_loop_kernel 30 % (registration.hip); the same bound here
 static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of kernel arguments");
@@ -320,7 +323,9 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
     atomicAdd(&a.az_hist[bin], 1u);
     a.rays[ix] = r;
   }
-  // capacity hint for the next scan: one 64-bit add per workgroup
+  // The record slots this scan can need (sum of the per-ray bounds): one 64-bit add per workgroup; the last workgroup to
+  // get here hands the total to the host (host-mapped memory: value, then the sequence number the host spins on), which
+  // sizes the record buffers BEFORE it enqueues the tail march -- the capacity never rests on a guess.
   unsigned long long ub = r.ub;
   for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
   if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
@@ -328,7 +333,13 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
   if (threadIdx.x == 0)
   {
     const unsigned long long t = ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3];
-    if (t) atomicAdd(&a.counters->ub_total, t);
+    if (t) __hip_atomic_fetch_add(&a.counters->ub_total, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(&a.counters->setup_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+    {
+      const unsigned long long total = __hip_atomic_load(&a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1921,8 +1932,6 @@ __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, con
     c->last_listed = c->n_listed;
     c->last_runs = c->desc_cursor;
     c->last_slots = c->raw_cursor;
-    // capacity hint for the host (read without synchronisation before the next scan)
-    *reinterpret_cast<volatile unsigned long long *>(status + 2) = c->ub_total;
   }
   __syncthreads();
 #ifdef WS_TAIL_TIMING
@@ -2035,17 +2044,17 @@ __global__ __launch_bounds__(256) void box_copy_kernel(uint32_t *map_data, MapPa
   }
 }
 
-int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t s)
+int launch_box_copy(ws_map *m, const MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t s)
 {
   const int64_t n = (int64_t)ext[0] * ext[1] * ext[2];
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   if (pack)
-    hipLaunchKernelGGL((box_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2],
+    hipLaunchKernelGGL((box_copy_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], par, lo[0], lo[1], lo[2],
                        ext[0], ext[1], ext[2], box_dev);
   else
-    hipLaunchKernelGGL((box_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2],
+    hipLaunchKernelGGL((box_copy_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], par, lo[0], lo[1], lo[2],
                        ext[0], ext[1], ext[2], box_dev);
   WS_HIP(hipGetLastError());
   return WS_OK;
@@ -2065,13 +2074,13 @@ __global__ __launch_bounds__(256) void box_fill_kernel(uint32_t *map_data, MapPa
   }
 }
 
-int launch_box_fill(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t s)
+int launch_box_fill(ws_map *m, const MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t s)
 {
   const int64_t n = (int64_t)ext[0] * ext[1] * ext[2];
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(box_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], m->par[which], lo[0], lo[1], lo[2], ext[0], ext[1],
+  hipLaunchKernelGGL(box_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->data[which], par, lo[0], lo[1], lo[2], ext[0], ext[1],
                      ext[2], value);
   WS_HIP(hipGetLastError());
   return WS_OK;
@@ -2174,6 +2183,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.rec_raw = m->rec_raw;
   sa.rec_sorted = m->rec_sorted;
   sa.rec_cap = m->rec_cap;
+  sa.scan_seq = ++m->scan_seq;
   sa.desc = m->desc;
   sa.desc_cap = m->desc_cap;
   sa.fk_keys = m->fk_keys;
@@ -2200,18 +2210,37 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
   hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
   prof_end(ctx, WS_K_SETUP);
-  if (!m->capacity_known)
   {
-    // first scan of this map: nothing is known about what its scans need.  One synchronisation, once: read the sum of
-    // the per-ray record bounds the set-up pass has just computed and size the buffers for it.  Later scans use the
-    // previous scan's need as the hint (grow_for_next_scan), without waiting.
-    unsigned long long need = 0;
-    WS_HIP(hipMemcpyAsync(&need, &m->counters->ub_total, sizeof need, hipMemcpyDeviceToHost, s));
-    WS_HIP(hipStreamSynchronize(s));
-    m->capacity_known = true;
-    if (need + need / 8 > m->rec_cap)
+    // The set-up pass has counted the record slots this scan can need; its last workgroup writes the total and this
+    // scan's sequence number into host-mapped memory.  The host waits for that word -- ray_setup is the first kernel of
+    // the update, and the direction sort enqueued behind it runs meanwhile, so the stream does not drain -- and grows the
+    // buffers first if the scan does not fit.  (The reference's update_tsdf blocks on three cudaMemcpy at this point,
+    // update_tsdf.cu:152-154.)  A hint from the previous scan is not enough: a door that opens multiplies the need.
+    volatile uint32_t *st = m->status_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (st[6] != sa.scan_seq)
     {
-      const int rc = resize_records(m, need + need / 4);
+      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+      {
+        WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
+        if (st[6] != sa.scan_seq)
+        {
+          set_error("TSDF update: the set-up pass did not report its record bound");
+          return WS_ERR_INTERNAL;
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
+    if (need > m->rec_cap)
+    {
+      if (need > 0xfffffff0ull)
+      {
+        set_error("TSDF update: the scan needs more than 2^32 candidate records");
+        return WS_ERR_CAPACITY;
+      }
+      const int rc = resize_records(m, need + need / 8);
       if (rc != WS_OK) return rc;
       sa.rec_raw = m->rec_raw;
       sa.rec_sorted = m->rec_sorted;

@@ -84,12 +84,17 @@ __device__ __forceinline__ int32_t div_trunc(int32_t x, const FastDiv &f) { retu
 __device__ __forceinline__ int32_t l2norm_i(int32_t x, int32_t y, int32_t z)
 {
   int32_t sq = wadd(wadd(wmul(x, x), wmul(y, y)), wmul(z, z));
+  if (sq < 0) return 0; // NaN -> 0 like the reference's cvt.rzi.s32.f32 (and v_cvt_i32_f32); explicit: fptosi of NaN is poison to the compiler
   return (int32_t)sqrtf((float)sq);
 }
-// Vector3<long>::l2norm — same header, T = long
+// Vector3<long>::l2norm — same header, T = long.  A wrapped (negative) sum is NaN after sqrtf; the reference's CUDA code
+// converts it with cvt.rzi.s64.f32 (= __float2ll_rz), which gives 0x8000000000000000 for NaN (the 32-bit conversion
+// above gives 0, like v_cvt_i32_f32).  gfx950 has no f32 -> i64 instruction and the compiler's expansion is not
+// specified for NaN, so the case is decided here (oracle/ws_oracle.c:l2norm_l does the same).
 __device__ __forceinline__ int64_t l2norm_l(int64_t x, int64_t y, int64_t z)
 {
   int64_t sq = wadd64(wadd64(wmul64(x, x), wmul64(y, y)), wmul64(z, z));
+  if (sq < 0) return INT64_MIN;
   return (int64_t)sqrtf((float)sq);
 }
 

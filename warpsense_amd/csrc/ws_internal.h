@@ -82,7 +82,7 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
   uint32_t n_desc_sorted; // == desc_cursor once the tile scan has run
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
-  uint32_t pad0;
+  uint32_t setup_done;    // workgroups of ray_setup_kernel that have added their record bounds
   unsigned long long ub_total; // sum of the per-ray record upper bounds (capacity hint for the next scan)
   // statistics of the last update, filled by finish_update_kernel
   uint32_t last_records;
@@ -166,16 +166,18 @@ struct ws_map
   ws::RunDesc *desc = nullptr;
   uint32_t *sorted_desc = nullptr; // [desc_cap][2]: start, count
   uint32_t desc_cap = 0;
+  uint32_t desc_scale = 1;   // run descriptors per 8 records (doubled after a scan that ran out of them)
   // free-space candidates that hit a keyed voxel: voxel index -> earliest order key (open addressing)
   unsigned long long *fk_keys = nullptr, *fk_vals = nullptr;
   uint32_t fk_slots = 0;
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
   uint32_t tail_blocks = 0;        // workgroups of the last tail march
   bool fused_done = false;         // the last scatter already integrated into avg_map
-  bool capacity_known = false;     // a scan has told what the record buffers must hold
+  uint32_t scan_seq = 0;           // scatters launched on this map (ray_setup reports its record bound under this number)
+  bool grow_aux = false;           // a scan overflowed the run descriptors / the free-space hash: double them before the next
   ws::TsdfCounters *counters = nullptr;
   ws::TsdfCounters *counters_host = nullptr; // pinned
-  uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [2..3] capacity hint (u64)
+  uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [4..5] record bound of the scan in flight (u64), [6] its sequence number
   uint32_t *status_dev = nullptr;            // device view of status_host
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
@@ -268,9 +270,9 @@ int launch_scatter_prep(ws_map *m);
 int resize_records(ws_map *m, uint64_t records); // api.hip: (re)allocate the candidate-record buffers
 uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
-int launch_box_copy(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
+int launch_box_copy(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
-int launch_box_fill(ws_map *m, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t stream);
+int launch_box_fill(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t stream);
 int check_all_equal_host(const uint32_t *data, int64_t n, uint32_t value);
 
 int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null, int32_t res, uint32_t flags,

@@ -35,6 +35,9 @@ class HipGnBackend:
         import torch
         self.reg, self.tsdf, self.res, self.flags = reg, tsdf, int(map_resolution), int(flags)
         self._L = reg._L
+        # one stream for the library, torch and the hand-off to the collective: the 44 words are written by the library's
+        # kernels and read by the all-reduce (RCCL kernel or host copy) with nothing but stream order in between
+        reg.ctx.use_torch_stream()
         self.sums = torch.zeros(44, dtype=torch.int64, device="cuda")
         self._pending = False  # iterate(): sums of an iteration whose update has not been applied yet
 
@@ -79,6 +82,21 @@ class HipGnBackend:
         out = np.zeros(16, dtype=np.float32)
         check(self._L.ws_reg_poll(self.reg.handle, C.byref(fin), C.byref(it), out.ctypes.data_as(C.c_void_p)), "ws_reg_poll")
         return bool(fin.value), int(it.value), out.reshape(4, 4).T.copy()
+
+
+def all_reduce_sums(sums, group=None):
+    """Sum the 44 int64 words over the ranks of `group`, in place.  RCCL ("nccl") reduces the device tensor over xGMI;
+    a gloo group (the CPU tests, and two processes that share ONE GPU in the GPU tests) gets a host copy -- 352 bytes."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return sums
+    if sums.is_cuda and dist.get_backend(group) == "gloo":
+        host = sums.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        sums.copy_(host)
+        return sums
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
 
 
 class _GraphBatch:
@@ -133,14 +151,12 @@ class _GraphBatch:
             # one kernel + one all-reduce per iteration (the update of iteration i rides in the launch of iteration i + 1)
             for _ in range(n):
                 sums = backend.iterate(first, count)
-                if dist.is_initialized():
-                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+                all_reduce_sums(sums, group)
             backend.solve(sums)  # the last update of the batch, so that poll() sees the state after n iterations
             return
         for _ in range(n):
             sums = backend.accumulate(first, count)
-            if dist.is_initialized():
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sums(sums, group)
             backend.solve(sums)
 
     def run(self):
