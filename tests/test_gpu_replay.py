@@ -44,7 +44,17 @@ def oracle_replay(clouds, size, tau, mw, res, reg, shift_m):
             updates += 1
         T, it, _ = O.register_cloud(om, scan, np.eye(4), reg[0], reg[1], reg[2], res)
         T = T.astype(np.float32)
-        pose[:3, :3] = T[:3, :3] @ pose[:3, :3]
+        # app.cpp:172-176 in float32, products summed in index order -- spelled out: numpy's matmul goes through BLAS, whose
+        # summation order / FMA use is not specified (it differed from the index-order sum by one ulp on the GPU box, which
+        # the bit-exact pose assertion below caught once it stopped being a silent skip)
+        R = np.zeros((3, 3), dtype=np.float32)
+        for i in range(3):
+            for j in range(3):
+                acc = np.float32(0)
+                for k in range(3):
+                    acc = np.float32(acc + np.float32(T[i, k] * pose[k, j]))
+                R[i, j] = acc
+        pose[:3, :3] = R
         pose[:3, 3] += T[:3, 3]
         poses.append(pose.copy())
         its.append(it)

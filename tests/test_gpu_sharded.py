@@ -50,7 +50,7 @@ class _OracleLoop:
 
 
 @pytest.mark.parametrize("route", ["iterate", "accumulate"])
-@pytest.mark.parametrize("world,drop", [(2, 1), (3, 0), (3, 2), (8, 5)])
+@pytest.mark.parametrize("world,drop", [(2, 1), (3, 0), (3, 1), (8, 5)])
 def test_hip_shard_ranges_sum_to_the_whole(world, drop, route):
     """G in {2, 3, 8} ranges (ragged: N is not a multiple of G) through ws_reg_iterate_shard_dev (one launch per iteration,
     the update of iteration i at the head of launch i + 1) and through ws_reg_accumulate_dev + ws_reg_solve_dev: the sum of

@@ -316,7 +316,7 @@ def test_record_buffers_are_sized_by_the_scan_itself():
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
     lm, t, oa, on = make_pair(size, tau, res, mw)
     t.set_capacity(1 << 20)  # 1 Mi records; the second scan reserves ~10 Mi
-    near = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=32, azimuths=256, half_extents_mm=(900.0, 800.0, 500.0), seed=10)
+    near = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=16, azimuths=256, half_extents_mm=(900.0, 800.0, 500.0), seed=10)
     far = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
     slots = []
     for pts in (near, far, near):

@@ -99,8 +99,17 @@ class Context:
               "ws_ctx_set_stream")
 
     def use_torch_stream(self):
+        """Run the library's work on torch's CURRENT stream, so that torch operations (copies of the 44 sums, RCCL
+        collectives) and the library's kernels are ordered by the stream alone.  The C ABI takes a hipStream_t and reads
+        NULL as "the context's own stream", so torch's legacy default stream (handle 0) cannot be named there: in that case
+        a new stream is created and made torch's current stream (for this thread) first."""
         import torch
-        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream == 0:
+            cur = torch.cuda.Stream()
+            torch.cuda.set_stream(cur)
+        self._torch_stream = cur  # keep it alive
+        self.set_stream(cur.cuda_stream)
 
     def sync(self):
         check(self._L.ws_sync(self.handle), "ws_sync")
