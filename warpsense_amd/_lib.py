@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
+# WS_HIP_LIB: another build of the same library (A/B measurements of kernel variants on one box; tools/ab_bench.sh)
+LIB_PATH = os.environ.get("WS_HIP_LIB") or os.path.join(PKG_DIR, "libwarpsense_hip.so")
 
 WS_MAP_AVG, WS_MAP_NEW = 0, 1
 WS_INTEGRATE_SPARSE, WS_INTEGRATE_DENSE, WS_INTEGRATE_SPARSE_SEPARATE = 0, 1, 2

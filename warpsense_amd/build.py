@@ -50,14 +50,28 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
+def build_variant(name: str, extra_flags: str, verbose: bool = False) -> str:
+    """warpsense_amd/variants/<name>.so: the library built with extra compiler flags (kernel tuning switches), selected at
+    run time with WS_HIP_LIB=<path> -- several variants measured back to back on ONE box (the boxes differ by a few %)."""
+    out = os.path.join(PKG_DIR, "variants", name + ".so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    old = os.environ.get("WS_EXTRA_FLAGS", "")
+    os.environ["WS_EXTRA_FLAGS"] = (old + " " + extra_flags).strip()
+    try:
+        return build_native(force=True, verbose=verbose, lib_path=out, obj_dir=os.path.join(PKG_DIR, "build", "variant_" + name))
+    finally:
+        os.environ["WS_EXTRA_FLAGS"] = old
+
+
+def build_native(force: bool = False, verbose: bool = False, lib_path: str = LIB_PATH, obj_dir: str | None = None) -> str:
     if not force and not needs_build():
-        return LIB_PATH
+        return lib_path
     objs = []
     procs = []
-    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+    obj_dir = obj_dir or os.path.join(PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
     for s in SOURCES:
-        obj = os.path.join(PKG_DIR, "build", s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         cmd = [hipcc(), *flags(), "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -69,11 +83,11 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out.decode(errors="replace"))
         if verbose and out:
             print(out.decode(errors="replace"))
-    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    link = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib_path]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
-    return LIB_PATH
+    return lib_path
 
 
 def find_hdf5() -> tuple[str, str] | None:
@@ -115,5 +129,9 @@ def build_h5(force: bool = False, verbose: bool = False) -> str | None:
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m warpsense_amd.build --variant NAME "-DFLAG=1 ..."
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2] if len(sys.argv) > i + 2 else "", verbose=True))
+        sys.exit(0)
     print(build_native(force="--force" in sys.argv, verbose=True))
     print(build_h5(force="--force" in sys.argv, verbose=True) or "libwarpsense_h5.so: skipped (no HDF5 C library found)")

@@ -216,7 +216,7 @@ static int map_free(ws_map *m)
       break;
     }
   map_free_records(m);
-  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->az_cur, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nruns,
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nruns,
                   m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -333,8 +333,7 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->az_cur, AZ_ALLOC * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(m->az_cur, 0, AZ_ALLOC * sizeof(uint32_t), s));
+  TRY(hipMalloc((void **)&m->ray_bin, MAX_SCAN_POINTS * 2 * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->fan_steps, 256 * sizeof(int32_t)));
   ws::fill_fan_steps(m->fan_steps_host, m->res);
@@ -769,6 +768,10 @@ int ws_tsdf_update(ws_map *m, const int32_t *xyz_host, size_t n, const int32_t s
 int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
 {
   if (!m || !out) return invalid("ws_tsdf_stats: NULL argument");
+  {
+    const int rc0 = launch_tsdf_stats(m);
+    if (rc0 != WS_OK) return rc0;
+  }
   WS_HIP(hipMemcpyAsync(m->counters_host, m->counters, sizeof(TsdfCounters), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
   const TsdfCounters *c = m->counters_host;

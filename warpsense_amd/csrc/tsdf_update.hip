@@ -53,7 +53,7 @@ struct ScatterArgs
   RaySetup *rays;
   uint32_t *az_hist;   // [AZ_BINS + 1] rays per direction bin (last bin: rays that contribute nothing)
   uint32_t *az_off;    // [AZ_BINS]: number of rays that contribute (written by the direction sort)
-  uint32_t *az_cur;    // [AZ_BINS + 1] placement cursors of the direction sort (zero at the start of a scan)
+  uint2 *ray_bin;      // [n] (direction bin, rank inside the bin) of every ray: set-up blocks -> sort blocks of the same launch
   uint32_t *ray_order; // ray indices sorted by direction bin
   const int32_t *fan_steps; // [256], see tail_bound
   uint8_t *vstate;     // one byte per voxel: VOX_*
@@ -78,6 +78,15 @@ static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of k
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_FREEHIT = 4;
 constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
+#ifndef WS_FUSE_SETUP
+#define WS_FUSE_SETUP 0 // 1: ray set-up and direction sort in one launch (sort blocks wait for the set-up blocks)
+#endif
+#ifndef WS_SORT_BLOCKS
+#define WS_SORT_BLOCKS 64
+#endif
+#ifndef WS_FUSE_PLACE
+#define WS_FUSE_PLACE 1 // 1: tile scan and descriptor placement in one launch
+#endif
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
@@ -120,13 +129,12 @@ __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
 struct PrepArgs
 {
   TsdfCounters *counters;
-  uint32_t *az_hist, *az_cur;
+  uint32_t *az_hist;
   uint32_t n_hist;
   uint32_t *tile_nruns;
   int64_t n_tiles;
   unsigned long long *fk; // keys and values: one allocation
   int64_t n_fk;
-  uint32_t fk_all; // 1: fill the whole hash (first preparation of a map), 0: only the claimed slots
   unsigned long long *look; // look-back words of the tile scan
   uint32_t n_look;
 };
@@ -134,36 +142,32 @@ __device__ __forceinline__ void scatter_prep(const PrepArgs &p, bool counters_to
 {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   if (counters_too && tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
-  for (int64_t i = tid; i < p.n_hist; i += stride)
-  {
-    p.az_hist[i] = 0;
-    p.az_cur[i] = 0;
-  }
+  for (int64_t i = tid; i < p.n_hist; i += stride) p.az_hist[i] = 0;
   for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nruns[i] = 0;
-  // the free-space key hash: only the slots the scan claimed (bitmap behind the hash), or all of it the first time
+  // the free-space key hash: all of it (the scans themselves only clear the slots they claimed, fk_clear_claimed)
   uint32_t *claimed = reinterpret_cast<uint32_t *>(p.fk + p.n_fk);
-  if (p.fk_all)
+  for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
+  for (int64_t i = tid; i < p.n_fk / 64; i += stride) claimed[i] = 0;
+  for (int64_t i = tid; i < p.n_look; i += stride) p.look[i] = 0;
+}
+// the slots of the free-space key hash the PREVIOUS scan claimed (one bit per slot behind the hash) back to empty; run
+// by the set-up blocks of a scan, long before its free-space pass
+__device__ __forceinline__ void fk_clear_claimed(unsigned long long *fk, uint32_t slots, int64_t tid, int64_t stride)
+{
+  uint32_t *claimed = reinterpret_cast<uint32_t *>(fk + 2 * (size_t)slots);
+  for (int64_t i = tid; i < (int64_t)(slots / 32); i += stride)
   {
-    for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
-    for (int64_t i = tid; i < p.n_fk / 64; i += stride) claimed[i] = 0;
-  }
-  else
-  {
-    for (int64_t i = tid; i < p.n_fk / 64; i += stride)
+    uint32_t bits = claimed[i];
+    if (bits == 0) continue;
+    claimed[i] = 0;
+    while (bits)
     {
-      uint32_t bits = claimed[i];
-      if (bits == 0) continue;
-      claimed[i] = 0;
-      while (bits)
-      {
-        const uint32_t h = (uint32_t)i * 32u + (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1;
-        p.fk[h] = KEY_INF;
-        p.fk[p.n_fk / 2 + h] = KEY_INF;
-      }
+      const uint32_t h = (uint32_t)i * 32u + (uint32_t)__builtin_ctz(bits);
+      bits &= bits - 1;
+      fk[h] = KEY_INF;
+      fk[(size_t)slots + h] = KEY_INF;
     }
   }
-  for (int64_t i = tid; i < p.n_look; i += stride) p.look[i] = 0;
 }
 __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter_prep(p, true); }
 
@@ -186,10 +190,12 @@ __device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1,
 }
 
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
-__global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
+__device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n_setup_blocks)
 {
   __shared__ unsigned long long ub_wave[4];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
+  // the free-space key hash still holds what the previous scan claimed: back to empty, long before this scan's free pass
+  fk_clear_claimed(a.fk_keys, a.fk_mask + 1u, (int64_t)ix, (int64_t)n_setup_blocks * 256);
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
@@ -320,7 +326,11 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
       bin = (uint32_t)(b * EL_BINS + e);
     }
     r.pad |= (int32_t)(bin << 1); // bits 1 .. 14 (RAY_SIMPLE is bit 30)
-    atomicAdd(&a.az_hist[bin], 1u);
+    // the histogram's old value is this ray's rank inside its bin: the sort blocks place it without a second atomic.
+    // Both travel at agent scope (performed at the coherent level): the sort blocks run on other XCDs in the same launch.
+    const uint32_t rank = __hip_atomic_fetch_add(&a.az_hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.ray_bin[ix]), (unsigned long long)bin | ((unsigned long long)rank << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
     a.rays[ix] = r;
   }
   // The record slots this scan can need (sum of the per-ray bounds): one 64-bit add per workgroup; the last workgroup to
@@ -329,12 +339,19 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
   unsigned long long ub = r.ub;
   for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
   if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this lane's (bin, rank) has been written through ...
+  __syncthreads();                                  // ... and so has everybody else's in the workgroup
   if (threadIdx.x == 0)
   {
     const unsigned long long t = ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3];
-    if (t) __hip_atomic_fetch_add(&a.counters->ub_total, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__hip_atomic_fetch_add(&a.counters->setup_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+    // No cache-wide fence (an agent-scope release / acquire walks the XCD's L2: 15-20 us on this kernel, measured): the
+    // sum is a RETURNING atomic, and the arrival count below takes its operand from that result, so the add has been
+    // performed at the coherent level before the count is.
+    unsigned long long before = 0;
+    if (t) before = __hip_atomic_fetch_add(&a.counters->ub_total, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t one = 1u;
+    asm volatile("" : "+v"(one) : "v"(before));
+    if (__hip_atomic_fetch_add(&a.counters->setup_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_setup_blocks - 1)
     {
       const unsigned long long total = __hip_atomic_load(&a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -343,18 +360,36 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a)
   }
 }
 
-// Counting sort of the rays by direction bin.  Every workgroup scans the 8193-entry histogram itself (32 KB from L2,
-// one block scan) instead of waiting for a one-workgroup scan kernel in between: one launch less on the critical path.
-__global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
+// Counting sort of the rays by direction bin, in the SAME launch as the set-up: blocks [0, S) are the set-up blocks above,
+// blocks [S, 2S) wait until all of them have counted (workgroups are dispatched in index order, so a sort block can only be
+// on the chip when every set-up block is there or done: no deadlock whatever the grid size) and place the rays.  One launch
+// and its ~10 us of dependent start-up less on the critical path.  Every sort block scans the 8193-entry histogram itself
+// (32 KB, one block scan).
+template <bool FUSED>
+__device__ __forceinline__ void ray_sort_block(const ScatterArgs &a, uint32_t n_setup_blocks)
 {
   __shared__ uint32_t s_off[AZ_BINS + 2];
   __shared__ uint32_t wave_sums[4];
   constexpr int TOTAL = AZ_BINS + 1;
   constexpr int PER = (TOTAL + 255) / 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (FUSED)
+  {
+    if (threadIdx.x == 0)
+      while (__hip_atomic_load(&a.counters->setup_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_setup_blocks) __builtin_amdgcn_s_sleep(16);
+    __syncthreads();
+  }
   const int lo = threadIdx.x * PER, hi = min(lo + PER, TOTAL);
+  uint32_t h[PER];
   uint32_t v = 0;
-  for (int i = lo; i < hi; ++i) v += a.az_hist[i];
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+  {
+    const int i = lo + j;
+    // (a launch of its own sees the histogram through the kernel boundary; fused, it was counted on other XCDs in this launch)
+    h[j] = i < hi ? (FUSED ? __hip_atomic_load(&a.az_hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.az_hist[i]) : 0u;
+    v += h[j];
+  }
   uint32_t x = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1)
@@ -366,19 +401,34 @@ __global__ __launch_bounds__(256) void ray_scatter_kernel(ScatterArgs a)
   __syncthreads();
   uint32_t run = x - v;
   for (int w = 0; w < wave; ++w) run += wave_sums[w];
-  for (int i = lo; i < hi; ++i)
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
   {
-    s_off[i] = run;
-    run += a.az_hist[i];
+    const int i = lo + j;
+    if (i < hi) s_off[i] = run;
+    run += h[j];
   }
   if (hi == TOTAL && lo < hi) s_off[TOTAL] = run;
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.az_off[AZ_BINS] = s_off[AZ_BINS]; // rays that contribute: the tail march's grid
-  const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
-  if (ix >= a.n) return;
-  const uint32_t bin = ((uint32_t)a.rays[ix].pad >> 1) & 0x3fffu;
-  a.ray_order[s_off[bin] + atomicAdd(&a.az_cur[bin], 1u)] = ix;
+  const uint32_t b = blockIdx.x - n_setup_blocks, nb = gridDim.x - n_setup_blocks;
+  if (b == 0 && threadIdx.x == 0) a.az_off[AZ_BINS] = s_off[AZ_BINS]; // rays that contribute: the tail march's grid
+  for (uint32_t ix = b * 256u + threadIdx.x; ix < a.n; ix += nb * 256u)
+  {
+    const unsigned long long br = FUSED ? __hip_atomic_load(reinterpret_cast<unsigned long long *>(&a.ray_bin[ix]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : *reinterpret_cast<const unsigned long long *>(&a.ray_bin[ix]);
+    a.ray_order[s_off[(uint32_t)br] + (uint32_t)(br >> 32)] = ix;
+  }
 }
+
+// n_setup_blocks == gridDim.x: set-up only (the sort follows as a launch of its own)
+__global__ __launch_bounds__(256) void ray_setup_sort_kernel(ScatterArgs a, uint32_t n_setup_blocks)
+{
+  if (blockIdx.x < n_setup_blocks)
+    ray_setup_block(a, n_setup_blocks);
+  else
+    ray_sort_block<true>(a, n_setup_blocks);
+}
+__global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a) { ray_sort_block<false>(a, 0); }
 
 // ---------------------------------------------------------------------------------------------------------
 // ray tails -> records, sorted by tile inside the workgroup
@@ -450,6 +500,8 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
   __shared__ u32x4 s_queue[4 * TAIL_QCAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n_sorted = a.az_off[AZ_BINS];
+  // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
   const uint32_t slot = (blockIdx.x / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
   const int part0 = (int)(blockIdx.x % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
   const bool has_ray = slot < n_sorted;
@@ -1036,6 +1088,10 @@ struct TileScanArgs
   int64_t n_tiles;
   int32_t nty, ntz;
   TsdfCounters *counters;
+  // run descriptors as the tail march wrote them -> grouped by tile (placement blocks of tile_scan_kernel / desc_place_kernel)
+  const RunDesc *desc;
+  uint32_t desc_cap;
+  uint32_t *sorted_desc;
 };
 
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
@@ -1169,10 +1225,41 @@ constexpr uint32_t LOOKBACK_MAX_BLOCKS = 2048;
 __device__ __forceinline__ unsigned long long look_pack(unsigned long long v) { return (v & 0x7fffffffull) | ((v >> 32) << 31); } // runs(31) | listed(31)
 __device__ __forceinline__ unsigned long long look_unpack(unsigned long long w) { return (w & 0x7fffffffull) | (((w >> 31) & 0x7fffffffull) << 32); }
 
-__global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned long long *look)
+// run descriptors grouped by tile: the tile's counter of runs doubles as its placement cursor (and ends at zero).
+// COHERENT: called by the placement blocks of tile_scan_kernel, which read what scan blocks of the same launch wrote.
+template <bool COHERENT>
+__device__ __forceinline__ void place_descriptors(const TileScanArgs &a, uint32_t first_block, uint32_t n_blocks)
+{
+  // n_desc_sorted = sum of tile_nruns = descriptors actually written: they are the first n of the array (a reservation
+  // that did not fit wrote nothing and counted nothing, and every later one failed too)
+  uint32_t n = COHERENT ? __hip_atomic_load(&a.counters->n_desc_sorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.counters->n_desc_sorted;
+  if (n > a.desc_cap) n = a.desc_cap;
+  for (uint32_t i = (blockIdx.x - first_block) * 256u + threadIdx.x; i < n; i += n_blocks * 256u)
+  {
+    const RunDesc d = a.desc[i];
+    const uint32_t old = atomicSub(&a.tile_nruns[d.tile], 1u);
+    const uint32_t begin = COHERENT ? __hip_atomic_load(&a.tile_begin[d.tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.tile_begin[d.tile];
+    const uint32_t pos = begin + old - 1u;
+    a.sorted_desc[2 * (size_t)pos + 0] = d.start;
+    a.sorted_desc[2 * (size_t)pos + 1] = d.count;
+  }
+}
+
+// Blocks [0, n_scan_blocks): the scan.  Blocks behind them: the placement of the run descriptors, which needs every tile's
+// range -- they wait for the scan blocks' arrival count (in-order dispatch: a placement block is only on the chip when every
+// scan block is there or done), instead of a launch of their own.
+__global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned long long *look, uint32_t n_scan_blocks)
 {
   __shared__ unsigned long long wave_sums[4];
   __shared__ unsigned long long s_prefix;
+  if (blockIdx.x >= n_scan_blocks)
+  {
+    if (threadIdx.x == 0)
+      while (__hip_atomic_load(&a.counters->scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_scan_blocks) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    place_descriptors<true>(a, n_scan_blocks, gridDim.x - n_scan_blocks);
+    return;
+  }
   const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
   uint32_t nr[SCAN_TILES_PER_THREAD];
   uint32_t listed = 0; // bit mask
@@ -1216,10 +1303,10 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
     }
     __hip_atomic_store(&look[b], LOOK_INCL | look_pack(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_prefix = prefix;
-    if (b == gridDim.x - 1)
+    if (b == n_scan_blocks - 1)
     {
-      a.counters->n_desc_sorted = (uint32_t)(prefix + total);
-        a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
+      __hip_atomic_store(&a.counters->n_desc_sorted, (uint32_t)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
     }
   }
   __syncthreads();
@@ -1230,7 +1317,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
   {
     if (!(listed & (1u << j))) continue;
     const int64_t t = t0 + j;
-    if (nr[j]) a.tile_begin[t] = run_off;
+    if (nr[j]) __hip_atomic_store(&a.tile_begin[t], run_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // read by the placement blocks
     TileEntry e;
     e.tile = (uint32_t)t;
     e.desc_begin = run_off;
@@ -1243,25 +1330,14 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
     run_off += nr[j];
     list_off += 1;
   }
+  // this block's ranges (and, from the last block, the totals) have been written through: count it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.counters->scan_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// run descriptors grouped by tile: the tile's counter of runs doubles as its placement cursor (and ends at zero)
-__global__ __launch_bounds__(256) void desc_place_kernel(const RunDesc *desc, uint32_t desc_cap, uint32_t *tile_nruns, const uint32_t *tile_begin,
-                                                         uint32_t *sorted_desc, const TsdfCounters *counters)
-{
-  // n_desc_sorted = sum of tile_nruns = descriptors actually written: they are the first n of the array (a reservation
-  // that did not fit wrote nothing and counted nothing, and every later one failed too)
-  uint32_t n = counters->n_desc_sorted;
-  if (n > desc_cap) n = desc_cap;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
-  {
-    const RunDesc d = desc[i];
-    const uint32_t old = atomicSub(&tile_nruns[d.tile], 1u);
-    const uint32_t pos = tile_begin[d.tile] + old - 1u;
-    sorted_desc[2 * (size_t)pos + 0] = d.start;
-    sorted_desc[2 * (size_t)pos + 1] = d.count;
-  }
-}
+// the placement as a launch of its own, behind the three-kernel scan of maps with more than LOOKBACK_MAX_BLOCKS scan blocks
+__global__ __launch_bounds__(256) void desc_place_kernel(TileScanArgs a) { place_descriptors<false>(a, 0, gridDim.x); }
 
 // ---------------------------------------------------------------------------------------------------------
 // exact resolve of one tile in LDS
@@ -1287,8 +1363,12 @@ struct ResolveArgs
   uint32_t *resolve_stats; // [grid][2]: contested voxels, free-space hits on keyed voxels
   TsdfCounters *counters;
   uint32_t *status;
+  unsigned long long *look; // look-back words of the tile scan: consumed, zeroed here for the next scan
+  uint32_t n_look;
 };
+static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
 
+constexpr int PLACE_BLOCKS = 256; // workgroups that group the run descriptors by tile
 constexpr int RESOLVE_GRID = 4096; // 1024 / 2048 / 8192 workgroups: the same 170 us, 3072: 182 (block_stats holds two words per workgroup)
 constexpr uint32_t M_IDLE = 0xffffffffu, M_NONE = 0x10000u; // mstate: voxel not in the ordered rounds / no earlier negative seen
 
@@ -1496,6 +1576,21 @@ __global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
     }
   };
 
+  // The per-scan scratch this scan has consumed goes back to zero here, for the next scan (no clean-up launch behind the
+  // update): the look-back words of the tile scan, and the cursors of the tail march after a copy for ws_tsdf_stats.
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n_look; i += gridDim.x * 256u) a.look[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    TsdfCounters *c = a.counters;
+    c->last_slots = c->raw_cursor;
+    c->last_runs = c->desc_cursor;
+    c->last_listed = n_list;
+    c->raw_cursor = 0;
+    c->desc_cursor = 0;
+    c->setup_done = 0;
+    c->scan_done = 0;
+    c->ub_total = 0;
+  }
   const uint32_t e0 = blockIdx.x;
   if (e0 >= n_list)
   {
@@ -1896,13 +1991,10 @@ __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
   }
 }
 
-// bookkeeping after an update: statistics of the scan (no shared counters in the hot kernels: per-workgroup slots)
-__global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, const uint32_t *tail_stats, uint32_t n_tail, const uint32_t *resolve_stats,
-                                                            uint32_t n_resolve, uint32_t *status, PrepArgs prep)
+// statistics of the last update, on demand (ws_tsdf_stats): the hot kernels keep per-workgroup slots, no shared counters
+__global__ __launch_bounds__(256) void tsdf_stats_kernel(TsdfCounters *c, const uint32_t *tail_stats, uint32_t n_tail, const uint32_t *resolve_stats,
+                                                         uint32_t n_resolve)
 {
-  // every workgroup: leave the scatter's scratch zero / empty for the NEXT scan (it then starts without a prep launch)
-  scatter_prep(prep, false);
-  if (blockIdx.x != 0) return;
   __shared__ uint32_t part[12];
   uint32_t rec = 0, con = 0, fh = 0;
   for (uint32_t i = threadIdx.x; i < n_tail; i += 256) rec += tail_stats[i];
@@ -1929,42 +2021,14 @@ __global__ __launch_bounds__(256) void finish_update_kernel(TsdfCounters *c, con
     c->last_records = part[0] + part[3] + part[6] + part[9];
     c->last_contested = part[1] + part[4] + part[7] + part[10];
     c->last_free_keyed = part[2] + part[5] + part[8] + part[11];
-    c->last_listed = c->n_listed;
-    c->last_runs = c->desc_cursor;
-    c->last_slots = c->raw_cursor;
   }
-  __syncthreads();
-#ifdef WS_TAIL_TIMING
-  if (blockIdx.x == 0)
-  {
-    __shared__ uint32_t hist[2][24];
-    __shared__ unsigned long long sums[2];
-    if (threadIdx.x < 48) hist[threadIdx.x / 24][threadIdx.x % 24] = 0;
-    if (threadIdx.x < 2) sums[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_tail; i += 256)
-    {
-      const uint32_t t = tail_stats[32768 + i] * 16, p2 = tail_stats[49152 + i] * 16;
-      atomicAdd(&hist[0][min(23u, t / 16384u)], 1u);
-      atomicAdd(&hist[1][min(23u, p2 / 16384u)], 1u);
-      atomicAdd(&sums[0], (unsigned long long)t);
-      atomicAdd(&sums[1], (unsigned long long)p2);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      printf("tail march: %u workgroups, mean %llu cycles (phase 2 %llu); histogram of totals in 16384-cycle bins:", n_tail, sums[0] / max(n_tail, 1u),
-             sums[1] / max(n_tail, 1u));
-      for (int i = 0; i < 24; ++i) printf(" %u", hist[0][i]);
-      printf(" | phase 2:");
-      for (int i = 0; i < 24; ++i) printf(" %u", hist[1][i]);
-      printf("\n");
-    }
-  }
-#endif
-  // the per-scan counters: zero for the next scan (n_listed stays: a separate integrate pass may still follow)
-  if (threadIdx.x < offsetof(TsdfCounters, last_records) / 4 && threadIdx.x != offsetof(TsdfCounters, n_listed) / 4)
-    reinterpret_cast<uint32_t *>(c)[threadIdx.x] = 0;
+}
+int launch_tsdf_stats(ws_map *m)
+{
+  hipLaunchKernelGGL(tsdf_stats_kernel, dim3(1), dim3(256), 0, m->ctx->stream, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
+                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), m->resolve_blocks);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
 }
 
 // cu_avg_tsdf_krnl over EVERY voxel: the HBM-roofline stream, 16 B per voxel
@@ -2097,18 +2161,16 @@ int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n)
 }
 
 constexpr int PREP_GRID = 512;
-static PrepArgs make_prep_args(ws_map *m, bool whole_hash = true)
+static PrepArgs make_prep_args(ws_map *m)
 {
   PrepArgs p;
   p.counters = m->counters;
   p.az_hist = m->az_hist;
-  p.az_cur = m->az_cur;
   p.n_hist = (uint32_t)(AZ_BINS + 1);
   p.tile_nruns = m->tile_nruns;
   p.n_tiles = m->n_tiles;
   p.fk = m->fk_keys;
   p.n_fk = (int64_t)2 * m->fk_slots;
-  p.fk_all = whole_hash ? 1 : 0; // the stand-alone preparation fills the whole hash; the pass after a scan clears what the scan claimed
   p.look = reinterpret_cast<unsigned long long *>(m->block_sums);
   p.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
   return p;
@@ -2143,7 +2205,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   m->tail_blocks = 0;
   if (n == 0)
   {
-    WS_HIP(hipMemsetAsync(m->counters, 0, offsetof(TsdfCounters, last_records), s));
+    m->resolve_blocks = 0;
+    WS_HIP(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
     return WS_OK; // (nothing listed: a following integrate pass has nothing to do)
   }
 
@@ -2174,7 +2237,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.rays = (RaySetup *)m->rays;
   sa.az_hist = m->az_hist;
   sa.az_off = m->az_off;
-  sa.az_cur = m->az_cur;
+  sa.ray_bin = reinterpret_cast<uint2 *>(m->ray_bin);
   sa.ray_order = m->ray_order;
   sa.fan_steps = m->fan_steps;
   sa.vstate = m->vstate;
@@ -2204,17 +2267,22 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   m->tail_blocks = grid_tail.x;
 
   prof_begin(ctx, WS_K_SETUP);
-  // normally the previous update's finish pass has already left everything zero / empty (m->prepped)
+  // normally the kernels of the previous update have left their scratch zero / empty on their way (m->prepped)
   if (!m->prepped) hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), block, 0, s, make_prep_args(m));
   m->prepped = false;
-  hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
-  hipLaunchKernelGGL(ray_scatter_kernel, grid_setup, block, 0, s, sa);
+#if WS_FUSE_SETUP
+  // set-up blocks + direction-sort blocks in one launch
+  hipLaunchKernelGGL(ray_setup_sort_kernel, dim3(grid_setup.x + min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa, grid_setup.x);
+#else
+  hipLaunchKernelGGL(ray_setup_sort_kernel, grid_setup, block, 0, s, sa, grid_setup.x);
+  hipLaunchKernelGGL(ray_sort_kernel, dim3(min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa);
+#endif
   prof_end(ctx, WS_K_SETUP);
   {
     // The set-up pass has counted the record slots this scan can need; its last workgroup writes the total and this
-    // scan's sequence number into host-mapped memory.  The host waits for that word -- ray_setup is the first kernel of
-    // the update, and the direction sort enqueued behind it runs meanwhile, so the stream does not drain -- and grows the
-    // buffers first if the scan does not fit.  (The reference's update_tsdf blocks on three cudaMemcpy at this point,
+    // scan's sequence number into host-mapped memory.  The host waits for that word -- the set-up blocks are the first
+    // thing the update runs, and the direction-sort blocks of the same launch run meanwhile, so the stream does not drain --
+    // and grows the buffers first if the scan does not fit.  (The reference's update_tsdf blocks on three cudaMemcpy at this point,
     // update_tsdf.cu:152-154.)  A hint from the previous scan is not enough: a door that opens multiplies the need.
     volatile uint32_t *st = m->status_host;
     const auto t0 = std::chrono::steady_clock::now();
@@ -2272,18 +2340,27 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ta.nty = m->nty;
   ta.ntz = m->ntz;
   ta.counters = m->counters;
+  ta.desc = m->desc;
+  ta.desc_cap = m->desc_cap;
+  ta.sorted_desc = m->sorted_desc;
   if (m->scan_blocks <= LOOKBACK_MAX_BLOCKS)
   {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums));
+#if WS_FUSE_PLACE
+    // scan blocks + descriptor-placement blocks in one launch
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks + PLACE_BLOCKS), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums),
+                       m->scan_blocks);
+#else
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums), m->scan_blocks);
+    hipLaunchKernelGGL(desc_place_kernel, dim3(PLACE_BLOCKS), block, 0, s, ta);
+#endif
   }
   else
   {
     hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
     hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
     hipLaunchKernelGGL(tile_list_kernel, dim3(m->scan_blocks), block, 0, s, ta);
+    hipLaunchKernelGGL(desc_place_kernel, dim3(PLACE_BLOCKS), block, 0, s, ta);
   }
-  hipLaunchKernelGGL(desc_place_kernel, dim3(256), block, 0, s, (const RunDesc *)m->desc, m->desc_cap, m->tile_nruns, (const uint32_t *)m->tile_begin,
-                     m->sorted_desc, (const TsdfCounters *)m->counters);
   prof_end(ctx, WS_K_TILE_BIN);
 
   ResolveArgs ra;
@@ -2311,6 +2388,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.resolve_stats = m->block_stats + WS_TAIL_STATS;
   ra.counters = m->counters;
   ra.status = m->status_dev;
+  ra.look = reinterpret_cast<unsigned long long *>(m->block_sums);
+  ra.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
+  m->resolve_blocks = RESOLVE_GRID;
   prof_begin(ctx, WS_K_TILE_RESOLVE);
   const bool fuse = fused && !s0;
   if (s0)
@@ -2321,6 +2401,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   prof_end(ctx, WS_K_TILE_RESOLVE);
   m->fused_done = fuse;
+  m->prepped = true; // every kernel above has put back what it consumed (the free-space hash: the next scan's set-up blocks)
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
@@ -2359,10 +2440,7 @@ int launch_tsdf_integrate(ws_map *m)
     }
     prof_end(ctx, WS_K_INTEGRATE);
   }
-  hipLaunchKernelGGL(finish_update_kernel, dim3(PREP_GRID), block, 0, s, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
-                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), (uint32_t)RESOLVE_GRID, m->status_dev, make_prep_args(m, false));
   WS_HIP(hipGetLastError());
-  m->prepped = true;
   m->fused_done = false;
   m->new_is_default = true;
   return WS_OK;

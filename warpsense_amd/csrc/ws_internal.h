@@ -82,7 +82,9 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
   uint32_t n_desc_sorted; // == desc_cursor once the tile scan has run
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
-  uint32_t setup_done;    // workgroups of ray_setup_kernel that have added their record bounds
+  uint32_t setup_done;    // set-up blocks of ray_setup_sort_kernel that have counted their rays and added their record bounds
+  uint32_t scan_done;     // scan blocks of tile_scan_kernel that have written their tiles' ranges
+  uint32_t pad0;
   unsigned long long ub_total; // sum of the per-ray record upper bounds (capacity hint for the next scan)
   // statistics of the last update, filled by finish_update_kernel
   uint32_t last_records;
@@ -91,7 +93,6 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t last_runs;
   uint32_t last_free_keyed;
   uint32_t last_slots; // record slots the last scan reserved
-  uint32_t pad1[2];
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -143,7 +144,8 @@ struct ws_map
   uint32_t *data[2] = {nullptr, nullptr};
   uint8_t *vstate = nullptr; // one byte per voxel: keyed / touched by free space / free-space hit on a keyed voxel
   void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
-  uint32_t *az_hist = nullptr, *az_off = nullptr, *az_cur = nullptr, *ray_order = nullptr; // rays grouped by direction bin
+  uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
+  void *ray_bin = nullptr;   // [1 000 000] uint2: (direction bin, rank inside the bin) per ray
   int32_t *fan_steps = nullptr;       // [256] first ray step whose fan has j + 1 targets (depends on res only), see tail_bound
   int32_t fan_steps_host[256] = {};   // staging of the same (lives as long as the map: async upload)
   bool prepped = false; // the scatter's scratch (histograms, tile counters, free-space hash) is zero / empty
@@ -172,6 +174,7 @@ struct ws_map
   uint32_t fk_slots = 0;
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
   uint32_t tail_blocks = 0;        // workgroups of the last tail march
+  uint32_t resolve_blocks = 0;     // workgroups of the last tile resolve
   bool fused_done = false;         // the last scatter already integrated into avg_map
   uint32_t scan_seq = 0;           // scatters launched on this map (ray_setup reports its record bound under this number)
   bool grow_aux = false;           // a scan overflowed the run descriptors / the free-space hash: double them before the next
@@ -270,6 +273,7 @@ int launch_scatter_prep(ws_map *m);
 int resize_records(ws_map *m, uint64_t records); // api.hip: (re)allocate the candidate-record buffers
 uint32_t tile_scan_blocks(int64_t n_tiles);
 int launch_tsdf_integrate(ws_map *m);
+int launch_tsdf_stats(ws_map *m); // fills the last_* statistics of TsdfCounters from the per-workgroup slots
 int launch_box_copy(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
 int fill_u32(ws_context *ctx, uint32_t *dst, uint32_t value, int64_t n);
 int launch_box_fill(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t value, hipStream_t stream);
