@@ -201,6 +201,29 @@ int ws_reg_iterate_shard_dev(ws_reg *reg, const ws_map *map, int32_t map_resolut
                              int64_t *sums_dev /* 44 */, int32_t apply_previous);
 int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out[16]); /* synchronises */
 
+/* The same sharded loop WITHOUT the host in it (north_star: point-sharded registration across GPUs): every rank runs the
+ * resident loop of ws_register_cloud on its points [first, first + count) and the ranks' 44 sums meet in MAILBOXES in each
+ * other's HBM -- fine-grained device memory, peer-mapped through hipIpc, system-scope atomic adds over xGMI whose top byte
+ * counts the ranks (exact for any rank order) -- so an iteration costs one device-side exchange instead of a launch, an RCCL
+ * call and two host calls.  Set-up, once per process group:
+ *   ws_reg_peer_mailbox(reg, handle)            -> this rank's mailbox as a 64-byte IPC handle (hipIpcMemHandle_t)
+ *   [all-gather the handles, any transport]
+ *   ws_reg_peer_connect(reg, rank, world, handles (world x 64 bytes), blocks)
+ * then all ranks call ws_register_cloud_peers together for every cloud (every rank has prepared the WHOLE cloud; the map is
+ * replicated).  `blocks`: workgroups of the loop on this rank, 0 = 256 (one per CU); ranks that share one GPU (tests) pass
+ * 256 / ranks-per-GPU so that all of them are resident at once.  WS_ERR_TIMEOUT: a peer did not deliver within 0.25 s -- all
+ * ranks see it; call ws_reg_peer_reset on every rank (between two barriers of the caller's) and fall back to the RCCL route.
+ * ws_reg_peer_connect_local connects ws_reg handles of ONE process (several contexts / streams on one GPU) without IPC. */
+#define WS_IPC_HANDLE_BYTES 64
+int ws_reg_peer_mailbox(ws_reg *reg, void *ipc_handle_out /* WS_IPC_HANDLE_BYTES, may be NULL */);
+int ws_reg_peer_connect(ws_reg *reg, int32_t rank, int32_t world, const void *ipc_handles, int32_t blocks);
+int ws_reg_peer_connect_local(ws_reg *reg, int32_t rank, int32_t world, ws_reg *const *regs, int32_t blocks);
+int ws_reg_peer_disconnect(ws_reg *reg);
+int ws_reg_peer_reset(ws_reg *reg);
+int ws_register_cloud_peers(ws_reg *reg, const ws_map *map, size_t first, size_t count, const float T_in[16], int32_t max_iterations,
+                            float it_weight_gradient, float epsilon, int32_t map_resolution, uint32_t flags, float T_out[16],
+                            int32_t *iterations);
+
 /* Test entry: the 6x6 solve of the Gauss-Newton update alone (LU with partial pivoting in double, one wavefront per
  * system; stands for Eigen's hf.inverse() * g, tsdf_registration.cpp:69). n systems: A row-major n x 36, b n x 6 ->
  * x n x 6, status n (0, or -1 for a singular matrix). Host pointers; synchronises. */

@@ -195,3 +195,141 @@ def test_sharded_register_cloud_two_processes_on_one_gpu(drop):
     for rank, first, count, it, it_o, same, err in got:
         assert it == it_o > 5, (rank, it, it_o)
         assert same, (rank, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the sharded loop WITHOUT the host in it: resident loop per rank, sums exchanged through mailboxes in HBM (ws_reg_peer_*)
+# ---------------------------------------------------------------------------------------------------------------------
+def _peer_ranks_in_one_process(reg, q, res, world, blocks):
+    """`world` ranks as ws_reg handles on their own contexts (own streams) of one process, connected without IPC"""
+    import warpsense_amd as W
+    from warpsense_amd.dist import HipGnBackend
+    ranks = []
+    for r in range(world):
+        ctx = W.Context(-1)  # own stream: the ranks' resident kernels must be on the chip together
+        rc = W.RegistrationCuda(ctx=ctx)
+        rc.prepare_registration(q)
+        b = HipGnBackend.__new__(HipGnBackend)  # (no torch-stream hand-off: this route has no host step per iteration)
+        b.reg, b.tsdf, b.res, b.flags, b._L, b.peers, b._pending = rc, reg.tsdf(), res, 0, rc._L, None, False
+        ranks.append(b)
+    for r, b in enumerate(ranks):
+        b.connect_local(ranks, r, blocks)
+    return ranks
+
+
+def _run_ranks(ranks, n, args):
+    import threading
+    from warpsense_amd.dist import shard_range
+    world = len(ranks)
+    out = [None] * world
+
+    def work(r):
+        first, count = shard_range(n, r, world)
+        out[r] = ranks[r].register_peers(first, count, np.eye(4, dtype=np.float32), *args)  # ctypes drops the GIL: the calls overlap
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    return out
+
+
+@pytest.mark.parametrize("world,blocks,drop", [(2, 128, 1), (3, 80, 2), (4, 64, 3), (1, 256, 0)])
+def test_peer_mailbox_loop_equals_the_oracle(world, blocks, drop):
+    """2 / 3 / 4 ranks share cuda:0 (at most 256 / world resident workgroups each, so that all are on the chip at once; one
+    process drives at most four hardware queues concurrently, so eight ranks cannot be co-resident from one process): every rank
+    runs the resident Gauss-Newton loop on its ragged shard, the ranks' 44 sums meet in counted mailboxes, nobody talks to the
+    host in between.  Every rank must return the oracle's iteration count and pose, bit for bit, registration after
+    registration (the mailbox words are never reset: each launch starts counting where the last one stopped)."""
+    reg, oa, q, res = _scene()
+    if drop:
+        q = np.ascontiguousarray(q[:-drop])
+    n = q.shape[0]
+    args = (200, 0.1, 0.03)
+    ranks = _peer_ranks_in_one_process(reg, q, res, world, blocks)
+    T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), *args, res)
+    for rep in range(3):
+        out = _run_ranks(ranks, n, args)
+        for r, got in enumerate(out):
+            assert got is not None, f"rank {r} timed out (repetition {rep})"
+            T, it = got
+            assert it == it_o > 5, (rep, r, it, it_o)
+            assert np.array_equal(T, T_o), (rep, r, np.abs(T - T_o).max())
+    # cut-offs: every rank stops at the same iteration
+    for max_it in (0, 1, 7):
+        out = _run_ranks(ranks, n, (max_it, 0.1, 0.03))
+        T_c, it_c, _ = O.register_cloud(oa, q, np.eye(4), max_it, 0.1, 0.03, res)
+        for got in out:
+            assert got is not None and got[1] == it_c <= max_it and np.array_equal(got[0], T_c)
+    for b in ranks:
+        b.reg.close()
+
+
+def test_peer_loop_times_out_when_a_rank_is_missing_and_recovers():
+    """rank 1 never launches: rank 0 gives up after the 0.25 s poll limit (WS_ERR_TIMEOUT -> None) instead of hanging; after
+    ws_reg_peer_reset on both, the pair registers exactly again"""
+    reg, oa, q, res = _scene()
+    n = q.shape[0]
+    args = (200, 0.1, 0.03)
+    ranks = _peer_ranks_in_one_process(reg, q, res, 2, 128)
+    from warpsense_amd.dist import shard_range
+    first, count = shard_range(n, 0, 2)
+    assert ranks[0].register_peers(first, count, np.eye(4, dtype=np.float32), *args) is None
+    for b in ranks:
+        b.reset_peers()
+    T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), *args, res)
+    for got in _run_ranks(ranks, n, args):
+        assert got is not None and got[1] == it_o and np.array_equal(got[0], T_o)
+
+
+def _peer_worker(rank, world, port, q_out, drop):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from warpsense_amd.dist import HipGnBackend, sharded_register_cloud
+        reg, oa, q, res = _scene()
+        if drop:
+            q = np.ascontiguousarray(q[:-drop])
+        reg.reg_.prepare_registration(q)
+        backend = HipGnBackend(reg.reg_, reg.tsdf(), res)
+        backend.connect_peers(blocks=256 // world)  # IPC handles all-gathered over gloo
+        T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
+        ok = True
+        for _ in range(3):
+            T, it = sharded_register_cloud(backend, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03)
+            ok = ok and it == it_o and bool(np.array_equal(T, T_o))
+        q_out.put((rank, ok, it, it_o))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("drop", [1])
+def test_peer_mailbox_loop_two_processes_over_ipc(drop):
+    """the deployment shape on the one GPU of the box: two PROCESSES, mailboxes exported with hipIpcGetMemHandle, gathered over
+    the process group and opened with hipIpcOpenMemHandle; sharded_register_cloud takes the device-side route"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q_out, drop)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    got = sorted(q_out.get(timeout=10) for _ in range(2))
+    for rank, ok, it, it_o in got:
+        assert ok and it == it_o > 5, (rank, ok, it, it_o)

@@ -26,7 +26,8 @@ EXPORTS = [
     "ws_shift_end", "ws_map_get_params", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
     "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_points_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
-    "ws_reg_solve_dev", "ws_reg_iterate_shard_dev", "ws_reg_poll", "ws_reg_set_loop", "ws_debug_solve6", "ws_debug_reg_stall", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
+    "ws_reg_solve_dev", "ws_reg_iterate_shard_dev", "ws_reg_poll", "ws_reg_peer_mailbox", "ws_reg_peer_connect", "ws_reg_peer_connect_local",
+    "ws_reg_peer_disconnect", "ws_reg_peer_reset", "ws_register_cloud_peers", "ws_reg_set_loop", "ws_debug_solve6", "ws_debug_reg_stall", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
     "ws_scan_preprocess_dev", "ws_scan_points_dev", "ws_scan_download", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
 ]
 
@@ -160,6 +161,12 @@ def load() -> C.CDLL:
     L.ws_reg_accumulate_dev.argtypes = [vp, vp, i32, u32, sz, sz, vp]
     L.ws_reg_solve_dev.argtypes = [vp, vp]
     L.ws_reg_poll.argtypes = [vp, P(i32), P(i32), vp]
+    L.ws_reg_peer_mailbox.argtypes = [vp, vp]
+    L.ws_reg_peer_connect.argtypes = [vp, i32, i32, vp, i32]
+    L.ws_reg_peer_connect_local.argtypes = [vp, i32, i32, vp, i32]
+    L.ws_reg_peer_disconnect.argtypes = [vp]
+    L.ws_reg_peer_reset.argtypes = [vp]
+    L.ws_register_cloud_peers.argtypes = [vp, vp, sz, sz, vp, i32, C.c_float, C.c_float, i32, u32, vp, P(i32)]
     L.ws_prof_enable.argtypes = [vp, u32]
     L.ws_prof_read.argtypes = [vp, C.c_int, P(C.c_double), P(i64)]
     L.ws_prof_reset.argtypes = [vp]

@@ -804,6 +804,9 @@ int ws_reg_destroy(ws_reg *r)
   if (r->result_host) (void)hipHostFree(r->result_host);
   if (r->grid_bar) (void)hipFree(r->grid_bar);
   if (r->shard_arrived) (void)hipFree(r->shard_arrived);
+  (void)ws_reg_peer_disconnect(r);
+  if (r->mailbox) (void)hipFree(r->mailbox);
+  if (r->peer_block_dev) (void)hipFree(r->peer_block_dev);
   delete r;
   return WS_OK;
 }
@@ -950,6 +953,24 @@ int ws_reg_poll(ws_reg *r, int32_t *finished, int32_t *iterations, float T_out[1
   return WS_OK;
 }
 
+// the host side of one resident launch: spin on the flag the kernel raises behind its result (host-mapped memory)
+static int wait_resident_loop(ws_reg *r)
+{
+  volatile int32_t *done = r->host_flag;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (*done == 0)
+  {
+    if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+    {
+      WS_HIP(hipStreamSynchronize(r->ctx->stream));
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return WS_OK;
+}
+
 int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t max_iterations, float it_weight_gradient,
                       float epsilon, int32_t res, uint32_t flags, float T_out[16], int32_t *iterations)
 {
@@ -967,27 +988,15 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
     init.it_weight_gradient = it_weight_gradient;
     init.epsilon = epsilon;
     init.max_iterations = max_iterations;
-    volatile int32_t *done = r->host_flag;
-    *done = 0; // nothing on the stream writes it any more: every earlier registration was waited for
+    *(volatile int32_t *)r->host_flag = 0; // nothing on the stream writes it any more: every earlier registration was waited for
     int rc = launch_reg_loop(r, m, res, flags, init);
     if (rc != WS_OK) return rc;
     r->latest = 0;
     // The kernel raises the flag in host-mapped memory after its result (release at system scope).  Spinning on it costs a
     // microsecond or two; waking up from hipStreamSynchronize costs tens (measured: 84 -> ~35 us between the end of a
     // registration and the first kernel of the next scan).  Bounded: a kernel that never finishes is the runtime's to report.
-    {
-      const auto t0 = std::chrono::steady_clock::now();
-      uint32_t spins = 0;
-      while (*done == 0)
-      {
-        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
-        {
-          WS_HIP(hipStreamSynchronize(r->ctx->stream));
-          break;
-        }
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
+    rc = wait_resident_loop(r);
+    if (rc != WS_OK) return rc;
     const GnCore *h = &r->result_host->core;
     if (!h->error)
     {
@@ -1019,6 +1028,155 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
   rc = ws_reg_poll(r, &fin, &iters, T_out);
   if (rc != WS_OK) return rc;
   if (iterations) *iterations = iters;
+  return map_take_error(const_cast<ws_map *>(m));
+}
+
+// ------------------------------------------------------------------ multi-GPU resident loop
+static int peer_own_mailbox(ws_reg *r)
+{
+  if (r->mailbox) return WS_OK;
+  // fine-grained: coherent for system-scope atomics from every GPU that maps it (and for the polls of the owner)
+  WS_HIP(hipExtMallocWithFlags(&r->mailbox, 4096, hipDeviceMallocFinegrained));
+  WS_HIP(hipMemset(r->mailbox, 0, 4096));
+  return WS_OK;
+}
+
+int ws_reg_peer_mailbox(ws_reg *r, void *ipc_handle_out)
+{
+  if (!r) return invalid("ws_reg_peer_mailbox: reg is NULL");
+  static_assert(sizeof(hipIpcMemHandle_t) == WS_IPC_HANDLE_BYTES, "WS_IPC_HANDLE_BYTES");
+  int rc = peer_own_mailbox(r);
+  if (rc != WS_OK) return rc;
+  if (ipc_handle_out)
+  {
+    hipIpcMemHandle_t h;
+    WS_HIP(hipIpcGetMemHandle(&h, r->mailbox));
+    std::memcpy(ipc_handle_out, &h, sizeof h);
+  }
+  return WS_OK;
+}
+
+int ws_reg_peer_disconnect(ws_reg *r)
+{
+  if (!r) return WS_OK;
+  if (r->peer_world) (void)hipStreamSynchronize(r->ctx->stream);
+  for (int i = 0; i < 8; ++i)
+  {
+    if (r->peer_opened[i] && r->peer_mailbox[i]) (void)hipIpcCloseMemHandle(r->peer_mailbox[i]);
+    r->peer_opened[i] = false;
+    r->peer_mailbox[i] = nullptr;
+  }
+  r->peer_world = 0;
+  return WS_OK;
+}
+
+static int peer_finish_connect(ws_reg *r, int rank, int world, int blocks)
+{
+  if (blocks <= 0) blocks = reg_default_blocks();
+  if (blocks % reg_groups() != 0 || blocks > reg_default_blocks()) return invalid("ws_reg_peer_connect: blocks must be a multiple of 8, at most 256");
+  std::vector<unsigned char> image(reg_peer_block_bytes());
+  reg_peer_block_fill(image.data(), r->peer_mailbox, rank, world);
+  if (!r->peer_block_dev) WS_HIP(hipMalloc(&r->peer_block_dev, reg_peer_block_bytes()));
+  WS_HIP(hipMemcpy(r->peer_block_dev, image.data(), image.size(), hipMemcpyHostToDevice)); // also zeroes `then`: the mailboxes are fresh
+  WS_HIP(hipMemset(r->mailbox, 0, reg_mailbox_bytes()));
+  r->peer_rank = rank;
+  r->peer_world = world;
+  r->peer_blocks = blocks;
+  return WS_OK;
+}
+
+int ws_reg_peer_connect(ws_reg *r, int32_t rank, int32_t world, const void *ipc_handles, int32_t blocks)
+{
+  if (!r || !ipc_handles) return invalid("ws_reg_peer_connect: NULL argument");
+  if (world < 1 || world > 8 || rank < 0 || rank >= world) return invalid("ws_reg_peer_connect: 1 <= world <= 8, 0 <= rank < world");
+  int rc = peer_own_mailbox(r);
+  if (rc != WS_OK) return rc;
+  (void)ws_reg_peer_disconnect(r);
+  // the mailboxes of ranks on other GPUs are reached over xGMI: peer access to every visible device (already enabled / not
+  // possible are both fine here: the open below decides)
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) == hipSuccess)
+    for (int d = 0; d < n_dev; ++d)
+      if (d != r->ctx->device)
+      {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, r->ctx->device, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);
+      }
+  (void)hipGetLastError();
+  for (int i = 0; i < world; ++i)
+  {
+    if (i == rank)
+    {
+      r->peer_mailbox[i] = r->mailbox;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, static_cast<const unsigned char *>(ipc_handles) + (size_t)i * sizeof h, sizeof h);
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess)
+    {
+      (void)ws_reg_peer_disconnect(r);
+      return hip_fail(e, "hipIpcOpenMemHandle (mailbox of a peer rank)", __FILE__, __LINE__);
+    }
+    r->peer_mailbox[i] = p;
+    r->peer_opened[i] = true;
+  }
+  return peer_finish_connect(r, rank, world, blocks);
+}
+
+int ws_reg_peer_connect_local(ws_reg *r, int32_t rank, int32_t world, ws_reg *const *regs, int32_t blocks)
+{
+  if (!r || !regs) return invalid("ws_reg_peer_connect_local: NULL argument");
+  if (world < 1 || world > 8 || rank < 0 || rank >= world || regs[rank] != r) return invalid("ws_reg_peer_connect_local: regs[rank] must be reg, world <= 8");
+  (void)ws_reg_peer_disconnect(r);
+  for (int i = 0; i < world; ++i)
+  {
+    if (!regs[i]) return invalid("ws_reg_peer_connect_local: NULL rank");
+    const int rc = peer_own_mailbox(regs[i]);
+    if (rc != WS_OK) return rc;
+    r->peer_mailbox[i] = regs[i]->mailbox;
+  }
+  return peer_finish_connect(r, rank, world, blocks);
+}
+
+int ws_reg_peer_reset(ws_reg *r)
+{
+  if (!r || !r->peer_world) return invalid("ws_reg_peer_reset: not connected");
+  WS_HIP(hipStreamSynchronize(r->ctx->stream));
+  return peer_finish_connect(r, r->peer_rank, r->peer_world, r->peer_blocks);
+}
+
+int ws_register_cloud_peers(ws_reg *r, const ws_map *m, size_t first, size_t count, const float T_in[16], int32_t max_iterations,
+                            float it_weight_gradient, float epsilon, int32_t res, uint32_t flags, float T_out[16], int32_t *iterations)
+{
+  if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud_peers: NULL argument");
+  if (!r->peer_world) return invalid("ws_register_cloud_peers: ws_reg_peer_connect first");
+  if (res < 1) return invalid("ws_register_cloud_peers: map_resolution must be positive");
+  GnCore init;
+  std::memset(&init, 0, sizeof init);
+  std::memcpy(init.T, T_in, 16 * sizeof(float));
+  for (int k = 0; k < 3; ++k) init.center[k] = (int32_t)T_in[12 + k]; // tsdf_registration.cpp:33
+  init.it_weight_gradient = it_weight_gradient;
+  init.epsilon = epsilon;
+  init.max_iterations = max_iterations;
+  *(volatile int32_t *)r->host_flag = 0;
+  int rc = launch_reg_loop(r, m, res, flags, init, true, first, count);
+  if (rc != WS_OK) return rc;
+  r->latest = 0;
+  rc = wait_resident_loop(r);
+  if (rc != WS_OK) return rc;
+  const GnCore *h = &r->result_host->core;
+  if (h->error)
+  {
+    // a rank did not deliver (its kernel was not on the chip, or the process is gone): every rank times out within one
+    // exchange of the first.  The caller re-runs the registration through the RCCL route (warpsense_amd.dist does) after
+    // ws_reg_peer_reset on every rank.
+    set_error("ws_register_cloud_peers: the exchange with the peer ranks timed out");
+    return WS_ERR_TIMEOUT;
+  }
+  std::memcpy(T_out, h->T, 16 * sizeof(float));
+  if (iterations) *iterations = h->iterations;
   return map_take_error(const_cast<ws_map *>(m));
 }
 

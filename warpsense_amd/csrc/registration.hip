@@ -19,6 +19,8 @@
 // wrapping group accumulators whose words count their additions (the exchange is the barrier), a per-lane voxel cache.
 // reg_iter_kernel is one launch per iteration (state and 256 x 32 partials double buffered by launch parity, so no
 // fences or atomics are needed); it is the fallback when the grid cannot be resident, and the A/B reference.
+#include <cstring>
+
 #include "ws_device.h"
 
 namespace ws
@@ -627,7 +629,7 @@ struct Prefetched
   int32_t p[2][3];
   bool valid[2];
 };
-__device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a)
+__device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a, const uint32_t REG_STRIDE = ws::REG_STRIDE)
 {
   Prefetched f;
 #pragma unroll
@@ -645,7 +647,7 @@ __device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a)
 
 template <bool CACHED = false>
 __device__ __forceinline__ void accumulate_points(const PointArgs &a, const float *T, const Prefetched &f, int64_t (&acc)[REG_SLOTS],
-                                                  VoxelCache *cache = nullptr)
+                                                  VoxelCache *cache = nullptr, const uint32_t REG_STRIDE = ws::REG_STRIDE)
 {
   const IntTransform t = make_int_transform(T);
   // the two prefetched points: 14 gathers in flight before the first is consumed
@@ -827,14 +829,15 @@ constexpr int REG_POLL_SLEEP = 2;        // between polls
 constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
 
 // first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
-__device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, unsigned long long *wg_sum, bool publish)
+__device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, unsigned long long *wg_sum, bool publish,
+                                                const uint32_t per_group = REG_BLOCKS / REG_GROUPS)
 {
   const int lane = threadIdx.x & 63, slot = lane & (REG_SLOTS - 1);
   const unsigned long long s = wg_sum[slot];
   if (lane < REG_SLOTS) wg_sum[slot] = 0; // for the next iteration (the same wave read it one instruction ago)
   if (!publish) return;
   const uint32_t half = lane < REG_SLOTS ? (uint32_t)((uint64_t)s & 0xffffffffull) : (uint32_t)((uint64_t)s >> 32);
-  const int group = blockIdx.x / (REG_BLOCKS / REG_GROUPS);
+  const int group = (int)(blockIdx.x / per_group);
   __hip_atomic_fetch_add(&accum[(size_t)group * REG_WORDS + lane], REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -843,7 +846,7 @@ __device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][
 // other parity was last complete (rotated here).  false: gave up (another kernel is holding CUs this grid needs, or
 // another workgroup gave up) -- every workgroup then leaves the loop.
 __device__ __forceinline__ bool counted_collect(uint64_t *accum, uint32_t *abort_flag, uint64_t (&then_cur)[REG_GROUPS], uint64_t (&then_other)[REG_GROUPS],
-                                                int64_t *red)
+                                                int64_t *red, const uint32_t per_group = REG_BLOCKS / REG_GROUPS, int64_t *total_out = nullptr)
 {
   const int lane = threadIdx.x & 63;
   uint64_t w[REG_GROUPS];
@@ -857,7 +860,7 @@ __device__ __forceinline__ bool counted_collect(uint64_t *accum, uint32_t *abort
     for (int g = 0; g < REG_GROUPS; ++g)
     {
       w[g] = __hip_atomic_load(&accum[(size_t)g * REG_WORDS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ok = ok && ((w[g] - then_cur[g]) >> 56) == (uint64_t)(REG_BLOCKS / REG_GROUPS);
+      ok = ok && ((w[g] - then_cur[g]) >> 56) == (uint64_t)per_group;
     }
     if (__all(ok)) break;
     __builtin_amdgcn_s_sleep(REG_POLL_SLEEP);
@@ -883,7 +886,66 @@ __device__ __forceinline__ bool counted_collect(uint64_t *accum, uint32_t *abort
     then_cur[g] = t;
   }
   const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)s, 32);
-  if (lane < REG_SLOTS) red[lane] = (int64_t)(s + (high << 32));
+  const int64_t total = (int64_t)(s + (high << 32)); // lanes 0 .. 31: the total of slot `lane`
+  if (lane < REG_SLOTS) red[lane] = total;
+  if (total_out) *total_out = total;
+  return true;
+}
+
+// ---- the same exchange ACROSS GPUs (point-sharded registration), inside the resident loop ---------------
+// Every rank runs the resident loop on its shard.  After the on-chip exchange above, workgroup 0 of a rank ADDS the rank's 32
+// totals -- again as low / high halves whose top byte counts the additions -- into a 2 x 64-word MAILBOX in every rank's
+// HBM (its own included): fine-grained memory, peer-mapped (hipIpc) or local, system-scope atomics over xGMI.  Every
+// workgroup then polls ITS OWN rank's mailbox (local memory) until the count says that all `world` ranks have added: the
+// low 56 bits are the exact sums over the ranks, identical on every rank, and every rank goes on to the identical solve --
+// no host, no launch, no RCCL call per iteration.  The words are never reset; what a parity held when it was last
+// complete is carried in registers during a launch and in PeerBlock::then from launch to launch (all ranks run the same
+// number of iterations, so at the end of a launch every addition ever made has been seen complete by every rank).
+struct PeerBlock
+{
+  uint64_t *mailbox[8]; // [rank] -> that rank's mailbox: [2 parities][REG_WORDS]
+  int32_t rank, world;
+  int32_t pad[2];
+  uint64_t then[2][REG_WORDS];
+};
+__device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, uint64_t &then, int64_t total /* lanes 0..31 */, int64_t *red, uint32_t *abort_flag)
+{
+  const int lane = threadIdx.x & 63;
+  const int world = pb->world;
+  const int64_t other = shfl_xor_i64(total, 32); // lanes 32 .. 63 take the total of slot lane - 32 from the lower half
+  const uint64_t mine = (uint64_t)(lane < REG_SLOTS ? total : other);
+  if (blockIdx.x == 0)
+  {
+    const uint32_t half = lane < REG_SLOTS ? (uint32_t)(mine & 0xffffffffull) : (uint32_t)(mine >> 32);
+    for (int r = 0; r < world; ++r)
+      __hip_atomic_fetch_add(pb->mailbox[r] + (size_t)parity * REG_WORDS + lane, REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  uint64_t *own = pb->mailbox[pb->rank] + (size_t)parity * REG_WORDS + lane;
+  uint64_t w;
+  uint32_t spins = 0;
+  long long t0 = 0;
+  __builtin_amdgcn_s_sleep(REG_FIRST_POLL_SLEEP);
+  for (;;)
+  {
+    w = __hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__all(((w - then) >> 56) == (uint64_t)world)) break;
+    __builtin_amdgcn_s_sleep(REG_POLL_SLEEP);
+    if ((++spins & 1023u) == 0)
+    {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      const bool give_up = now - t0 > REG_BARRIER_TIMEOUT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (__any(give_up))
+      {
+        if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+  const uint64_t sum = (w - then) & REG_SUM_MASK;
+  then = w;
+  const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)sum, 32);
+  if (lane < REG_SLOTS) red[lane] = (int64_t)(sum + (high << 32));
   return true;
 }
 
@@ -893,8 +955,9 @@ struct LoopArgs
   GnCore init;       // the state the loop starts from (by value: no staging copy, no host synchronisation before the launch)
   GnState *state;    // out: state[0] (device copy for ws_reg_poll)
   GnState *result_host; // out: the same in host-mapped memory (the host only waits for the stream, no copy back)
-  uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch
-  uint32_t *abort_flag; // zeroed before the launch
+  uint64_t *accum;   // [2][REG_GROUPS][REG_WORDS] counted group accumulators, zeroed before the launch; the abort flag (zeroed too)
+                     // sits REG_ACCUM_OFFSET bytes in front of them (its own pointer would be the 257th byte of arguments)
+  PeerBlock *peers;  // multi-GPU loop only
   uint32_t *clear_next; // the set of the NEXT launch (abort flag + accumulators): cleared on the way out
   uint32_t clear_words;
   int32_t debug_stall;  // test hook (ws_debug_reg_stall): workgroup 0 keeps its first contribution to itself.  Sits in the padding
@@ -905,16 +968,29 @@ struct LoopArgs
 // kernel takes 7.86 us instead of 6.03 us -- same instructions, and 192 bytes are no faster than 256.  Keep them within 256.
 static_assert(sizeof(LoopArgs) <= 256, "reg_loop_kernel: more than 256 bytes of kernel arguments");
 
+constexpr size_t REG_ACCUM_OFFSET = 256; // accumulators behind the abort flag
+
+// PEERS: this rank's shard of the points, a grid of any multiple of REG_GROUPS workgroups (ranks that share one GPU in the
+// tests split the chip), and the cross-GPU exchange behind the on-chip one
+template <bool PEERS>
 __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
+  const uint32_t n_blocks = PEERS ? gridDim.x : (uint32_t)REG_BLOCKS, stride = n_blocks * REG_THREADS, per_group = n_blocks / REG_GROUPS;
+  uint32_t *const abort_flag = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.accum) - REG_ACCUM_OFFSET);
   __shared__ unsigned long long wg_sum[REG_SLOTS]; // the workgroup's totals of an iteration (LDS atomics of the eight waves)
   __shared__ int64_t red[REG_SLOTS];
   __shared__ alignas(16) float T_sh[16];
   __shared__ int stop_sh;
 
-  const Prefetched pref = prefetch_points(a.pts);
+  const Prefetched pref = prefetch_points(a.pts, stride);
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
+  uint64_t mb_then0 = 0, mb_then1 = 0; // first wave, PEERS: this lane's mailbox words of both parities when last complete
+  if (PEERS && threadIdx.x < 64)
+  {
+    mb_then0 = a.peers->then[0][threadIdx.x];
+    mb_then1 = a.peers->then[1][threadIdx.x];
+  }
   // The loop state is uniform, so the compiler would keep it in scalar registers -- on top of the ~50 the kernel arguments
   // occupy, i.e. spilled to vector lanes and reloaded (v_readlane) in the middle of the first wave's dependency chain,
   // and everything the vector unit computes from it (all of it is float arithmetic) would cross between the two register
@@ -954,7 +1030,10 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
       if (k > 0)
       {
         // totals of iteration k - 1 (parity (k + 1) & 1) straight from the counted accumulators: this IS the grid barrier
-        const bool ok = counted_collect(a.accum + (size_t)((k + 1) & 1) * REG_GROUPS * REG_WORDS, a.abort_flag, then_cur, then_other, red);
+        int64_t total = 0;
+        bool ok = counted_collect(a.accum + (size_t)((k + 1) & 1) * REG_GROUPS * REG_WORDS, abort_flag, then_cur, then_other, red, per_group, &total);
+        if (PEERS && ok) // the ranks' totals -> everybody's mailbox -> the totals over all ranks, in red[]
+          ok = ((k + 1) & 1) ? peer_exchange(a.peers, 1, mb_then1, total, red, abort_flag) : peer_exchange(a.peers, 0, mb_then0, total, red, abort_flag);
         WS_LSTAMP(2);
         if (!ok)
         {
@@ -980,11 +1059,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     const int32_t obx = cache[0].bx, oby = cache[0].by, obz = cache[0].bz;
     const bool ofilled = cache[0].filled;
 #endif
-    accumulate_points<true>(a.pts, T, pref, acc, cache);
+    accumulate_points<true>(a.pts, T, pref, acc, cache, stride);
     WS_LSTAMP(4);
     wave_reduce32_add(acc, wg_sum);
     WS_LSTAMP(5);
-    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0));
+    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0), per_group);
 #ifdef WS_REG_TIMING
     WS_LSTAMP(6);
     for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
@@ -1019,6 +1098,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #endif
   if (blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < a.clear_words; i += REG_THREADS) a.clear_next[i] = 0u; // nobody touches that set during this launch
+  if (PEERS && blockIdx.x == 0 && threadIdx.x < 64 && !st.error)
+  {
+    a.peers->then[0][threadIdx.x] = mb_then0; // where the next launch starts counting
+    a.peers->then[1][threadIdx.x] = mb_then1;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
 #pragma unroll
@@ -1334,22 +1418,21 @@ int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags
 int reg_loop_supported(int device)
 {
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reg_loop_kernel, REG_THREADS, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reg_loop_kernel<false>, REG_THREADS, 0) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
 }
 
 // Two sets of {abort flag, counted accumulators}, used by alternate launches: a launch finds its set zero because the
 // launch before it cleared it on its way out (block 0, after its own loop) -- no memset kernel in front of every launch.
-constexpr size_t REG_ACCUM_OFFSET = 256; // accumulators behind the abort flag
 constexpr size_t REG_ACCUM_BYTES = sizeof(uint64_t) * 2 * REG_GROUPS * REG_WORDS;
 constexpr size_t REG_SET_BYTES = REG_ACCUM_OFFSET + REG_ACCUM_BYTES;
 
-int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const GnCore &init)
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const GnCore &init, bool peers, size_t first, size_t count)
 {
   ws_context *ctx = r->ctx;
   LoopArgs a;
-  a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  a.pts = make_point_args(r, m, res, flags, peers ? first : 0, peers ? count : r->n);
   a.init = init;
   a.state = r->state;
   a.result_host = r->result_host_dev;
@@ -1361,19 +1444,36 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   char *mine = reinterpret_cast<char *>(r->grid_bar) + (r->loop_launches & 1u) * REG_SET_BYTES;
   char *other = reinterpret_cast<char *>(r->grid_bar) + ((r->loop_launches + 1) & 1u) * REG_SET_BYTES;
   r->loop_launches += 1;
-  a.accum = reinterpret_cast<uint64_t *>(mine + REG_ACCUM_OFFSET);
-  a.abort_flag = reinterpret_cast<uint32_t *>(mine);
+  a.accum = reinterpret_cast<uint64_t *>(mine + REG_ACCUM_OFFSET); // (the abort flag is the first word of the set)
+  a.peers = reinterpret_cast<PeerBlock *>(r->peer_block_dev);
   a.clear_next = reinterpret_cast<uint32_t *>(other);
   a.clear_words = (uint32_t)(REG_SET_BYTES / sizeof(uint32_t));
   a.host_flag = r->host_flag_dev;
   a.debug_stall = r->debug_stall_next;
   r->debug_stall_next = 0;
   prof_begin(ctx, WS_K_REG);
-  hipLaunchKernelGGL(reg_loop_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  if (peers)
+    hipLaunchKernelGGL(reg_loop_kernel<true>, dim3((unsigned)r->peer_blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(reg_loop_kernel<false>, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
+
+// host image of PeerBlock (api.hip fills it: the mailbox pointers are peer-mapped or local device addresses)
+size_t reg_peer_block_bytes() { return sizeof(PeerBlock); }
+void reg_peer_block_fill(void *host_image, void *const mailbox[8], int rank, int world)
+{
+  PeerBlock *pb = reinterpret_cast<PeerBlock *>(host_image);
+  std::memset(pb, 0, sizeof(PeerBlock));
+  for (int i = 0; i < 8; ++i) pb->mailbox[i] = reinterpret_cast<uint64_t *>(i < world ? mailbox[i] : nullptr);
+  pb->rank = rank;
+  pb->world = world;
+}
+size_t reg_mailbox_bytes() { return sizeof(uint64_t) * 2 * REG_WORDS; }
+int reg_groups() { return REG_GROUPS; }
+int reg_default_blocks() { return REG_BLOCKS; }
 
 size_t reg_barrier_bytes() { return 2 * REG_SET_BYTES; }
 

@@ -1397,7 +1397,13 @@ __device__ __forceinline__ void for_each_record(uint32_t desc_begin, uint32_t nr
   }
 }
 
-constexpr int RES_MAXR = 8;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
+#ifndef WS_RES_MAXR
+#define WS_RES_MAXR 8
+#endif
+#ifndef WS_RESOLVE_WGS
+#define WS_RESOLVE_WGS 4
+#endif
+constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
 struct TilePre
@@ -1443,7 +1449,7 @@ struct TilePost
 // bytes and descriptors of later tiles and the records of the next tile are all requested together at the END of an
 // iteration, and the stores of a tile are issued right AFTER the next wait, so they drain under the LDS phases.
 template <bool HAS_S0, bool FUSED>
-__global__ __launch_bounds__(256, 4) void tile_resolve_kernel(ResolveArgs a)
+__global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(ResolveArgs a)
 {
   __shared__ unsigned long long kpos[TILE_VOXELS];
   __shared__ unsigned long long kneg[TILE_VOXELS];

@@ -226,6 +226,13 @@ struct ws_reg
   int loop_supported = 0;            // the device holds the whole grid of reg_loop_kernel at once
   int debug_stall_next = 0;          // ws_debug_reg_stall
   int resident_fallbacks = 0;        // registrations redone with one launch per iteration after a barrier timeout
+  // multi-GPU resident loop (ws_reg_peer_*): the ranks' totals meet in mailboxes in each other's HBM
+  void *mailbox = nullptr;           // own mailbox: fine-grained device memory, [2][64] uint64
+  void *peer_mailbox[8] = {};        // every rank's mailbox as this process addresses it ([peer_rank] == mailbox)
+  bool peer_opened[8] = {};          // opened with hipIpcOpenMemHandle (to be closed)
+  void *peer_block_dev = nullptr;    // PeerBlock
+  int peer_rank = 0, peer_world = 0; // 0: not connected
+  int peer_blocks = 0;               // grid of the peer loop on this rank
 };
 
 // scan pre-processing buffers (App::preprocess on the device, scan_preprocess.hip)
@@ -286,7 +293,12 @@ int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, si
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
-int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init);
+int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init, bool peers = false, size_t first = 0, size_t count = 0);
+size_t reg_peer_block_bytes();
+void reg_peer_block_fill(void *host_image, void *const mailbox[8], int rank, int world);
+size_t reg_mailbox_bytes();
+int reg_groups();
+int reg_default_blocks();
 int reg_loop_supported(int device);
 int launch_solve6_test(ws_context *ctx, const double *A_dev, const double *b_dev, size_t n, double *x_dev, int32_t *status_dev);
 size_t reg_barrier_bytes();

@@ -40,6 +40,7 @@ class HipGnBackend:
         reg.ctx.use_torch_stream()
         self.sums = torch.zeros(44, dtype=torch.int64, device="cuda")
         self._pending = False  # iterate(): sums of an iteration whose update has not been applied yet
+        self.peers = None      # (rank, world) once connect_peers() / connect_local() has mapped the mailboxes
 
     def begin(self, T_in, max_iterations, it_weight_gradient, epsilon):
         T = np.ascontiguousarray(np.asarray(T_in, dtype=np.float32).reshape(4, 4).T).reshape(16)
@@ -76,6 +77,51 @@ class HipGnBackend:
         pts = self._L.ws_reg_points_dev(self.reg.handle, C.byref(n))
         return (tuple(int(v) for v in par.reshape(-1)), int(self._L.ws_map_device_data(self.tsdf.device_map(), 0) or 0), int(pts or 0), int(n.value),
                 self.res, self.flags)
+
+    # ---- the loop without the host in it: the ranks' sums meet in mailboxes in each other's HBM (ws_reg_peer_*) ----------
+    def connect_peers(self, group=None, blocks: int = 0):
+        """Once per process group: export this rank's mailbox as an IPC handle, all-gather the handles, map the peers'.
+        `blocks`: workgroups of the resident loop on this rank (0 = 256, one per CU; ranks that share one GPU must split
+        the chip: 256 // ranks-per-GPU).  Afterwards sharded_register_cloud runs ws_register_cloud_peers."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world > 8:
+            raise ValueError("the device-side exchange connects at most 8 ranks (one node); larger groups use the RCCL route")
+        handle = (C.c_ubyte * 64)()
+        check(self._L.ws_reg_peer_mailbox(self.reg.handle, handle), "ws_reg_peer_mailbox")
+        handles = [bytes(handle)]
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+        blob = b"".join(handles)
+        check(self._L.ws_reg_peer_connect(self.reg.handle, rank, world, blob, int(blocks)), "ws_reg_peer_connect")
+        if world > 1:
+            dist.barrier(group=group)  # every mailbox is mapped (and zero) before anybody's first launch
+        self.peers = (rank, world)
+
+    def connect_local(self, backends, rank: int, blocks: int = 0):
+        """the same for several HipGnBackend objects of ONE process (tests: several contexts on one GPU), without IPC"""
+        arr = (C.c_void_p * len(backends))(*[b.reg.handle for b in backends])
+        check(self._L.ws_reg_peer_connect_local(self.reg.handle, rank, len(backends), arr, int(blocks)), "ws_reg_peer_connect_local")
+        self.peers = (rank, len(backends))
+
+    def reset_peers(self):
+        check(self._L.ws_reg_peer_reset(self.reg.handle), "ws_reg_peer_reset")
+
+    def register_peers(self, first: int, count: int, T_in, max_iterations, it_weight_gradient, epsilon):
+        """ws_register_cloud_peers: the whole Gauss-Newton loop in one launch per rank.  Returns (T 4x4, iterations), or None
+        if the exchange with the peers timed out (WS_ERR_TIMEOUT)."""
+        T = np.ascontiguousarray(np.asarray(T_in, dtype=np.float32).reshape(4, 4).T).reshape(16)
+        out = np.empty(16, dtype=np.float32)
+        it = C.c_int32(0)
+        rc = self._L.ws_register_cloud_peers(self.reg.handle, self.tsdf.device_map(), int(first), int(count), T.ctypes.data_as(C.c_void_p),
+                                             int(max_iterations), C.c_float(it_weight_gradient), C.c_float(epsilon), self.res, self.flags,
+                                             out.ctypes.data_as(C.c_void_p), C.byref(it))
+        if rc == -6:  # WS_ERR_TIMEOUT
+            return None
+        check(rc, "ws_register_cloud_peers")
+        return out.reshape(4, 4).T.copy(), int(it.value)
 
     def poll(self):
         fin, it = C.c_int32(0), C.c_int32(0)
@@ -207,6 +253,24 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     first, count = shard_range(n_points, rank, world)
+    if getattr(backend, "peers", None) is not None and backend.peers[1] == world:
+        # the resident loop on every rank, sums exchanged device to device: one launch per registration
+        res = backend.register_peers(first, count, T_in, max_iterations, it_weight_gradient, epsilon)
+        ok = res is not None
+        if world > 1:  # a time-out is seen by every rank, but agree before anyone takes the other route
+            import torch
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if dist.get_backend(group) != "gloo":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(int(flag.item()))
+        if ok:
+            return res
+        import sys
+        print("[warpsense_amd.dist] the device-side exchange timed out; this registration runs through the all-reduce route", file=sys.stderr)
+        backend.reset_peers()
+        if world > 1:
+            dist.barrier(group=group)
     runner = None
     if graphs is not None:
         key = (first, count, batch) + (backend.binding() if hasattr(backend, "binding") else ())
