@@ -9,8 +9,11 @@ One step = one synthetic OS1-128 scan (131 072 points) through
     TSDFCuda::update_tsdf  (ray-march scatter + integrate into the 513^3 map @ 50 mm)  and
     TSDFRegistration::register_cloud (Gauss-Newton to convergence against that map),
 with the scan already resident in HBM.  N > 1: every rank keeps a replica of the map and applies the full
-scan; the registration points are sharded by index and the 44-word normal equations are all-reduced over
-RCCL each iteration — total work is fixed, so "scaling" is "strong".
+scan; the registration points are sharded by index and the ranks' 44-word normal equations meet every iteration
+-- device to device through mailboxes in each other's HBM (the resident loop of ws_register_cloud_peers; RCCL
+all-reduce per iteration as the fallback) — total work is fixed, so "scaling" is "strong".
+The same line also carries `replica_scans_per_s`: N independent sensor streams, one per GPU (weak scaling, the
+deployment DESIGN.md §6 recommends for clouds of this size), clearly labelled and never used as `value`.
 
 Rank 0 prints ONE JSON line (see the driver contract); extra keys: roofline, cpu_baseline, kernels.
 """
@@ -46,22 +49,20 @@ def parse():
 def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
     """The reference's CPU path (port, oracle/cpu_baseline.cpp) on this box's host cores, one scan of the same workload:
     (i)  update_tsdf with thread_count = 1 (src/cpu/update_tsdf.cpp:397-564, what src/cpu/fastsense.cpp:172 calls),
-    (ii) the OpenMP overload (:566-724) at 8 threads and at all cores,
-    (iii) register_cloud (src/cpu/registration.cpp:14-177) at 8 threads and at all cores.
-    Median of the timed runs after one warm-up each; `value` uses the fastest update variant + the fastest registration."""
+    (ii) the OpenMP overload (:566-724) at 8 and at 32 threads,
+    (iii) register_cloud (src/cpu/registration.cpp:14-177) at 8 and at 32 threads.
+    Protocol (bounded to ~40 s): every variant runs once as a probe (which is also its warm-up: page faults of the
+    513^3 map, OpenMP thread start); the fastest update variant is then timed 3 more times and `value` uses the MEDIAN OF THOSE
+    WARMED SAMPLES (the probe is reported, not counted); the 1-thread variant gets one warmed sample; registration variants
+    one warm-up + 3 samples each."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     ncpu = os.cpu_count() or 1
 
-    def timed(fn, runs, warm=1):
-        for _ in range(warm):
-            fn()
-        ts = []
-        for _ in range(runs):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)), ts
+    def once(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
 
     samples = {}
     m = O.OracleMap(size, tau, 0)
@@ -70,19 +71,21 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
         m.data[:] = O.pack(tau, 0)
         return O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=threads)
 
-    # (the port's per-thread hash maps are merged serially: beyond a few dozen threads it only gets slower — 256 threads
-    # took 37 s per scan on the MI355X host — so "all cores" is capped at 32)
+    # (the port's per-thread hash maps are merged serially: beyond a few dozen threads it only gets slower -- 256 threads
+    # took 37 s per scan on the MI355X host -- so the widest variant is 32 threads)
     many = min(ncpu, 32)
-    variants = [("update_1_thread", 1, 3), ("update_8_threads", min(8, ncpu), 2)]
+    variants = [("update_1_thread", 1), ("update_8_threads", min(8, ncpu))]
     if many > 8:
-        variants.append((f"update_{many}_threads", many, 1))
-    best_upd = None
-    for name, th, runs in variants:
-        med, ts = timed(lambda th=th: upd(th), runs, warm=1 if th == 1 else 0)
-        samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th}
-        if best_upd is None or med < best_upd[0]:
-            best_upd = (med, th, name)
-    upd(best_upd[1])  # the map the registration runs against
+        variants.append((f"update_{many}_threads", many))
+    probes = {name: once(lambda th=th: upd(th)) for name, th in variants}
+    best_name, best_th = min(variants, key=lambda v: probes[v[0]])
+    for name, th in variants:
+        runs = 3 if name == best_name else (1 if th == 1 else 0)
+        ts = [once(lambda th=th: upd(th)) for _ in range(runs)]
+        samples[name] = {"median_s": float(np.median(ts)) if ts else None, "runs_s": [round(t, 3) for t in ts], "probe_s": round(probes[name], 3),
+                         "threads": th, "warmed_samples": len(ts)}
+    best_upd = samples[best_name]["median_s"]
+    upd(best_th)  # the map the registration runs against
     it_box = []
 
     def reg(threads):
@@ -90,19 +93,23 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
         it_box.append(it)
 
     best_reg = None
-    reg_variants = [("register_8_threads", min(8, ncpu), 2)]
+    reg_variants = [("register_8_threads", min(8, ncpu))]
     if many > 8:
-        reg_variants.append((f"register_{many}_threads", many, 2))
-    for name, th, runs in reg_variants:
-        med, ts = timed(lambda th=th: reg(th), runs, warm=0)
-        samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th, "iterations": it_box[-1]}
+        reg_variants.append((f"register_{many}_threads", many))
+    for name, th in reg_variants:
+        once(lambda th=th: reg(th))
+        ts = [once(lambda th=th: reg(th)) for _ in range(3)]
+        med = float(np.median(ts))
+        samples[name] = {"median_s": med, "runs_s": [round(t, 3) for t in ts], "threads": th, "iterations": it_box[-1], "warmed_samples": 3}
         if best_reg is None or med < best_reg[0]:
             best_reg = (med, th, name)
-    return {"value": 1.0 / (best_upd[0] + best_reg[0]), "unit": "scans/s", "cores": int(max(best_upd[1], best_reg[1])), "kind": "port",
-            "sample": f"1 scan of the same workload ({points.shape[0]} points, {size[0] + 1 - size[0] % 2}^3 map): fastest update variant "
-                      f"{best_upd[2]} {best_upd[0]:.2f} s + fastest registration {best_reg[2]} {best_reg[0]:.2f} s; medians of all variants in `variants`",
+    one = samples["update_1_thread"]["median_s"] or samples["update_1_thread"]["probe_s"]
+    return {"value": 1.0 / (best_upd + best_reg[0]), "unit": "scans/s", "cores": int(max(best_th, best_reg[1])), "host_cpus": ncpu, "kind": "port",
+            "sample": f"1 scan of the same workload ({points.shape[0]} points, {size[0] + 1 - size[0] % 2}^3 map): median of 3 warmed runs of the "
+                      f"fastest update variant {best_name} {best_upd:.2f} s + median of 3 warmed runs of {best_reg[2]} {best_reg[0]:.2f} s; "
+                      f"all variants (probe + warmed runs) in `variants`",
             "variants": samples,
-            "update_1_thread_scans_per_s": 1.0 / (samples["update_1_thread"]["median_s"] + best_reg[0])}
+            "update_1_thread_scans_per_s": 1.0 / (one + best_reg[0])}
 
 
 def main():
@@ -157,6 +164,16 @@ def main():
     eye = np.eye(4, dtype=np.float32)
     backend = HipGnBackend(reg, tsdf, res)
     force_sharded = os.environ.get("WS_BENCH_FORCE_SHARDED") == "1"  # exercise the multi-rank driver on one rank
+    exchange = "single GPU"
+    if world > 1:
+        exchange = "RCCL all-reduce of 44 int64 per iteration (host-driven launches)"
+        if os.environ.get("WS_BENCH_NO_PEERS") != "1":
+            try:
+                backend.connect_peers()  # mailboxes exported / mapped with hipIpc: the loop runs without the host in it
+                exchange = "device-side: counted mailboxes in the peers' HBM over xGMI, one resident launch per registration"
+            except Exception as exc:  # no peer mapping on this node: the RCCL route still works
+                print(f"[bench] device-side exchange unavailable ({exc!r}); using the RCCL route", file=sys.stderr)
+                backend.peers = None
     reg.prepare_registration(d_pert)
     its = []
 
@@ -297,6 +314,62 @@ def main():
         except Exception as exc:  # RCCL unavailable on this box: report why, keep the bench line
             sharded_1rank = {"error": repr(exc)[:200]}
 
+    # N independent sensor streams, one per GPU (replicas: no exchange at all) -- reported NEXT TO the strong-scaling value
+    replica = None
+    if world > 1 and not args.no_registration:
+        def replica_step():
+            tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
+            reg.prepare_registration(d_pert)
+            reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
+        for _ in range(2):
+            replica_step()
+        fence()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            replica_step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        replica = world * args.steps / float(t.item())
+
+    # The multi-GPU loop with the device-side exchange, exercised on this ONE GPU: two ranks (own contexts / streams, 128
+    # resident workgroups each) register the same cloud, every rank its half of the points, the 44 sums through mailboxes.
+    sharded_2rank = None
+    if world == 1 and not force_sharded and not args.no_registration and os.environ.get("WS_BENCH_SKIP_SHARDED") != "1":
+        # (a process of its own, tools/peer_bench.py: this one already drives torch / RCCL streams, and the ranks' kernels
+        # must be on the chip together)
+        try:
+            import subprocess
+            fence()
+            r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_bench.py"), "--ranks", "2", "--map", str(args.map)],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            lines = [l for l in r2.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            sharded_2rank = json.loads(lines[-1]) if lines else {"error": r2.stderr.decode(errors="replace")[-300:]}
+        except Exception as exc:
+            sharded_2rank = {"error": repr(exc)[:200]}
+
+    # host buffers (H2D of the scan reported separately, never part of `value`): 1.5 MB pageable / pinned -> HBM
+    h2d = None
+    if rank == 0:
+        try:
+            host_pts = torch.from_numpy(points)
+            pinned = host_pts.pin_memory()
+            dst = torch.empty_like(d_points)
+
+            def copy_us(src):
+                ts = []
+                for _ in range(12):
+                    torch.cuda.synchronize()
+                    t5 = time.perf_counter()
+                    dst.copy_(src, non_blocking=False)
+                    torch.cuda.synchronize()
+                    ts.append(1e6 * (time.perf_counter() - t5))
+                return float(np.median(ts[2:]))
+            h2d = {"bytes": int(host_pts.numel() * 4), "pageable_us": copy_us(host_pts), "pinned_us": copy_us(pinned),
+                   "note": "what ws_tsdf_update (host scan, update_tsdf.cu:152-154) adds in front of the first kernel; not in `value`"}
+        except Exception as exc:
+            h2d = {"error": repr(exc)[:200]}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -316,9 +389,11 @@ def main():
         tsdf_kernels = [k for k in kernels if k in scatter_classes or k == "integrate"]
         dom = max(tsdf_kernels, key=lambda k: kernels[k]["avg_us"])
         traffic = None
+        traffic_source = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 tj = json.load(fh)
+                traffic_source = "profiles/pmc_traffic.json@" + str(tj.get("git_sha", "unknown")) + " (PMC passes of tools/profile_r03.sh, not measured in this run)"
                 mode_key = "dense" if args.integrate == "dense" else "sparse"
                 # HBM bytes of the whole kernel group the achieved figure is computed over (PMC passes, tools/make_traffic.py)
                 traffic = tj.get(f"integrate:{mode_key}") if dom == "integrate" else tj.get(f"scatter_total:{mode_key}")
@@ -331,13 +406,13 @@ def main():
             # the scatter's bytes belong to its kernels TOGETHER (set-up, both marches, binning, tile resolve with the fused
             # integrate, bookkeeping pass): one event pair per scan of the timed region around all of them
             grp_bytes, grp_us, grp = b_scatter + b_integrate, update_span_us, [k for k in scatter_classes if k in kernels]
-            timing = "one hipEvent pair per scan of the timed region around all kernels of the update (incl. its bookkeeping pass)"
+            timing = "one hipEvent pair per scan of the timed region around all kernels of the update"
         else:
             grp_bytes, grp_us, grp = b_scatter, t_scatter, [k for k in scatter_classes if k in kernels]
             timing = "sum of the per-class hipEvent pairs (separate pass)"
         achieved = grp_bytes / (grp_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "kernel_group": grp, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": grp_bytes,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": grp_bytes,
                     "avg_launch_us": grp_us, "timing": timing, "dominant_kernel_us": kernels[dom]["avg_us"],
                     "per_class_sum_us": t_scatter,
                     "note": "VALU-bound ray march (DESIGN.md §5); bytes = SURVEY §8d's scatter term" + (" + fused integrate" if fused else "")}
@@ -372,17 +447,22 @@ def main():
                    "registration": "skipped" if args.no_registration else
                    {"max_iterations": reg_params[0], "it_weight_gradient": reg_params[1], "epsilon": reg_params[2],
                     "iterations_per_scan": float(np.mean(its)) if its else None},
-                   "parallelism": "single GPU" if world == 1 else f"map replicated, registration points sharded x{world}, "
-                                                                   "RCCL all-reduce of 44 int64 per iteration",
+                   "parallelism": "single GPU" if world == 1 else f"map replicated, registration points sharded x{world}; exchange: {exchange}",
                    "contested_voxels": stats["contested_voxels"], "tiles_streamed": stats["tiles"], "tail_records": stats["records"],
                    "record_runs": stats["runs"]},
         "roofline": roofline,
         "kernels": kernels,
         "sharded_1rank_scans_per_s": sharded_1rank["scans_per_s"] if sharded_1rank and "scans_per_s" in sharded_1rank else None,
         "sharded_1rank": sharded_1rank,
+        "sharded_2rank_1gpu": sharded_2rank,
+        "replica_scans_per_s": replica,
+        "replica_note": None if replica is None else f"{world} independent streams, one per GPU, no exchange (weak scaling); `value` is the point-sharded run",
+        "h2d_scan": h2d,
     }
     if roofline is not None and dense_eq is not None:
         roofline["dense_equivalent"] = dense_eq
+    if h2d and "pageable_us" in h2d:
+        out["scans_per_s_with_pageable_h2d"] = 1.0 / (elapsed / args.steps + 1e-6 * h2d["pageable_us"])
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(points, perturbed, size, tau, mw, res, reg_params)
     else:

@@ -333,3 +333,21 @@ def test_peer_mailbox_loop_two_processes_over_ipc(drop):
     got = sorted(q_out.get(timeout=10) for _ in range(2))
     for rank, ok, it, it_o in got:
         assert ok and it == it_o > 5, (rank, ok, it, it_o)
+
+
+def test_peer_mailbox_loop_eight_ranks_on_one_gpu():
+    """world = 8, the size of a node: eight ranks x 32 resident workgroups share cuda:0 (tools/peer_bench.py in a process of its
+    own with 16 hardware queues, so that all eight kernels are on the chip together), the benchmark cloud of 131 072 points on the
+    513^3 map: every rank ends with the one-rank resident loop's iteration count and pose, bit for bit"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "peer_bench.py"), "--ranks", "8", "--reps", "3"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert lines, r.stderr.decode(errors="replace")[-2000:]
+    out = json.loads(lines[-1])
+    assert "error" not in out, out
+    assert out["ranks"] == 8 and out["same_result_as_one_rank"] is True and out["iterations"] > 5

@@ -905,7 +905,9 @@ struct PeerBlock
 {
   uint64_t *mailbox[8]; // [rank] -> that rank's mailbox: [2 parities][REG_WORDS]
   int32_t rank, world;
-  int32_t pad[2];
+  uint32_t exchanges; // exchanges completed by all launches so far: the mailbox parity CONTINUES across launches (a rank that
+                      // is already in the next registration adds into the parity its slower peers are NOT still polling)
+  int32_t pad;
   uint64_t then[2][REG_WORDS];
 };
 __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, uint64_t &then, int64_t total /* lanes 0..31 */, int64_t *red, uint32_t *abort_flag)
@@ -986,10 +988,12 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
   uint64_t mb_then0 = 0, mb_then1 = 0; // first wave, PEERS: this lane's mailbox words of both parities when last complete
+  uint32_t mb_base = 0;                // exchanges before this launch
   if (PEERS && threadIdx.x < 64)
   {
     mb_then0 = a.peers->then[0][threadIdx.x];
     mb_then1 = a.peers->then[1][threadIdx.x];
+    mb_base = a.peers->exchanges;
   }
   // The loop state is uniform, so the compiler would keep it in scalar registers -- on top of the ~50 the kernel arguments
   // occupy, i.e. spilled to vector lanes and reloaded (v_readlane) in the middle of the first wave's dependency chain,
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
         int64_t total = 0;
         bool ok = counted_collect(a.accum + (size_t)((k + 1) & 1) * REG_GROUPS * REG_WORDS, abort_flag, then_cur, then_other, red, per_group, &total);
         if (PEERS && ok) // the ranks' totals -> everybody's mailbox -> the totals over all ranks, in red[]
-          ok = ((k + 1) & 1) ? peer_exchange(a.peers, 1, mb_then1, total, red, abort_flag) : peer_exchange(a.peers, 0, mb_then0, total, red, abort_flag);
+          ok = ((mb_base + k - 1) & 1) ? peer_exchange(a.peers, 1, mb_then1, total, red, abort_flag) : peer_exchange(a.peers, 0, mb_then0, total, red, abort_flag);
         WS_LSTAMP(2);
         if (!ok)
         {
@@ -1102,6 +1106,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   {
     a.peers->then[0][threadIdx.x] = mb_then0; // where the next launch starts counting
     a.peers->then[1][threadIdx.x] = mb_then1;
+    if (threadIdx.x == 0) a.peers->exchanges = mb_base + k; // k exchanges in this launch (the same number on every rank)
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
