@@ -229,6 +229,11 @@ int ws_register_cloud_peers(ws_reg *reg, const ws_map *map, size_t first, size_t
  * x n x 6, status n (0, or -1 for a singular matrix). Host pointers; synchronises. */
 int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status);
 
+/* Diagnostics: the per-workgroup statistics slots of the last TSDF update (records per tail workgroup; with a library built
+ * with -DWS_TAIL_TIMING also start / middle / end of every tail workgroup on the 100 MHz wall clock at +16384 / +32768 / +49152;
+ * tools/tail_schedule.py).  Synchronises. */
+int ws_debug_block_stats(ws_map *map, uint32_t *out, size_t words);
+
 /* Test entry: make the NEXT resident registration of `reg` lose one workgroup's contribution to the first exchange, as if
  * another kernel kept that workgroup off the chip: the exchange times out (0.25 s) and ws_register_cloud repeats the
  * registration with one launch per iteration. *fallbacks (may be NULL) receives how often that has happened on `reg`. */

@@ -1187,6 +1187,15 @@ int ws_reg_set_loop(ws_reg *r, int mode)
   return WS_OK;
 }
 
+int ws_debug_block_stats(ws_map *m, uint32_t *out, size_t words)
+{
+  if (!m || !out) return invalid("ws_debug_block_stats: NULL argument");
+  if (words > WS_BLOCK_STATS) words = WS_BLOCK_STATS;
+  WS_HIP(hipMemcpyAsync(out, m->block_stats, words * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
+  WS_HIP(hipStreamSynchronize(m->ctx->stream));
+  return WS_OK;
+}
+
 int ws_debug_reg_stall(ws_reg *r, int32_t stall_next, int32_t *fallbacks)
 {
   if (!r) return invalid("ws_debug_reg_stall: NULL argument");

@@ -87,6 +87,13 @@ constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTE
 #ifndef WS_FUSE_PLACE
 #define WS_FUSE_PLACE 1 // 1: tile scan and descriptor placement in one launch
 #endif
+#ifndef WS_TAIL_PERSISTENT
+#define WS_TAIL_PERSISTENT 0 // (measured: 216-222 us against 187-195 us for one workgroup per item: resident workgroups run in lock step and their sort phases collide)
+//  1: the tail march runs as resident workgroups that take (64 rays x 4 parts) items from a counter
+#endif
+#ifndef WS_FREE_PIPE
+#define WS_FREE_PIPE 1 // 1: the voxel byte of a free-space candidate is requested one emit phase before it is used (126 -> 122 us)
+#endif
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
@@ -492,7 +499,8 @@ typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate 
 
 // A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
 // quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
-__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
+// one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails
+__device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
   __shared__ uint32_t s_cursor, s_base, s_ub, s_overflow, s_desc_base, s_round_total;
   __shared__ uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_cur[HT_SLOTS];
@@ -500,10 +508,8 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
   __shared__ u32x4 s_queue[4 * TAIL_QCAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n_sorted = a.az_off[AZ_BINS];
-  // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
-  const uint32_t slot = (blockIdx.x / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
-  const int part0 = (int)(blockIdx.x % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
+  const uint32_t slot = (item / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
+  const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
   const bool has_ray = slot < n_sorted;
   uint32_t ix = 0;
   RaySetup r;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
   const uint32_t ub_total = s_ub;
 
 #ifdef WS_TAIL_TIMING
-  const long long tt0 = clock64();
+  const long long tt0 = wall_clock64(); // 100 MHz, the same clock on every CU: start / middle / end per workgroup -> ws_debug_block_stats
 #endif
   // ---- phase 1: march, one record per scatter target
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
@@ -616,63 +622,57 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
     uint32_t qhead = 0, qtail = 0;
     const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
     const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
-    AxisRun wx, wy, wz;
-    wx.r = wx.ar = wx.aq = wx.q = wx.spos = wx.sm = 0;
-    wx.gap = 0x3fffffff;
-    wy = wx;
-    wz = wx;
-    int32_t k = k0;
-    bool first = false; // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71)
+    AxisRun ix0, iy0, iz0;
+    ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
+    ix0.gap = 0x3fffffff;
+    iy0 = ix0;
+    iz0 = ix0;
+    int32_t k = k0; // the next sample of this lane
     if (work)
     {
       const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-      run_init(wx, f, r, r.dx, f.posx, kinit, true);
-      run_init(wy, f, r, r.dy, f.posy, kinit, true);
-      run_init(wz, f, r, r.dz, f.posz, kinit, false);
-      if (k0 == 0) first = div_res(run_proj(wx, false, res), f) != 0 || div_res(run_proj(wy, false, res), f) != 0;
+      run_init(ix0, f, r, r.dx, f.posx, kinit, true);
+      run_init(iy0, f, r, r.dy, f.posy, kinit, true);
+      run_init(iz0, f, r, r.dz, f.posz, kinit, false);
     }
-    bool alive = work;
-    for (;;)
+    // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
+    AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
+    auto push = [&](bool cand, bool cx, bool cy) {
+      const unsigned long long mask = __ballot(cand);
+      if (mask == 0) return;
+      if (cand)
+      {
+        u32x4 e;
+        e.x = (uint32_t)fast_proj(wx, cx, res);
+        e.y = (uint32_t)fast_proj(wy, cy, res);
+        e.z = (uint32_t)fast_proj(wz, false, res);
+        e.w = (uint32_t)k | ((uint32_t)lane << 16);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
+      }
+      qtail += (uint32_t)__popcll(mask);
+    };
     {
-      const bool any_alive = __any(alive);
+      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk starts: out
+      // of the loop, so that every iteration is "step, then test"
+      bool first = false;
+      if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
+      push(first, false, false);
+      if (work && k0 == 0) k = 1;
+    }
+    int32_t todo = work ? k1 - k : 0;
+    for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
+    const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
+    for (int32_t it = 0;; ++it)
+    {
+      const bool any_alive = it < n_iter;
       if (any_alive)
       {
         // ---- sample phase
-        bool cand = false, cx = false, cy = false;
-        if (alive)
-        {
-          if (k == 0)
-          {
-            cand = first;
-          }
-          else
-          {
-            cx = run_step(wx, dist, res);
-            cy = run_step(wy, dist, res);
-            run_step_z(wz, dist);
-            cand = cx || cy;
-          }
-        }
-        const unsigned long long mask = __ballot(cand);
-        if (mask)
-        {
-          if (cand)
-          {
-            u32x4 e;
-            e.x = (uint32_t)run_proj(wx, cx, res);
-            e.y = (uint32_t)run_proj(wy, cy, res);
-            e.z = (uint32_t)run_proj(wz, false, res);
-            e.w = (uint32_t)k | ((uint32_t)lane << 16);
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
-          }
-          qtail += (uint32_t)__popcll(mask);
-        }
-        if (alive)
-        {
-          k += 1;
-          alive = k < k1;
-        }
+        const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
+        fast_step_z(wz);
+        push((cx || cy) && k < k1, cx, cy);
+        k += 1;
       }
       // ---- emit phase: 64 queued samples, one per lane
       const uint32_t cnt = qtail - qhead;
@@ -725,15 +725,18 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
       if (!any_alive && qtail == qhead) break;
     }
   }
-#ifdef WS_TAIL_TIMING
-  const long long tt1 = clock64();
-#endif
   __syncthreads();
 #ifdef WS_TAIL_TIMING
-  const long long tt2 = clock64();
+  const long long tt2 = wall_clock64();
+  if (threadIdx.x == 0)
+  {
+    a.tail_stats[16384 + item] = (uint32_t)tt0;
+    a.tail_stats[32768 + item] = (uint32_t)tt2;
+    a.tail_stats[49152 + item] = (uint32_t)tt2;
+  }
 #endif
   const uint32_t total = min(s_cursor, ub_total);
-  if (threadIdx.x == 0) a.tail_stats[blockIdx.x] = total;
+  if (threadIdx.x == 0) a.tail_stats[item] = total;
   if (total == 0) return;
 
   // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
@@ -869,13 +872,31 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
     if (threadIdx.x == 0) s_overflow = 0;
   }
 #ifdef WS_TAIL_TIMING
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) a.tail_stats[49152 + item] = (uint32_t)wall_clock64();
+#endif
+}
+
+// Persistent workgroups (as many as the chip holds at once) that take work items from a counter: a launch of one workgroup
+// per item spent a third of its time ramping up and draining (tools/tail_schedule.py: 4096 workgroups of 48 us each over 1536
+// slots finished after 190 us, the sum of their durations over the slots is 127 us) -- items differ by 10x in work.
+__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
+{
+  __shared__ uint32_t s_item;
+  // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
+  const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
+#if WS_TAIL_PERSISTENT
+  for (;;)
   {
-    // durations (16-cycle units) behind the per-workgroup record counts: summarised once per scan by finish_update_kernel
-    const long long t_end = clock64();
-    a.tail_stats[32768 + blockIdx.x] = (uint32_t)((t_end - tt0) >> 4);
-    a.tail_stats[49152 + blockIdx.x] = (uint32_t)((t_end - tt2) >> 4);
+    if (threadIdx.x == 0) s_item = atomicAdd(&a.counters->tail_next, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= n_items) break;
+    tail_item(a, item);
+    __syncthreads(); // everybody is done with the item's LDS state (and has read s_item)
   }
+#else
+  if (blockIdx.x < n_items) tail_item(a, blockIdx.x);
 #endif
 }
 
@@ -884,27 +905,50 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fk_hash(unsigned long long idx, int32_t shift) { return (uint32_t)((idx * 0x9E3779B97F4A7C15ull) >> shift); }
 
-// what a free-space candidate does to its voxel (vx, vy, vz in world voxel coordinates, inside the window)
-__device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz)
+// What a free-space candidate does to its voxel, in two halves: the byte of the voxel is REQUESTED when the candidate is
+// popped from the queue and USED one emit phase later.  The free pass is not bound by instruction issue alone: shortening
+// the sample phase from ~115 to ~60 instructions moved it from 137 to 126 us, taking this load's round trip off the wave's
+// path to 122 us; what remains is the scattered byte traffic itself (21 M byte loads, 9 M byte stores, one cache line each).
+struct FreePending
+{
+  int64_t idx;   // voxel (storage index)
+  uint32_t tile;
+  uint32_t ix;   // ray
+  int32_t k;     // ray step
+  uint32_t b;    // the voxel's byte (in flight until the next emit phase)
+  bool valid;
+};
+__device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFrame &f, FreePending &p, bool valid, uint32_t ix, int32_t k, int32_t vx, int32_t vy,
+                                             int32_t vz)
 {
   const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
                 sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-  const int64_t idx = storage_index(a.map, sx, sy, sz);
-  const uint8_t b = a.vstate[idx];
+  p.valid = valid;
+  p.idx = valid ? storage_index(a.map, sx, sy, sz) : 0; // unconditional (clamped) load: nothing waits for it here
+  p.tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+  p.ix = ix;
+  p.k = k;
+  p.b = a.vstate[p.idx];
+}
+__device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p)
+{
+  if (!p.valid) return;
+  const int64_t idx = p.idx;
+  const uint32_t b = p.b;
   if (b & VOX_KEYED)
   {
     // the voxel also has ordered candidates (from the tails): this one takes part in the key order.  Only the
     // earliest free-space candidate of a voxel can matter (a later one meets a state that is at least as final).
     if (!(b & VOX_FREEHIT)) a.vstate[idx] = VOX_KEYED | VOX_FREEHIT;
-    const unsigned long long t = order_key(ix, k, 0);
+    const unsigned long long t = order_key(p.ix, p.k, 0);
     uint32_t h = fk_hash((unsigned long long)idx, a.fk_shift);
     bool done = false;
-    for (int p = 0; p < 128 && !done; ++p)
+    for (int q = 0; q < 128 && !done; ++q)
     {
       const unsigned long long cur = a.fk_keys[h];
       unsigned long long old = cur;
       if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
-      if (old == KEY_INF) // claimed: one bit per slot behind the hash tells the clean-up after the scan where to look
+      if (old == KEY_INF) // claimed: one bit per slot behind the hash tells the next scan's set-up where to clean
         atomicOr(&reinterpret_cast<uint32_t *>(a.fk_keys + 2 * ((size_t)a.fk_mask + 1))[h >> 5], 1u << (h & 31u));
       if (old == KEY_INF || old == (unsigned long long)idx)
       {
@@ -917,11 +961,19 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
   }
   else if (b == 0)
   {
-    // free space only (the common case): the result will be (tau, 64) whoever comes first
+    // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
+    // whose loads both saw 0 both store: idempotent.)
     a.vstate[idx] = VOX_TOUCHED;
-    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    if (a.tile_dirty[tile] == 0) a.tile_dirty[tile] = 1;
+    // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured)
+    if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
   }
+}
+// both halves at once (general walk)
+__device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz)
+{
+  FreePending p;
+  free_request(a, f, p, true, ix, k, vx, vy, vz);
+  free_finish(a, p);
 }
 
 constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
@@ -972,102 +1024,103 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
   u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
   uint32_t qhead = 0, qtail = 0;
   const int32_t res = f.res, half = f.half, dist = r.distance;
-  AxisRun wx, wy, wz;
-  wx.r = wx.ar = wx.aq = wx.q = wx.spos = wx.sm = 0;
-  wx.gap = 0x3fffffff;
-  wy = wx;
-  wz = wx;
-  int32_t k = k0;
-  bool first = false; // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71)
+  // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
+  // previous emit phase, then pop the next batch and request its bytes
+  FreePending pend;
+  pend.valid = false;
+  pend.idx = 0;
+  pend.tile = pend.ix = pend.b = 0;
+  pend.k = 0;
+  auto emit = [&]() {
+#if WS_FREE_PIPE
+    free_finish(a, pend);
+#endif
+    const uint32_t cnt = qtail - qhead;
+    const uint32_t n = cnt < 64 ? cnt : 64;
+    u32x4 e = {0, 0, 0, 0};
+    const bool has = (uint32_t)lane < n;
+    if (has) e = queue[(qhead + (uint32_t)lane) & (FREE_QCAP - 1)];
+    const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
+    free_request(a, f, pend, has, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
+#if !WS_FREE_PIPE
+    free_finish(a, pend);
+    pend.valid = false;
+#endif
+    qhead += n;
+  };
+  AxisRun ix0, iy0, iz0;
+  ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
+  ix0.gap = 0x3fffffff;
+  iy0 = ix0;
+  iz0 = ix0;
+  int32_t k = k0; // the next sample of this lane
   if (work)
   {
     const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-    run_init(wx, f, r, r.dx, f.posx, kinit, true);
-    run_init(wy, f, r, r.dy, f.posy, kinit, true);
-    run_init(wz, f, r, r.dz, f.posz, kinit, false);
-    if (k0 == 0)
+    run_init(ix0, f, r, r.dx, f.posx, kinit, true);
+    run_init(iy0, f, r, r.dy, f.posy, kinit, true);
+    run_init(iz0, f, r, r.dz, f.posz, kinit, false);
+  }
+  AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
+  int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
+  // target of the single on-ray candidate of a free-space sample (update_tsdf.cu:103-112 with iter_steps == 1): the sample
+  // minus the fan base offset, which changes every 328 mm of ray
+  auto push = [&](bool cand, bool cx, bool cy, int32_t dzl) {
+    const unsigned long long mask = __ballot(cand);
+    if (mask == 0) return;
+    if (cand)
     {
-      const int32_t px = run_proj(wx, false, res), py = run_proj(wy, false, res);
+      const int32_t px = fast_proj(wx, cx, res), py = fast_proj(wy, cy, res), pz = fast_proj(wz, false, res);
+      const int32_t delta_z = dzl >> 15; // (DZ_PER_DISTANCE * len) >> 15, len > 0; no fan in the free-space part: delta_z * 2 < res
+      if (delta_z != last_dz)
+      {
+        last_dz = delta_z;
+        c0x = trunc_shift15(delta_z * r.ivx);
+        c0y = trunc_shift15(delta_z * r.ivy);
+        c0z = trunc_shift15(delta_z * r.ivz);
+      }
+      u32x4 e;
+      e.x = (uint32_t)(px - c0x);
+      e.y = (uint32_t)(py - c0y);
+      e.z = (uint32_t)(pz - c0z);
+      e.w = (uint32_t)k | ((uint32_t)lane << 16);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      queue[(qtail + rank) & (FREE_QCAP - 1)] = e;
+    }
+    qtail += (uint32_t)__popcll(mask);
+  };
+  // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk was initialised:
+  // taken out of the loop, so that every iteration below is "step, then test"
+  {
+    bool first = false;
+    if (work && k0 == 0)
+    {
+      const int32_t px = fast_proj(wx, false, res), py = fast_proj(wy, false, res);
       first = div_trunc(px, f.rM, f.rK, res) != 0 || div_trunc(py, f.rM, f.rK, res) != 0;
     }
+    push(first, false, false, DZ_PER_DISTANCE); // len == 1
+    if (work && k0 == 0) k = 1;
   }
-  int32_t len = 1 + k * half;
-  int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
-  bool alive = work;
-  for (;;)
+  // iterations of the wave: the longest lane (uniform: the loop itself is scalar)
+  int32_t todo = work ? k1 - k : 0;
+  for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
+  const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
+  int32_t dzl = DZ_PER_DISTANCE * (1 + k * half); // DZ_PER_DISTANCE * len of the sample k, carried (no multiply per sample)
+  const int32_t dzl_step = DZ_PER_DISTANCE * half;
+  for (int32_t it = 0; it < n_iter; ++it)
   {
-    const bool any_alive = __any(alive);
-    if (any_alive)
-    {
-      // ---- sample phase
-      bool cand = false, cx = false, cy = false;
-      if (alive)
-      {
-        if (k == 0)
-        {
-          cand = first;
-        }
-        else
-        {
-          cx = run_step(wx, dist, res);
-          cy = run_step(wy, dist, res);
-          run_step_z(wz, dist);
-          cand = cx || cy;
-        }
-      }
-      const unsigned long long mask = __ballot(cand);
-      if (mask)
-      {
-        if (cand)
-        {
-          const int32_t px = run_proj(wx, cx, res), py = run_proj(wy, cy, res), pz = run_proj(wz, false, res);
-          const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0; no fan in the free-space part: delta_z * 2 < res
-          if (delta_z != last_dz)
-          {
-            last_dz = delta_z;
-            c0x = trunc_shift15(delta_z * r.ivx);
-            c0y = trunc_shift15(delta_z * r.ivy);
-            c0z = trunc_shift15(delta_z * r.ivz);
-          }
-          // target of the single on-ray candidate (update_tsdf.cu:103-112 with iter_steps == 1)
-          u32x4 e;
-          e.x = (uint32_t)(px - c0x);
-          e.y = (uint32_t)(py - c0y);
-          e.z = (uint32_t)(pz - c0z);
-          e.w = (uint32_t)k | ((uint32_t)lane << 16);
-          const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-          const uint32_t slot = (qtail + rank) & (FREE_QCAP - 1);
-          queue[slot] = e;
-        }
-        qtail += (uint32_t)__popcll(mask);
-      }
-      if (alive)
-      {
-        k += 1;
-        len += half;
-        alive = k < k1;
-      }
-    }
-    // ---- emit phase: 64 queued candidates, one per lane
-    const uint32_t cnt = qtail - qhead;
-    if (cnt >= 64 || (!any_alive && cnt > 0))
-    {
-      const uint32_t n = cnt < 64 ? cnt : 64;
-      u32x4 e = {0, 0, 0, 0};
-      if ((uint32_t)lane < n)
-      {
-        const uint32_t slot = (qhead + (uint32_t)lane) & (FREE_QCAP - 1);
-        e = queue[slot];
-      }
-      const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
-      if ((uint32_t)lane < n)
-      {
-        free_emit(a, f, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
-      }
-      qhead += n;
-    }
-    if (!any_alive && qtail == qhead) break;
+    // ---- sample phase: every lane steps (lanes that are through keep stepping; their samples are masked)
+    const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
+    fast_step_z(wz);
+    const bool cand = (cx || cy) && k < k1;
+    push(cand, cx, cy, dzl);
+    k += 1;
+    dzl += dzl_step;
+    // ---- emit phase
+    if (qtail - qhead >= 64) emit();
   }
+  while (qtail != qhead) emit();
+  free_finish(a, pend);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1595,6 +1648,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     c->desc_cursor = 0;
     c->setup_done = 0;
     c->scan_done = 0;
+    c->tail_next = 0;
     c->ub_total = 0;
   }
   const uint32_t e0 = blockIdx.x;
@@ -2203,6 +2257,18 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res)
   }
 }
 
+// workgroups of march_tail_kernel the device holds at once (queried once)
+static unsigned tail_resident_blocks(int device)
+{
+  static unsigned cached = 0;
+  if (cached) return cached;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, march_tail_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = WS_TAIL_WGS;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+  cached = (unsigned)per_cu * (unsigned)cus;
+  return cached;
+}
+
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
   ws_context *ctx = m->ctx;
@@ -2325,7 +2391,11 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   }
 
   prof_begin(ctx, WS_K_MARCH_TAILS);
+#if WS_TAIL_PERSISTENT
+  hipLaunchKernelGGL(march_tail_kernel, dim3(min(grid_tail.x, tail_resident_blocks(ctx->device))), block, 0, s, sa);
+#else
   hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);
+#endif
   prof_end(ctx, WS_K_MARCH_TAILS);
   if (!s0)
   {

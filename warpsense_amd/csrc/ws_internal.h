@@ -84,7 +84,7 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
   uint32_t setup_done;    // set-up blocks of ray_setup_sort_kernel that have counted their rays and added their record bounds
   uint32_t scan_done;     // scan blocks of tile_scan_kernel that have written their tiles' ranges
-  uint32_t pad0;
+  uint32_t tail_next;     // next work item of the tail march (persistent workgroups)
   unsigned long long ub_total; // sum of the per-ray record upper bounds (capacity hint for the next scan)
   // statistics of the last update, filled by finish_update_kernel
   uint32_t last_records;

@@ -423,6 +423,55 @@ __device__ __forceinline__ int32_t run_proj(AxisRun &w, bool crossed, int32_t re
   return (a ^ w.sm) - w.sm;
 }
 
+// ---- the same sample step with fewer instructions (the march kernels are bound by VALU issue) ---------------------------
+// The remainder is kept BIASED by 2^32 - dist, so that "r + ar >= dist" is the carry out of one 32-bit add, and the carry
+// feeds the quotient (add with carry) and the gap (subtract with borrow) directly: 8 vector instructions for an x / y axis,
+// 4 for z, no branch.  Lanes whose samples are used up keep stepping (their results are masked by the caller), so a wave
+// needs no per-lane exec regions in the sample phase.
+struct AxisFast
+{
+  uint32_t rb, ar, bias; // rb = r + bias, bias = 2^32 - dist
+  int32_t aq, q, gap, spos, sm;
+};
+__device__ __forceinline__ AxisFast fast_from(const AxisRun &w, int32_t dist)
+{
+  AxisFast f;
+  f.bias = (uint32_t)0 - (uint32_t)dist;
+  f.rb = (uint32_t)w.r + f.bias;
+  f.ar = (uint32_t)w.ar;
+  f.aq = w.aq;
+  f.q = w.q;
+  f.gap = w.gap;
+  f.spos = w.spos;
+  f.sm = w.sm;
+  return f;
+}
+__device__ __forceinline__ bool fast_step(AxisFast &w, int32_t res)
+{
+  const uint32_t t = w.rb + w.ar;
+  const uint32_t c = t < w.rb ? 1u : 0u; // carry: r + ar >= dist
+  w.rb = t + (c ? w.bias : 0u);
+  const int32_t dq = w.aq + (int32_t)c;
+  w.q += dq;
+  w.gap -= dq;
+  const bool crossed = w.gap <= 0;
+  w.gap += crossed ? res : 0;
+  return crossed;
+}
+__device__ __forceinline__ void fast_step_z(AxisFast &w)
+{
+  const uint32_t t = w.rb + w.ar;
+  const uint32_t c = t < w.rb ? 1u : 0u;
+  w.rb = t + (c ? w.bias : 0u);
+  w.q += w.aq + (int32_t)c;
+}
+__device__ __forceinline__ int32_t fast_proj(AxisFast &w, bool crossed, int32_t res)
+{
+  const int32_t a = w.spos + w.q;
+  if (crossed && (uint32_t)(a + res - 1) < (uint32_t)(res - 1)) w.gap += res - 1; // entered the cell around zero from below
+  return (a ^ w.sm) - w.sm;
+}
+
 // order key of a candidate: point(20) | ray step(16) | fan step(8)
 __device__ __forceinline__ uint64_t order_key(uint32_t ix, int32_t k, int32_t step)
 {
