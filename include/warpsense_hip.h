@@ -235,7 +235,7 @@ int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n,
 int ws_debug_block_stats(ws_map *map, uint32_t *out, size_t words);
 
 /* Test entry: make the NEXT resident registration of `reg` lose one workgroup's contribution to the first exchange, as if
- * another kernel kept that workgroup off the chip: the exchange times out (0.25 s) and ws_register_cloud repeats the
+ * another kernel kept that workgroup off the chip: the exchange times out (5 ms) and ws_register_cloud repeats the
  * registration with one launch per iteration. *fallbacks (may be NULL) receives how often that has happened on `reg`. */
 int ws_debug_reg_stall(ws_reg *reg, int32_t stall_next, int32_t *fallbacks);
 

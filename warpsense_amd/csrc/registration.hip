@@ -826,7 +826,13 @@ static_assert(REG_WORDS == 64 && REG_BLOCKS % REG_GROUPS == 0 && REG_BLOCKS / RE
 #endif
 constexpr int REG_FIRST_POLL_SLEEP = WS_REG_FIRST_POLL_SLEEP; // x 64 clocks before the first poll
 constexpr int REG_POLL_SLEEP = 2;        // between polls
-constexpr long long REG_BARRIER_TIMEOUT_TICKS = 25000000ll; // 0.25 s of the 100 MHz wall clock, then ws_register_cloud falls back to one launch per iteration
+// Poll limits on the 100 MHz wall clock.  The workgroups of ONE launch start within microseconds of each other, so an on-chip
+// exchange that is not complete after 5 ms means that some workgroup is not on the chip (another kernel holds its CU):
+// ws_register_cloud then repeats the registration with one launch per iteration, which needs no co-residency -- half a
+// frame at 100 Hz lost, not the 2.5 frames at 10 Hz the 0.25 s of round 2 cost.  Ranks of a multi-GPU loop are launched by
+// different processes: their mailboxes wait 0.25 s.
+constexpr long long REG_BARRIER_TIMEOUT_TICKS = 500000ll;
+constexpr long long REG_PEER_TIMEOUT_TICKS = 25000000ll;
 
 // first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
 __device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, unsigned long long *wg_sum, bool publish,
@@ -936,7 +942,7 @@ __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, u
     {
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
-      const bool give_up = now - t0 > REG_BARRIER_TIMEOUT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      const bool give_up = now - t0 > REG_PEER_TIMEOUT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
       if (__any(give_up))
       {
         if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

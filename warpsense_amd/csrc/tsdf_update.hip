@@ -585,6 +585,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // the workgroup's tile histogram is built on the fly (the slot travels in the record); a full table defers
       // the record to the extra rounds of phase 2
       const int slot = ht_insert(ht_key, rec.z);
+      // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together -- counting the lanes
+      // of a slot with ballots and adding once per (wave, tile) made the kernel 205 -> 345 us)
       if (slot >= 0)
         atomicAdd(&ht_cnt[slot], 1u);
       else
@@ -1337,29 +1339,48 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
   }
   unsigned long long total;
   const unsigned long long excl = block_scan_u64(mine, wave_sums, total);
-  if (threadIdx.x == 0)
+  if (threadIdx.x < 64)
   {
+    // The look-back, by the whole first wave: lane i reads the word of block b - 1 - i, so 64 predecessors cost ONE round
+    // trip (one thread walking back word by word paid a coherent load -- 1 to 2 us -- per predecessor: the last of the 33
+    // blocks of the 513^3 map waited ~30 us).  Everything up to the nearest inclusive prefix must be published (status
+    // != 0); aggregates in between are added, the inclusive prefix ends the walk.
     const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
     unsigned long long prefix = 0;
     if (b > 0)
     {
-      __hip_atomic_store(&look[b], LOOK_AGG | look_pack(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t j = (int64_t)b - 1; j >= 0; --j)
+      if (lane == 0) __hip_atomic_store(&look[b], LOOK_AGG | look_pack(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t j0 = (int64_t)b - 1;
+      for (;;)
       {
-        unsigned long long w;
-        do
-          w = __hip_atomic_load(&look[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((w & LOOK_MASK) == 0);
-        prefix += look_unpack(w & ~LOOK_MASK);
-        if ((w & LOOK_MASK) == LOOK_INCL) break;
+        const int64_t j = j0 - lane;
+        unsigned long long w = LOOK_INCL; // before block 0: an inclusive prefix of zero
+        if (j >= 0) w = __hip_atomic_load(&look[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long incl = __ballot((w & LOOK_MASK) == LOOK_INCL), ready = __ballot((w & LOOK_MASK) != 0);
+        const int first = incl ? __ffsll((long long)incl) - 1 : 64;                            // nearest inclusive prefix among these 64
+        const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);          // lanes 0 .. first
+        if ((ready & need) != need)
+        {
+          __builtin_amdgcn_s_sleep(2);
+          continue; // somebody in front has not published yet: read again
+        }
+        unsigned long long v = lane <= first ? look_unpack(w & ~LOOK_MASK) : 0ull;
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        prefix += v;
+        if (first < 64) break;
+        j0 -= 64;
       }
     }
-    __hip_atomic_store(&look[b], LOOK_INCL | look_pack(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_prefix = prefix;
-    if (b == n_scan_blocks - 1)
+    if (lane == 0)
     {
-      __hip_atomic_store(&a.counters->n_desc_sorted, (uint32_t)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
+      __hip_atomic_store(&look[b], LOOK_INCL | look_pack(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_prefix = prefix;
+      if (b == n_scan_blocks - 1)
+      {
+        __hip_atomic_store(&a.counters->n_desc_sorted, (uint32_t)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
+      }
     }
   }
   __syncthreads();
@@ -1596,6 +1617,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     {
       const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)p.my_start, r);
       const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)p.my_count, r);
+      // (A run covers one or two of the eight slots; skipping the others with uniform compares and branches removes 40 % of
+      // this kernel's vector instructions and makes it SLOWER, 166 -> 184 us: with four waves per SIMD the resolve is bound
+      // by the length of each wave's own instruction stream, and a taken scalar branch costs more than three selects.)
 #pragma unroll
       for (int k = 0; k < RES_MAXR; ++k)
       {
