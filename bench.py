@@ -176,6 +176,7 @@ def main():
                 backend.peers = None
     reg.prepare_registration(d_pert)
     its = []
+    graph_cache = {}
 
     def step():
         tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
@@ -187,7 +188,8 @@ def main():
         if world == 1 and not force_sharded:
             _, it = reg.register_cloud(tsdf.device_map(), eye, *reg_params, res)
         else:
-            _, it = sharded_register_cloud(backend, n, eye, *reg_params)
+            # device-side exchange if the peers' mailboxes are mapped; else RCCL with 16 iterations per (validated) HIP graph
+            _, it = sharded_register_cloud(backend, n, eye, *reg_params, graphs=graph_cache)
         its.append(it)
 
     def fence():
@@ -309,7 +311,26 @@ def main():
                 reg.prepare_registration(d_pert)
                 _, sh_it = sharded_register_cloud(backend, n, eye, *reg_params)
             fence()
-            sharded_1rank = {"scans_per_s": n_sh / (time.perf_counter() - t2), "iterations": sh_it}
+            sharded_1rank = {"scans_per_s": n_sh / (time.perf_counter() - t2), "iterations": sh_it,
+                             "route": "RCCL all-reduce per iteration, one launch + one collective per iteration enqueued by the host"}
+            # the same route with 16 iterations per captured HIP graph (validated bit for bit against stream launches when captured)
+            try:
+                graphs = {}
+                for _ in range(2):
+                    reg.prepare_registration(d_pert)
+                    _, g_it = sharded_register_cloud(backend, n, eye, *reg_params, graphs=graphs)
+                fence()
+                t2 = time.perf_counter()
+                for _ in range(n_sh):
+                    tsdf.update_tsdf(d_points, (0, 0, 0), (0, 0, 32768))
+                    reg.prepare_registration(d_pert)
+                    _, g_it = sharded_register_cloud(backend, n, eye, *reg_params, graphs=graphs)
+                fence()
+                runner = next(iter(graphs.values()))
+                sharded_1rank["graph_batches"] = {"scans_per_s": n_sh / (time.perf_counter() - t2), "iterations": g_it,
+                                                  "graph_in_use": runner.graph is not None}
+            except Exception as exc:
+                sharded_1rank["graph_batches"] = {"error": repr(exc)[:200]}
             dist.destroy_process_group()
         except Exception as exc:  # RCCL unavailable on this box: report why, keep the bench line
             sharded_1rank = {"error": repr(exc)[:200]}

@@ -40,8 +40,8 @@ def main(prefix):
         for name, frag in (("march_tails", "march_tail_kernel"), ("march_free", "march_free_kernel"), ("tile_resolve", "tile_resolve_kernel"),
                            ("ray_setup", "ray_s"), ("tile_bin", "tile_")):
             if name == "tile_bin":
-                val = (kb(f, "tile_count") + kb(f, "tile_blockscan") + kb(f, "tile_list") + kb(f, "desc_place") + kb(w, "tile_count") +
-                       kb(w, "tile_blockscan") + kb(w, "tile_list") + kb(w, "desc_place")) * 1024
+                parts = ("tile_count", "tile_blockscan", "tile_list", "tile_scan", "desc_place")
+                val = sum(kb(f, q) + kb(w, q) for q in parts) * 1024
             else:
                 val = (kb(f, frag) + kb(w, frag)) * 1024
             out[f"{name}:{mode}"] = int(val)
@@ -50,6 +50,22 @@ def main(prefix):
         if mode == "dense":
             out["integrate:dense"] = int((2 * kb(f, "integrate_dense") + kb(w, "integrate_dense")) * 1024)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # which sources these passes ran on: the commit (GRAFT snapshots carry no .git: WS_GIT_SHA from the caller) and a hash of
+    # the kernel sources themselves
+    import hashlib
+    import subprocess
+    sha = os.environ.get("WS_GIT_SHA")
+    if not sha:
+        try:
+            sha = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            sha = "unknown"
+    h = hashlib.sha256()
+    for f_ in ("tsdf_update.hip", "ws_march.h", "ws_device.h", "registration.hip", "api.hip"):
+        with open(os.path.join(root, "warpsense_amd", "csrc", f_), "rb") as fh:
+            h.update(fh.read())
+    out["git_sha"] = sha
+    out["csrc_sha256_16"] = h.hexdigest()[:16]
     with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print(out)
