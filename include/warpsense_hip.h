@@ -43,15 +43,18 @@ typedef enum
   WS_ERR_INVALID = -1,     /* bad argument                                             */
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
-  WS_ERR_CAPACITY = -4,    /* candidate-record buffers exhausted: a TSDF update is not exact (sticky, see below) */
+  WS_ERR_CAPACITY = -4,    /* run descriptors / free-space hash exhausted: a TSDF update is not exact (sticky, see below);
+                              also returned at once by ws_tsdf_update* for a scan that needs more than 2^32 records */
   WS_ERR_RANGE = -5,       /* ray too long for the order key; the ray was dropped (sticky)       */
-  WS_ERR_TIMEOUT = -6,     /* (kept for ABI stability: ws_register_cloud now retries with one launch per iteration) */
+  WS_ERR_TIMEOUT = -6,     /* ws_register_cloud_peers: a peer rank did not deliver (ws_register_cloud itself retries with one
+                              launch per iteration instead of returning this) */
   WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
 } ws_status;
 
-/* Sticky device-side errors.  ws_tsdf_update* only ENQUEUE work (like the reference, update_tsdf.cu:165), so a
- * problem found by the kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact) cannot come back
- * from that call.  It is kept in host-visible memory and returned ONCE by the first call on the same map that
+/* Sticky device-side errors.  ws_tsdf_update* return after ENQUEUEING the kernels (like the reference,
+ * update_tsdf.cu:165; they wait for the set-up pass's record bound first, where the reference blocks on its cudaMemcpys,
+ * :152-154), so a problem found by the later kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact)
+ * cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the first call on the same map that
  * synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.  compat.hpp turns it into
  * the reference's print-and-exit (common.cuh:10-21). */
 
@@ -144,10 +147,9 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers; default 32 Mi).  The FIRST scan of a map
- * synchronises once after its set-up pass and sizes the buffers for what that scan needs; later scans grow them from the
- * previous scan's need without waiting, so only a scan much larger than its predecessor can overflow (WS_ERR_CAPACITY,
- * sticky).  Reserving up front rules that out and skips the first-scan synchronisation. */
+/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers; default 32 Mi).  EVERY scan sizes the buffers
+ * itself: ws_tsdf_update* waits for the bound its set-up pass computes and grows them before the tail march is enqueued, so
+ * the records cannot overflow whatever the previous scan looked like.  Reserving up front only avoids the reallocation. */
 int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
 
 typedef struct
