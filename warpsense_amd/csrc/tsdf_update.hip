@@ -91,6 +91,10 @@ constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTE
 #define WS_TAIL_PERSISTENT 0 // (measured: 216-222 us against 187-195 us for one workgroup per item: resident workgroups run in lock step and their sort phases collide)
 //  1: the tail march runs as resident workgroups that take (64 rays x 4 parts) items from a counter
 #endif
+#ifndef WS_SORT_U
+#define WS_SORT_U 8 // (4: 188-191 us, 8: 185-187 us, 2: 196-198 us) records a thread of the tail march has in flight while it copies the workgroup's records into tile order
+#endif
+constexpr int SORT_U = WS_SORT_U;
 #ifndef WS_FREE_PIPE
 #define WS_FREE_PIPE 1 // 1: the voxel byte of a free-space candidate is requested one emit phase before it is used (126 -> 122 us)
 #endif
@@ -839,19 +843,19 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     }
     __syncthreads();
     const bool more = s_overflow != 0;
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 256u * SORT_U)
     {
-      u32x4 rec[4];
+      u32x4 rec[SORT_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < SORT_U; ++u)
       {
-        // unconditional (clamped) loads: four in flight; a load under a branch would be waited for on the spot
+        // unconditional (clamped) loads, SORT_U in flight; a load under a branch would be waited for on the spot
         const uint32_t i = i0 + (uint32_t)u * 256u;
         rec[u] = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + (i < total ? i : total - 1)]);
         if (i >= total) rec[u].z = REC_DONE;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < SORT_U; ++u)
       {
         if (rec[u].z == REC_DONE) continue;
         // round 0: the slot was found when the record was written; later rounds look the tile up again
