@@ -37,14 +37,14 @@ def test_config2_stream_on_the_1025_sliding_map():
         pytest.skip("needs ~48 GB of host memory (oracle maps) and ~24 GB on the GPU")
     tau, res, mw, size = 1000, 50, 640, (1024, 1024, 1024)
     reg = (200, 0.1, 0.03)
-    shift_m = 0.45
+    shift_m = 0.25
     params = W.Params(W.MapParams(resolution=res, max_distance=tau / 1000.0, max_weight=mw // 64, size=tuple(s * res / 1000.0 for s in size),
                                   shift=shift_m), W.RegistrationParams(*reg))
-    # sensor moving through a 20 x 16 x 5 m room (the benchmark room), 64 x 512 rays per scan
+    # sensor moving through a 20 x 16 x 5 m room (the benchmark room), full OS1-128 scans: 128 x 1024 = 131 072 rays each
     clouds = []
     for k in range(7):
         sensor = np.array([k * 220.0, 0.4 * k * 220.0, 0.0])
-        pts = S.os1_128_scan(sensor_mm=tuple(sensor), rings=64, azimuths=512, seed=300 + k)
+        pts = S.os1_128_scan(sensor_mm=tuple(sensor), rings=128, azimuths=1024, seed=300 + k)
         clouds.append(((pts.astype(np.float64) - sensor) / 1000.0).astype(np.float32))
     app = W.App(params, None)
     for c in clouds:
