@@ -128,11 +128,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the hot path)")
+    # WS_BENCH_SHARE_GPU=1 WS_BENCH_BACKEND=gloo: all ranks on cuda:0 with a gloo group -- a DRY RUN of the N > 1 code path
+    # (IPC mailboxes, device-side exchange, replica pass, reductions of the timings) on a 1-GPU box; its numbers mean nothing
+    share_gpu = os.environ.get("WS_BENCH_SHARE_GPU") == "1"
+    pg_backend = os.environ.get("WS_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("WS_BENCH_FORCE_SHARDED") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if pg_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=pg_backend, rank=rank, world_size=world)
+
+    def reduce_max(seconds: float) -> float:
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if pg_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import warpsense_amd as W
     from warpsense_amd import _lib, synthetic as S
@@ -169,7 +183,8 @@ def main():
         exchange = "RCCL all-reduce of 44 int64 per iteration (host-driven launches)"
         if os.environ.get("WS_BENCH_NO_PEERS") != "1":
             try:
-                backend.connect_peers()  # mailboxes exported / mapped with hipIpc: the loop runs without the host in it
+                # mailboxes exported / mapped with hipIpc: the loop runs without the host in it
+                backend.connect_peers(blocks=(256 // world) // 8 * 8 if share_gpu else 0)
                 exchange = "device-side: counted mailboxes in the peers' HBM over xGMI, one resident launch per registration"
             except Exception as exc:  # no peer mapping on this node: the RCCL route still works
                 print(f"[bench] device-side exchange unavailable ({exc!r}); using the RCCL route", file=sys.stderr)
@@ -218,9 +233,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed)
     ms, cnt = ctx.prof_read(_lib.WS_K_UPDATE)
     update_span_us = 1000.0 * ms / cnt if cnt else None
     ms, cnt = ctx.prof_read(_lib.WS_K_INTEGRATE)
@@ -349,9 +362,7 @@ def main():
         for _ in range(args.steps):
             replica_step()
         fence()
-        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        replica = world * args.steps / float(t.item())
+        replica = world * args.steps / reduce_max(time.perf_counter() - t3)
 
     # The multi-GPU loop with the device-side exchange, exercised on this ONE GPU: two ranks (own contexts / streams, 128
     # resident workgroups each) register the same cloud, every rank its half of the points, the 44 sums through mailboxes.
@@ -477,6 +488,7 @@ def main():
         "sharded_1rank": sharded_1rank,
         "sharded_2rank_1gpu": sharded_2rank,
         "replica_scans_per_s": replica,
+        "dry_run_shared_gpu": bool(share_gpu) or None,
         "replica_note": None if replica is None else f"{world} independent streams, one per GPU, no exchange (weak scaling); `value` is the point-sharded run",
         "h2d_scan": h2d,
     }
