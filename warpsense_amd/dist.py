@@ -95,7 +95,25 @@ class HipGnBackend:
             handles = [None] * world
             dist.all_gather_object(handles, bytes(handle), group=group)
         blob = b"".join(handles)
-        check(self._L.ws_reg_peer_connect(self.reg.handle, rank, world, blob, int(blocks)), "ws_reg_peer_connect")
+        err = None
+        rc = self._L.ws_reg_peer_connect(self.reg.handle, rank, world, blob, int(blocks))
+        if rc != 0:
+            msg = self._L.ws_last_error()
+            err = f"ws_reg_peer_connect failed with status {rc}: {msg.decode(errors='replace') if msg else ''}"
+        if world > 1:
+            # all or nobody: a rank that could not map a peer's mailbox must not leave the others waiting in the resident loop
+            import torch
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32)
+            if dist.get_backend(group) != "gloo":
+                flag = flag.cuda()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0 and err is None:
+                err = "a peer rank could not map the mailboxes"
+        if err is not None:
+            self._L.ws_reg_peer_disconnect(self.reg.handle)
+            self.peers = None
+            from ._lib import WsError
+            raise WsError(err)
         if world > 1:
             dist.barrier(group=group)  # every mailbox is mapped (and zero) before anybody's first launch
         self.peers = (rank, world)
