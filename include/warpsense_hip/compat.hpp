@@ -361,6 +361,29 @@ public:
   }
   void set_flags(uint32_t flags) { flags_ = flags; }
 
+  // ---- point-sharded registration over several GPUs (one process per GPU, the map replicated, every rank has prepared the
+  // whole cloud): the ranks' 44 sums meet in mailboxes in each other's HBM, ws_register_cloud_peers (warpsense_hip.h).
+  // mailbox(): this rank's mailbox as a 64-byte IPC handle, to be all-gathered by the caller's transport;
+  // connect(): map the peers' mailboxes; register_cloud_peers(): all ranks together, false if a peer did not deliver
+  // (then: barrier, reset_peers(), barrier, and the RCCL route -- ws_reg_iterate_shard_dev -- for that cloud).
+  void peer_mailbox(unsigned char handle[WS_IPC_HANDLE_BYTES]) { WS_CHECK(ws_reg_peer_mailbox(reg_, handle)); }
+  void peer_connect(int rank, int world, const unsigned char *handles /* world x WS_IPC_HANDLE_BYTES */, int blocks = 0)
+  {
+    WS_CHECK(ws_reg_peer_connect(reg_, rank, world, handles, blocks));
+  }
+  void reset_peers() { WS_CHECK(ws_reg_peer_reset(reg_)); }
+  bool register_cloud_peers(const DeviceMap *map_dev, size_t first, size_t count, const rmagine::Matrix4x4f &pretransform, int max_iterations,
+                            float it_weight_gradient, float epsilon, int map_resolution, rmagine::Matrix4x4f &out, int *iterations = nullptr)
+  {
+    int32_t it = 0;
+    const int rc = ws_register_cloud_peers(reg_, reinterpret_cast<const ws_map *>(map_dev), first, count, &pretransform.data[0][0], max_iterations,
+                                           it_weight_gradient, epsilon, map_resolution, flags_, &out.data[0][0], &it);
+    if (rc == WS_ERR_TIMEOUT) return false;
+    WS_CHECK(rc);
+    if (iterations) *iterations = it;
+    return true;
+  }
+
 private:
   ws_reg *reg_ = nullptr;
   uint32_t flags_ = WS_REG_ALL_POINTS;

@@ -87,6 +87,13 @@ int callsites(bool run)
     (void)cuda_map.in_bounds_with_buffer_neg(rmagine::Vector3i(1, 1, 1), 1);
     (void)cuda_map.in_bounds_with_buffer_pos(rmagine::Vector3i(3, 0, 0), 1);
     cuda::pause();
+    // beyond the reference: the multi-GPU loop of this library through the same class
+    unsigned char handle[WS_IPC_HANDLE_BYTES];
+    reg.peer_mailbox(handle);
+    reg.peer_connect(0, 1, handle);
+    rmagine::Matrix4x4f out;
+    int its = 0;
+    (void)reg.register_cloud_peers(tsdf.device_map(), 0, points_rm.size(), T, 200, 0.1f, 0.03f, 64, out, &its);
   }
   return 0;
 }
