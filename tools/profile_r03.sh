@@ -4,15 +4,19 @@
 # Counter passes are separate runs with --kernel-trace only (no --stats, no other trace domain), one TCC counter per run
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass), the SQ counters in two groups of eight.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# the traced runs leave out the multi-rank sections of bench.py (RCCL start-up, HIP-graph capture and a child process under the
+# tracer aborted rocprofv3 once); the untraced bench run below has them
+export WS_BENCH_SKIP_SHARDED=1
 TAG=${1:-r03}
 QUICK=${2:-}
 mkdir -p gpurun_out
 for mode in sparse dense; do
+  rm -rf gpurun_out/prof_${TAG}_${mode}
   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG}_${mode} -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --integrate ${mode} > gpurun_out/prof_${TAG}_${mode}.log 2>&1
   python tools/rocpd_stats.py $(ls gpurun_out/prof_${TAG}_${mode}/*.db gpurun_out/prof_${TAG}_${mode}/*/*.db 2>/dev/null | head -1) > gpurun_out/${TAG}_kernel_stats_${mode}.txt
 done
 if [ -z "$QUICK" ]; then
-  python bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+  WS_BENCH_SKIP_SHARDED=0 python bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
   for mode in sparse dense; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --kernel-trace --pmc ${ctr} -d gpurun_out/prof_${TAG}_pmc_${ctr}_${mode} -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-registration --integrate ${mode} > gpurun_out/prof_${TAG}_pmc_${ctr}_${mode}.log 2>&1
