@@ -205,8 +205,13 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
 {
   __shared__ unsigned long long ub_wave[4];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
-  // the free-space key hash still holds what the previous scan claimed: back to empty, long before this scan's free pass
-  fk_clear_claimed(a.fk_keys, a.fk_mask + 1u, (int64_t)ix, (int64_t)n_setup_blocks * 256);
+  // the free-space key hash still holds what the previous scan claimed: back to empty, long before this scan's free pass.
+  // (this thread's word of the claimed-slots bitmap is requested here and used at the END of the block: its round trip
+  // runs under the ray arithmetic)
+  const uint32_t fk_slots = a.fk_mask + 1u;
+  uint32_t *const fk_claimed = reinterpret_cast<uint32_t *>(a.fk_keys + 2 * (size_t)fk_slots);
+  const bool fk_mine = ix < fk_slots / 32u && (uint64_t)n_setup_blocks * 256u >= fk_slots / 32u;
+  const uint32_t fk_bits = fk_mine ? fk_claimed[ix] : 0u;
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
@@ -355,20 +360,36 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
   if (threadIdx.x == 0)
   {
     const unsigned long long t = ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3];
-    // No cache-wide fence (an agent-scope release / acquire walks the XCD's L2: 15-20 us on this kernel, measured): the
-    // sum is a RETURNING atomic, and the arrival count below takes its operand from that result, so the add has been
-    // performed at the coherent level before the count is.
-    unsigned long long before = 0;
-    if (t) before = __hip_atomic_fetch_add(&a.counters->ub_total, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t one = 1u;
-    asm volatile("" : "+v"(one) : "v"(before));
-    if (__hip_atomic_fetch_add(&a.counters->setup_done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_setup_blocks - 1)
+    // ONE atomic per workgroup carries both the sum and the arrival count (bits 48..: workgroups, at most 3907 of them;
+    // below: record slots, < 2^32): the workgroup that finds everybody else's count in the old value also has the total in
+    // it -- no second atomic, no read-back, and no cache-wide fence (an agent-scope release / acquire pair walks the XCD's
+    // L2: 15-20 us on this kernel, measured; two dependent returning atomics + a coherent load: ~5 us at the kernel's tail).
+    const unsigned long long before = __hip_atomic_fetch_add(&a.counters->ub_total, t + (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(before >> 48) == n_setup_blocks - 1)
     {
-      const unsigned long long total = __hip_atomic_load(&a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long total = (before & ((1ull << 48) - 1ull)) + t;
       __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  // the claimed slots of the free-space hash (see the top of the block)
+  if ((uint64_t)n_setup_blocks * 256u >= fk_slots / 32u)
+  {
+    uint32_t bits = fk_bits;
+    if (bits)
+    {
+      fk_claimed[ix] = 0;
+      while (bits)
+      {
+        const uint32_t h = ix * 32u + (uint32_t)__builtin_ctz(bits);
+        bits &= bits - 1;
+        a.fk_keys[h] = KEY_INF;
+        a.fk_keys[(size_t)fk_slots + h] = KEY_INF;
+      }
+    }
+  }
+  else
+    fk_clear_claimed(a.fk_keys, fk_slots, (int64_t)ix, (int64_t)n_setup_blocks * 256); // small scans: a strided loop
 }
 
 // Counting sort of the rays by direction bin, in the SAME launch as the set-up: blocks [0, S) are the set-up blocks above,
@@ -387,7 +408,7 @@ __device__ __forceinline__ void ray_sort_block(const ScatterArgs &a, uint32_t n_
   if (FUSED)
   {
     if (threadIdx.x == 0)
-      while (__hip_atomic_load(&a.counters->setup_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_setup_blocks) __builtin_amdgcn_s_sleep(16);
+      while ((uint32_t)(__hip_atomic_load(&a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48) < n_setup_blocks) __builtin_amdgcn_s_sleep(16);
     __syncthreads();
   }
   const int lo = threadIdx.x * PER, hi = min(lo + PER, TOTAL);
@@ -503,6 +524,15 @@ typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate 
 
 // A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
 // quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
+// does the scan in flight fit the record buffers?  (uniform: the set-up pass has finished, its total is final)
+__device__ __forceinline__ bool scan_fits(const ScatterArgs &a)
+{
+  // a plain (scalar) load: the total was finished by an earlier kernel.  (As a coherent load by every thread -- a million of
+  // them on one address -- this line alone took the tail march from 190 to 500 us.)
+  const unsigned long long need = a.counters->ub_total & ((1ull << 48) - 1ull);
+  return need <= (unsigned long long)a.rec_cap;
+}
+
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails
 __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
@@ -887,10 +917,16 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
 // slots finished after 190 us, the sum of their durations over the slots is 127 us) -- items differ by 10x in work.
 __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
 {
+#if WS_TAIL_PERSISTENT
   __shared__ uint32_t s_item;
+#endif
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
+  // The whole update is enqueued before the host has seen the record bound of this scan (below: launch_tsdf_scatter).  If the
+  // scan does not fit the record buffers, NOTHING of it may happen: the tail march and the free pass leave at once (no byte
+  // of the map's state is touched, the later kernels find nothing to do), and the host grows the buffers and runs it again.
+  if (scan_fits(a) == false) return;
 #if WS_TAIL_PERSISTENT
   for (;;)
   {
@@ -993,6 +1029,7 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
 __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 {
+  if (scan_fits(a) == false) return; // see march_tail_kernel
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
   const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
@@ -1293,14 +1330,35 @@ __device__ __forceinline__ void place_descriptors(const TileScanArgs &a, uint32_
   // that did not fit wrote nothing and counted nothing, and every later one failed too)
   uint32_t n = COHERENT ? __hip_atomic_load(&a.counters->n_desc_sorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.counters->n_desc_sorted;
   if (n > a.desc_cap) n = a.desc_cap;
-  for (uint32_t i = (blockIdx.x - first_block) * 256u + threadIdx.x; i < n; i += n_blocks * 256u)
+  // four descriptors per thread and pass, every step issued for all four before the next step uses any of them (loads,
+  // then the returning atomics and the coherent loads, then the stores): three round trips per pass instead of per descriptor
+  constexpr int PU = 4;
+  const uint32_t stride = n_blocks * 256u;
+  for (uint32_t i0 = (blockIdx.x - first_block) * 256u + threadIdx.x; i0 < n; i0 += stride * PU)
   {
-    const RunDesc d = a.desc[i];
-    const uint32_t old = atomicSub(&a.tile_nruns[d.tile], 1u);
-    const uint32_t begin = COHERENT ? __hip_atomic_load(&a.tile_begin[d.tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.tile_begin[d.tile];
-    const uint32_t pos = begin + old - 1u;
-    a.sorted_desc[2 * (size_t)pos + 0] = d.start;
-    a.sorted_desc[2 * (size_t)pos + 1] = d.count;
+    RunDesc d[PU];
+    uint32_t old[PU], begin[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+    {
+      const uint32_t i = i0 + (uint32_t)u * stride;
+      d[u] = a.desc[i < n ? i : n - 1u];
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+    {
+      const uint32_t i = i0 + (uint32_t)u * stride;
+      old[u] = i < n ? atomicSub(&a.tile_nruns[d[u].tile], 1u) : 0u;
+      begin[u] = COHERENT ? __hip_atomic_load(&a.tile_begin[d[u].tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.tile_begin[d[u].tile];
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+    {
+      const uint32_t i = i0 + (uint32_t)u * stride;
+      if (i >= n) continue;
+      const uint32_t pos = begin[u] + old[u] - 1u;
+      *reinterpret_cast<uint2 *>(&a.sorted_desc[2 * (size_t)pos]) = make_uint2(d[u].start, d[u].count);
+    }
   }
 }
 
@@ -1323,22 +1381,59 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned
   uint32_t nr[SCAN_TILES_PER_THREAD];
   uint32_t listed = 0; // bit mask
   unsigned long long mine = 0;
+  static_assert(SCAN_TILES_PER_THREAD == 16, "a thread's tiles are four 128-bit loads of counters and one of dirty bytes");
+  uint32_t dirty_bits = 0;
+  if (t0 + SCAN_TILES_PER_THREAD <= a.n_tiles)
+  {
+    // five 128-bit loads issued together, then one store: tile by tile (load, load, conditional store, ...) the in-order
+    // memory counter made sixteen dependent round trips out of this
+    u32x4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = *reinterpret_cast<const u32x4 *>(&a.tile_nruns[t0 + 4 * q]);
+    const u32x4 d = *reinterpret_cast<const u32x4 *>(&a.tile_dirty[t0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+      nr[4 * q + 0] = c[q].x;
+      nr[4 * q + 1] = c[q].y;
+      nr[4 * q + 2] = c[q].z;
+      nr[4 * q + 3] = c[q].w;
+    }
+    const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dirty_bits |= ((dw[j >> 2] >> (8 * (j & 3))) & 0xffu) ? (1u << j) : 0u;
+    if (dirty_bits)
+    {
+      const u32x4 z = {0, 0, 0, 0};
+      *reinterpret_cast<u32x4 *>(&a.tile_dirty[t0]) = z;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
+    {
+      const int64_t t = t0 + j;
+      nr[j] = 0;
+      if (t < a.n_tiles)
+      {
+        nr[j] = a.tile_nruns[t];
+        if (a.tile_dirty[t] != 0)
+        {
+          a.tile_dirty[t] = 0;
+          dirty_bits |= 1u << j;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
   {
-    const int64_t t = t0 + j;
-    nr[j] = 0;
-    if (t < a.n_tiles)
+    mine += nr[j];
+    if (nr[j] || (dirty_bits & (1u << j)))
     {
-      nr[j] = a.tile_nruns[t];
-      const bool dirty = a.tile_dirty[t] != 0;
-      if (dirty) a.tile_dirty[t] = 0;
-      mine += nr[j];
-      if (nr[j] || dirty)
-      {
-        mine += 1ull << 32;
-        listed |= 1u << j;
-      }
+      mine += 1ull << 32;
+      listed |= 1u << j;
     }
   }
   unsigned long long total;
@@ -1674,7 +1769,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     c->last_listed = n_list;
     c->raw_cursor = 0;
     c->desc_cursor = 0;
-    c->setup_done = 0;
     c->scan_done = 0;
     c->tail_next = 0;
     c->ub_total = 0;
@@ -2368,6 +2462,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 grid_free((unsigned)((n + 256 / FREE_LANES - 1) / (256 / FREE_LANES)));
   m->tail_blocks = grid_tail.x;
 
+  const bool fuse = fused && !s0;
+  for (int attempt = 0;; ++attempt)
+  {
   prof_begin(ctx, WS_K_SETUP);
   // normally the kernels of the previous update have left their scratch zero / empty on their way (m->prepped)
   if (!m->prepped) hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), block, 0, s, make_prep_args(m));
@@ -2380,46 +2477,6 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   hipLaunchKernelGGL(ray_sort_kernel, dim3(min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa);
 #endif
   prof_end(ctx, WS_K_SETUP);
-  {
-    // The set-up pass has counted the record slots this scan can need; its last workgroup writes the total and this
-    // scan's sequence number into host-mapped memory.  The host waits for that word -- the set-up blocks are the first
-    // thing the update runs, and the direction-sort blocks of the same launch run meanwhile, so the stream does not drain --
-    // and grows the buffers first if the scan does not fit.  (The reference's update_tsdf blocks on three cudaMemcpy at this point,
-    // update_tsdf.cu:152-154.)  A hint from the previous scan is not enough: a door that opens multiplies the need.
-    volatile uint32_t *st = m->status_host;
-    const auto t0 = std::chrono::steady_clock::now();
-    uint32_t spins = 0;
-    while (st[6] != sa.scan_seq)
-    {
-      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
-      {
-        WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
-        if (st[6] != sa.scan_seq)
-        {
-          set_error("TSDF update: the set-up pass did not report its record bound");
-          return WS_ERR_INTERNAL;
-        }
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
-    if (need > m->rec_cap)
-    {
-      if (need > 0xfffffff0ull)
-      {
-        set_error("TSDF update: the scan needs more than 2^32 candidate records");
-        return WS_ERR_CAPACITY;
-      }
-      const int rc = resize_records(m, need + need / 8);
-      if (rc != WS_OK) return rc;
-      sa.rec_raw = m->rec_raw;
-      sa.rec_sorted = m->rec_sorted;
-      sa.rec_cap = m->rec_cap;
-      sa.desc = m->desc;
-      sa.desc_cap = m->desc_cap;
-    }
-  }
-
   prof_begin(ctx, WS_K_MARCH_TAILS);
 #if WS_TAIL_PERSISTENT
   hipLaunchKernelGGL(march_tail_kernel, dim3(min(grid_tail.x, tail_resident_blocks(ctx->device))), block, 0, s, sa);
@@ -2498,7 +2555,6 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
   m->resolve_blocks = RESOLVE_GRID;
   prof_begin(ctx, WS_K_TILE_RESOLVE);
-  const bool fuse = fused && !s0;
   if (s0)
     hipLaunchKernelGGL((tile_resolve_kernel<true, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   else if (fuse)
@@ -2506,6 +2562,53 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   else
     hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   prof_end(ctx, WS_K_TILE_RESOLVE);
+  // The set-up pass has counted the record slots this scan can need; its last workgroup writes the total and this scan's
+  // sequence number into host-mapped memory.  Everything above was enqueued WITHOUT waiting for that word (the march kernels
+  // check the bound themselves and do nothing if the scan does not fit), so the device runs the update back to back; the
+  // host looks at the word now -- it arrived while the later launches were being enqueued -- and, should the scan not have
+  // fitted, grows the buffers and runs the update again.  (Waiting for the word BEFORE the tail march was enqueued left the
+  // device idle for ~10 us per scan once the set-up pass got faster than the host's flag -> launch -> doorbell path.)  A hint
+  // from the previous scan is not enough: a door that opens multiplies the need.
+  {
+    volatile uint32_t *st = m->status_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (st[6] != sa.scan_seq)
+    {
+      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+      {
+        WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
+        if (st[6] != sa.scan_seq)
+        {
+          set_error("TSDF update: the set-up pass did not report its record bound");
+          return WS_ERR_INTERNAL;
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
+    if (need <= m->rec_cap) break; // the normal case
+    if (attempt > 0)
+    {
+      set_error("TSDF update: the scan did not fit the record buffers it had just been given");
+      return WS_ERR_INTERNAL;
+    }
+    if (need > 0xfffffff0ull)
+    {
+      set_error("TSDF update: the scan needs more than 2^32 candidate records");
+      return WS_ERR_CAPACITY;
+    }
+    const int rc = resize_records(m, need + need / 8); // (waits for the stream: the skipped update has drained)
+    if (rc != WS_OK) return rc;
+    sa.rec_raw = m->rec_raw;
+    sa.rec_sorted = m->rec_sorted;
+    sa.rec_cap = m->rec_cap;
+    sa.desc = m->desc;
+    sa.desc_cap = m->desc_cap;
+    sa.scan_seq = ++m->scan_seq;
+    m->prepped = true; // the skipped update put its scratch back like any other
+  }
+  } // attempts
   m->fused_done = fuse;
   m->prepped = true; // every kernel above has put back what it consumed (the free-space hash: the next scan's set-up blocks)
   WS_HIP(hipGetLastError());

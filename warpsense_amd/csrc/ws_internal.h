@@ -82,10 +82,10 @@ struct TsdfCounters // device-resident, zeroed at the start of every scatter
   uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
   uint32_t n_desc_sorted; // == desc_cursor once the tile scan has run
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
-  uint32_t setup_done;    // set-up blocks of ray_setup_sort_kernel that have counted their rays and added their record bounds
+  uint32_t pad_setup;     // (the arrival count of the set-up blocks lives in the top 16 bits of ub_total)
   uint32_t scan_done;     // scan blocks of tile_scan_kernel that have written their tiles' ranges
   uint32_t tail_next;     // next work item of the tail march (persistent workgroups)
-  unsigned long long ub_total; // sum of the per-ray record upper bounds (capacity hint for the next scan)
+  unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
   // statistics of the last update, filled by finish_update_kernel
   uint32_t last_records;
   uint32_t last_contested;
