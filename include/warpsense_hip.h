@@ -52,8 +52,8 @@ typedef enum
 } ws_status;
 
 /* Sticky device-side errors.  ws_tsdf_update* return after ENQUEUEING the kernels (like the reference,
- * update_tsdf.cu:165; they wait for the set-up pass's record bound first, where the reference blocks on its cudaMemcpys,
- * :152-154), so a problem found by the later kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact)
+ * update_tsdf.cu:165; before returning they read the record bound the set-up pass has reported meanwhile -- the reference
+ * blocks on its cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact)
  * cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the first call on the same map that
  * synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.  compat.hpp turns it into
  * the reference's print-and-exit (common.cuh:10-21). */
@@ -148,8 +148,9 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
 /* Candidate-record capacity of the scatter (records of 16 bytes, two buffers; default 32 Mi).  EVERY scan sizes the buffers
- * itself: ws_tsdf_update* waits for the bound its set-up pass computes and grows them before the tail march is enqueued, so
- * the records cannot overflow whatever the previous scan looked like.  Reserving up front only avoids the reallocation. */
+ * itself: the march kernels compare the bound its set-up pass computes with the capacity and do nothing at all if the scan
+ * does not fit, ws_tsdf_update* reads the bound before it returns and in that case grows the buffers and runs the update
+ * again -- the records cannot overflow whatever the previous scan looked like.  Reserving up front only avoids that re-run. */
 int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
 
 typedef struct
