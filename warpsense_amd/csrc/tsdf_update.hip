@@ -1020,11 +1020,11 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
 
 constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
 #ifndef WS_FREE_LANES
-#define WS_FREE_LANES 8
+#define WS_FREE_LANES 4
 #endif
 constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space part of one ray
 
-// 32 rays per workgroup, 8 lanes per ray (measured: 32 lanes 163 us, 16: 146, 8: 141, 4: 147, 1: 280): lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
+// 64 rays per workgroup, 4 lanes per ray (round 2 walk: 32 lanes 163 us, 16: 146, 8: 141, 4: 147, 1: 280; round 3 walk: 8: 123, 4: 120, 2: 131): lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
 // so every lane has the same amount of work whatever the ray length.  Waves whose rays are all RAY_SIMPLE use the
 // compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
 __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
