@@ -25,6 +25,100 @@ def calc_weight(value, tau, weight_epsilon):
     return w
 
 
+# ------------------------------------------------------------------ 0. hand-derived vectors
+# The reference's own tests pin the accept rule only for weight-0 entries and the integrate / Jacobian kernels not at all
+# (SURVEY §8c).  The vectors below are worked out BY HAND from the cited reference lines -- a second, independent reading of
+# the same source, not an execution of it (the .cu files cannot be built here): they catch a slip in the C restatement, they
+# do not replace a reference run.
+def _accept(old, new):
+    """include/warpsense/cuda/util.h:74-78 for one thread: the stored entry survives iff |old.value| < |new.value| or
+    old.weight > 0; otherwise the new entry is written (ties on |value| replace)."""
+    (ov, ow), (nv, nw) = old, new
+    return old if (abs(ov) < abs(nv) or ow > 0) else new
+
+
+def test_hand_accept_rule_truth_table():
+    L = O.lib()
+    vals = (-1000, -300, -1, 0, 1, 300, 1000)
+    weights = (-64, -10, 0, 10, 64)
+    cell = (C.c_uint32 * 1)()
+    n = 0
+    for ov in vals:
+        for ow in weights:
+            for nv in vals:
+                for nw in weights:
+                    cell[0] = int(O.pack(ov, ow))
+                    L.wso_tsdf_min(cell, int(O.pack(nv, nw)))
+                    assert tuple(int(t) for t in O.unpack(cell[0])) == _accept((ov, ow), (nv, nw)), ((ov, ow), (nv, nw))
+                    n += 1
+    assert n == 35 * 35
+    # a sequence: negative-weight candidates fold to the smallest |value| (latest on ties) until a positive weight freezes the voxel
+    cell[0] = int(O.pack(1000, 0))
+    for v, w in ((-400, -64), (250, -30), (-250, -20), (600, 64), (100, 64), (-50, -64)):
+        L.wso_tsdf_min(cell, int(O.pack(v, w)))
+    # (-400,-64) -> (250,-30) -> (-250,-20) [tie replaces] -> (600, 64) rejected (600 > 250) -> (100, 64) accepted, frozen
+    assert tuple(int(t) for t in O.unpack(cell[0])) == (100, 64)
+
+
+@pytest.mark.parametrize("existing,fresh,want", [
+    ((10, 3), (-7, 2), (3, 5)),          # both weights > 0: (10*3 + -7*2) / 5 = 16 / 5 -> 3 (update_tsdf.cu:25-28)
+    ((-10, 3), (3, 2), (-4, 5)),         # (-30 + 6) / 5 = -24 / 5 -> -4: C division truncates toward zero
+    ((200, 600), (100, 64), (190, 640)),  # (120000 + 6400) / 664 = 190; weight min(max_weight = 640, 664)
+    ((1000, 0), (-120, -47), (-120, -47)),  # first write (existing weight <= 0) copies negative weights too (:31-35)
+    ((77, -5), (40, 64), (40, 64)),      # existing weight < 0, new positive: overwritten
+    ((77, -5), (40, -9), (40, -9)),      # existing weight < 0, new negative: overwritten
+    ((77, 12), (40, -9), (77, 12)),      # existing observed, new weight negative: neither branch -> unchanged
+    ((77, 12), (40, 0), (77, 12)),       # new weight 0: unchanged
+    ((77, 0), (40, 0), (77, 0)),         # both unobserved: unchanged
+])
+def test_hand_integrate_rule(existing, fresh, want):
+    """cu_avg_tsdf_krnl, src/warpsense/cuda/update_tsdf.cu:13-43: int arithmetic, then new_map is reset to (tau, 0)."""
+    tau = 1000
+    avg = np.array([O.pack(*existing)], dtype=np.uint32)
+    new = np.array([O.pack(*fresh)], dtype=np.uint32)
+    O.lib().wso_update_avg(O._p(new), O._p(avg), 1, 640, tau)
+    assert tuple(int(t) for t in O.unpack(avg[0])) == want
+    assert tuple(int(t) for t in O.unpack(new[0])) == (tau, 0)
+
+
+def test_hand_calc_jacobis_vector():
+    """calc_jacobis_krnl, src/warpsense/cuda/registration.cu:194-257, for one point in a 7^3 map at 50 mm: voxel (1, 0, -1)
+    holds (120, w 5); x neighbours (200 | 100) -> gradient.x = 50; y neighbours (50 | 30) -> 10; z_next unobserved -> 0;
+    then with y_last = -30 (strictly opposite signs) -> gradient.y = 0.  J = (point x gradient, gradient) with the point taken
+    relative to the (int) translation of the transform."""
+    om = O.OracleMap((7, 7, 7), 1000, 0)
+    om.set_entry(1, 0, -1, 120, 5)
+    om.set_entry(2, 0, -1, 200, 1)
+    om.set_entry(0, 0, -1, 100, 1)
+    om.set_entry(1, 1, -1, 50, 1)
+    om.set_entry(1, -1, -1, 30, 1)
+    om.set_entry(1, 0, 0, 80, 0)     # z_next: weight 0 -> no z gradient
+    om.set_entry(1, 0, -2, 60, 1)
+    p = np.array([[70, 10, -60]], dtype=np.int32)  # / 50 -> (1, 0, -1) (C truncation: -60 / 50 = -1)
+    J, vals, mask = O.calc_jacobis(om, np.eye(4, dtype=np.float32), p, 50)
+    # gradient (50, 10, 0); cross = (qy*gz - qz*gy, qz*gx - qx*gz, qx*gy - qy*gx) = (600, -3000, 700 - 500)
+    assert mask[0] == 1 and vals[0] == 120 and J[0].tolist() == [600, -3000, 200, 50, 10, 0]
+    # a pure translation by (100, 0, 0): the transformed point is (70, 10, -60) again for p = (-30, 10, -60), and the
+    # Jacobian uses point - center = (-30, 10, -60): cross.z = -30*10 - 10*50 = -800
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = 100.0
+    J, vals, mask = O.calc_jacobis(om, T, np.array([[-30, 10, -60]], dtype=np.int32), 50)
+    assert mask[0] == 1 and vals[0] == 120 and J[0].tolist() == [600, -3000, -800, 50, 10, 0]
+    # strictly opposite signs across the voxel: no gradient on that axis (registration.cu:239-242)
+    om.set_entry(1, -1, -1, -30, 1)
+    J, vals, mask = O.calc_jacobis(om, np.eye(4, dtype=np.float32), p, 50)
+    assert J[0].tolist() == [0, -3000, -500, 50, 0, 0]
+    # a zero on one side is not "opposite": (50 - 0) / 2 = 25
+    om.set_entry(1, -1, -1, 0, 1)
+    J, _, _ = O.calc_jacobis(om, np.eye(4, dtype=np.float32), p, 50)
+    assert J[0].tolist()[3:] == [50, 25, 0]
+    # unobserved centre voxel, and a voxel on the border (in_bounds_with_buffer_neg(buf, 1), :217): no correspondence
+    om.set_entry(1, 0, -1, 120, 0)
+    assert O.calc_jacobis(om, np.eye(4, dtype=np.float32), p, 50)[2][0] == 0
+    om.set_entry(3, 0, 0, 120, 5)
+    assert O.calc_jacobis(om, np.eye(4, dtype=np.float32), np.array([[160, 10, 10]], dtype=np.int32), 50)[2][0] == 0
+
+
 # ------------------------------------------------------------------ 1. reference KATs
 def test_kat_tsdf_write_cuda_semantics():
     """test/map.cpp:9-90 and test/cuda.cpp:268-414: point (5500,500,500), res 1000, tau 3000, 21^3 map."""
