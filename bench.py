@@ -234,6 +234,9 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         elapsed = reduce_max(elapsed)
+        if exchange.startswith("device-side") and backend.peers is None:  # the group left that route (repeated time-outs)
+            exchange = ("RCCL all-reduce of 44 int64 per iteration, 16 iterations per HIP graph (the device-side exchange kept timing out "
+                        "on this node and was dropped; the warm-up and timed steps include those time-outs)")
     ms, cnt = ctx.prof_read(_lib.WS_K_UPDATE)
     update_span_us = 1000.0 * ms / cnt if cnt else None
     ms, cnt = ctx.prof_read(_lib.WS_K_INTEGRATE)

@@ -154,3 +154,70 @@ def test_sharded_registration_is_exact_over_gloo(world, drop):
     it, it_ref, err = q.get(timeout=10)
     assert it == it_ref and it > 3
     assert err == 0.0
+
+
+class FlakyPeerBackend(OracleGnBackend):
+    """OracleGnBackend that also offers the device-side route -- and whose exchange never completes on rank 1 (a node whose
+    mapped mailboxes do not carry the atomics): what sharded_register_cloud does about it is host logic, testable here."""
+
+    def __init__(self, omap, points, res, rank, world):
+        super().__init__(omap, points, res)
+        self.rank, self.peers, self.calls, self.resets, self.drops = rank, (rank, world), 0, 0, 0
+
+    def register_peers(self, first, count, T_in, max_iterations, it_weight_gradient, epsilon):
+        self.calls += 1
+        return None if self.rank == 1 else (np.full((4, 4), 7.0, dtype=np.float32), 1)  # rank 0 "finished" with something else
+
+    def reset_peers(self):
+        self.resets += 1
+
+    def drop_peers(self):
+        self.drops += 1
+        self.peers = None
+
+
+def _flaky_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from warpsense_amd import synthetic as S
+    from warpsense_amd.dist import PEER_TIMEOUTS_BEFORE_GIVING_UP, sharded_register_cloud
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tau, res, mw, size = 1000, 50, 640, (96, 96, 48)
+        pts = S.os1_128_scan(rings=32, azimuths=128, half_extents_mm=(2000.0, 1700.0, 800.0), seed=5)
+        avg = O.OracleMap(size, tau, 0)
+        new = avg.copy()
+        O.update_tsdf(avg, new, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+        cloud = S.transform_points_mm(pts, S.perturbation(25, -15, 5, 1.2))
+        backend = FlakyPeerBackend(avg, cloud, res, rank, world)
+        T_ref, it_ref, _ = O.register_cloud(avg, cloud, np.eye(4), 60, 0.1, 0.03, res)
+        exact = []
+        for _ in range(PEER_TIMEOUTS_BEFORE_GIVING_UP + 2):
+            T, it = sharded_register_cloud(backend, cloud.shape[0], np.eye(4, dtype=np.float32), 60, 0.1, 0.03, batch=7)
+            exact.append(it == it_ref and bool(np.array_equal(T, T_ref.astype(np.float32))))
+        q.put((rank, exact, backend.calls, backend.resets, backend.drops, backend.peers, PEER_TIMEOUTS_BEFORE_GIVING_UP))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_group_whose_device_side_exchange_keeps_timing_out_leaves_that_route_together():
+    """rank 1's exchange times out every time, rank 0's does not: every registration still ends exact on BOTH ranks (the ranks
+    agree on the verdict before anyone returns, so rank 0's own result is discarded), and after
+    PEER_TIMEOUTS_BEFORE_GIVING_UP time-outs in a row both ranks drop the route for good -- no 0.25 s stall per scan."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flaky_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank, exact, calls, resets, drops, peers, limit in sorted(q.get(timeout=10) for _ in range(2)):
+        assert all(exact) and len(exact) == limit + 2, (rank, exact)
+        assert calls == limit and resets == limit - 1 and drops == 1 and peers is None, (rank, calls, resets, drops, peers)

@@ -19,6 +19,7 @@ from ._lib import check
 
 
 GRAPH_CACHE_MAX = 8  # captured batches kept by sharded_register_cloud's `graphs` dict
+PEER_TIMEOUTS_BEFORE_GIVING_UP = 2  # consecutive exchange time-outs after which a group stops using the device-side route
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -126,6 +127,11 @@ class HipGnBackend:
 
     def reset_peers(self):
         check(self._L.ws_reg_peer_reset(self.reg.handle), "ws_reg_peer_reset")
+
+    def drop_peers(self):
+        """leave the device-side route for good (sharded_register_cloud after repeated time-outs): unmap the peers' mailboxes"""
+        check(self._L.ws_reg_peer_disconnect(self.reg.handle), "ws_reg_peer_disconnect")
+        self.peers = None
 
     def register_peers(self, first: int, count: int, T_in, max_iterations, it_weight_gradient, epsilon):
         """ws_register_cloud_peers: the whole Gauss-Newton loop in one launch per rank.  Returns (T 4x4, iterations), or None
@@ -283,10 +289,18 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             ok = bool(int(flag.item()))
         if ok:
+            backend.peer_timeouts = 0
             return res
         import sys
-        print("[warpsense_amd.dist] the device-side exchange timed out; this registration runs through the all-reduce route", file=sys.stderr)
-        backend.reset_peers()
+        # every rank saw the same verdict above, so every rank counts alike and they leave the route together
+        backend.peer_timeouts = getattr(backend, "peer_timeouts", 0) + 1
+        give_up = backend.peer_timeouts >= PEER_TIMEOUTS_BEFORE_GIVING_UP
+        print("[warpsense_amd.dist] the device-side exchange timed out; this registration runs through the all-reduce route"
+              + (" and so do all later ones (time-out %d in a row)" % backend.peer_timeouts if give_up else ""), file=sys.stderr)
+        if give_up:
+            backend.drop_peers()
+        else:
+            backend.reset_peers()
         if world > 1:
             dist.barrier(group=group)
     runner = None
