@@ -1,7 +1,7 @@
 """Fixed and per-iteration cost of the resident registration loop: reg_loop_kernel timed (hipEvents on the library's
 stream) for several max_iterations on the benchmark scan, least-squares line through the points.
 
-    python tools/reg_fit.py
+    python tools/reg_fit.py [--points N]      (N: only the first N points of every ring-interleaved selection of the cloud)
 """
 import os
 import sys
@@ -12,6 +12,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=0, help="register a subset of this many points (spread evenly over the scan)")
+    args = ap.parse_args()
     import torch
     import warpsense_amd as W
     from warpsense_amd import _lib
@@ -22,7 +26,11 @@ def main():
     pts = S.os1_128_scan()
     tsdf.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
     reg = W.RegistrationCuda(None)
-    q = torch.from_numpy(S.transform_points_mm(pts, S.perturbation(100, 100, 0, 5.0))).cuda()
+    cloud = S.transform_points_mm(pts, S.perturbation(100, 100, 0, 5.0))
+    if args.points:
+        cloud = np.ascontiguousarray(cloud[np.linspace(0, len(cloud) - 1, args.points).astype(np.int64)])
+    print(f"cloud: {len(cloud)} points")
+    q = torch.from_numpy(cloud).cuda()
     reg.prepare_registration(q)
     ctx = tsdf.ctx
     eye = np.eye(4, dtype=np.float32)

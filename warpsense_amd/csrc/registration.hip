@@ -167,6 +167,7 @@ __device__ __forceinline__ void wave_reduce32(int64_t (&v)[REG_SLOTS], int64_t (
 
 // The same with the eight wave totals of a slot ADDED into wg_sum[slot] (LDS atomics, zero before) instead of laid side by
 // side: the first wave then reads one value per slot instead of eight (valid after the trailing barrier).
+// (the caller's barrier follows: a wave without points skips this call, not the barrier)
 __device__ __forceinline__ void wave_reduce32_add(int64_t (&v)[REG_SLOTS], unsigned long long *wg_sum)
 {
   const int lane = threadIdx.x & 63;
@@ -177,7 +178,6 @@ __device__ __forceinline__ void wave_reduce32_add(int64_t (&v)[REG_SLOTS], unsig
   reduce_stage<1, 2>(v, lane);
   v[0] = wadd64(v[0], dpp_xor_i64<1>(v[0]));
   if ((lane & 1) == 0) atomicAdd(&wg_sum[lane >> 1], (unsigned long long)v[0]);
-  __syncthreads();
 }
 
 // Sum REG_SLOTS per-lane values over the whole workgroup. Result: red[0..31] in LDS (valid after the
@@ -623,6 +623,13 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
 
 constexpr uint32_t REG_STRIDE = REG_BLOCKS * REG_THREADS; // points covered by one pass of the grid
 
+// Which point a thread takes in pass u of the grid: the grid's WAVES in the order (wave-in-workgroup, workgroup), 64 consecutive
+// points each.  A cloud (or a rank's shard) smaller than one pass then fills wave 0 of every workgroup before wave 1 of any:
+// the points are spread over all compute units, and a workgroup's unused waves skip the accumulate and reduce phases, so the
+// phase costs a 16 384-point shard (1 wave per workgroup) a third of what it costs the full cloud (8 waves, two per SIMD).
+// With workgroup-major order the same shard filled 32 workgroups to the brim and left 224 idle: no gain from sharding at all.
+__device__ __forceinline__ uint32_t point_slot() { return (((threadIdx.x >> 6) * gridDim.x + blockIdx.x) << 6) + (threadIdx.x & 63u); }
+
 // raw coordinates of this lane's first two points, loaded before anything else in the kernel
 struct Prefetched
 {
@@ -635,7 +642,7 @@ __device__ __forceinline__ Prefetched prefetch_points(const PointArgs &a, const 
 #pragma unroll
   for (int u = 0; u < 2; ++u)
   {
-    const uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x + (uint32_t)u * REG_STRIDE;
+    const uint32_t idx = a.first + point_slot() + (uint32_t)u * REG_STRIDE;
     f.valid[u] = idx < a.end;
     const size_t o = f.valid[u] ? 3 * (size_t)idx : 0;
     f.p[u][0] = f.valid[u] ? a.points[o + 0] : 0;
@@ -661,7 +668,7 @@ __device__ __forceinline__ void accumulate_points(const PointArgs &a, const floa
   else
     consume_point(g0, acc);
   // clouds larger than two passes of the grid (N > 131 072)
-  for (uint32_t idx = a.first + blockIdx.x * REG_THREADS + threadIdx.x + 2 * REG_STRIDE; idx < a.end; idx += REG_STRIDE)
+  for (uint32_t idx = a.first + point_slot() + 2 * REG_STRIDE; idx < a.end; idx += REG_STRIDE)
   {
     const Gathered g = gather_point(a, t, a.points[3 * (size_t)idx + 0], a.points[3 * (size_t)idx + 1], a.points[3 * (size_t)idx + 2], true);
     consume_point(g, acc);
@@ -991,6 +998,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   __shared__ int stop_sh;
 
   const Prefetched pref = prefetch_points(a.pts, stride);
+  const bool wave_has_points = __ballot(pref.valid[0]) != 0ull; // later passes of the grid only have points where the first has
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
   uint64_t mb_then0 = 0, mb_then1 = 0; // first wave, PEERS: this lane's mailbox words of both parities when last complete
@@ -1059,19 +1067,23 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
     WS_LSTAMP(3);
     if (stop_sh) break;
 
-    float T[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
-    int64_t acc[REG_SLOTS];
-#pragma unroll
-    for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
 #ifdef WS_REG_TIMING
     const int32_t obx = cache[0].bx, oby = cache[0].by, obz = cache[0].bz;
     const bool ofilled = cache[0].filled;
 #endif
-    accumulate_points<true>(a.pts, T, pref, acc, cache, stride);
-    WS_LSTAMP(4);
-    wave_reduce32_add(acc, wg_sum);
+    if (wave_has_points) // (uniform per wave; point_slot(): a small cloud or shard leaves whole waves of every workgroup without points)
+    {
+      float T[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+      int64_t acc[REG_SLOTS];
+#pragma unroll
+      for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+      accumulate_points<true>(a.pts, T, pref, acc, cache, stride);
+      WS_LSTAMP(4);
+      wave_reduce32_add(acc, wg_sum);
+    }
+    __syncthreads();
     WS_LSTAMP(5);
     if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0), per_group);
 #ifdef WS_REG_TIMING
