@@ -17,6 +17,10 @@
  *   - every function returns WS_OK (0) or a negative ws_status; ws_last_error() gives the message of
  *     the calling thread's last failure.  Nothing throws across the ABI.
  *   - work is stream-ordered on the context's HIP stream; functions that return host data synchronise.
+ *   - threads and devices: like the reference's CUDA classes the library launches on the CALLING thread's current device.
+ *     ws_ctx_create(device_id) makes that device current for the creating thread; a further thread that uses the context's
+ *     handles on a multi-GPU node calls hipSetDevice(device_id) once first (HIP's current device is per thread and starts
+ *     at 0).  ws_shift_wait / _slab / _end only wait on streams and may be called from any thread as they are.
  *
  * Result semantics: the TSDF scatter is resolved in the canonical serial order of the reference kernel
  * (ascending point index, ray step, fan step — SURVEY.md §7 H1), so results are deterministic and
