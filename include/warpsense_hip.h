@@ -246,6 +246,10 @@ int ws_debug_block_stats(ws_map *map, uint32_t *out, size_t words);
  * registration with one launch per iteration. *fallbacks (may be NULL) receives how often that has happened on `reg`. */
 int ws_debug_reg_stall(ws_reg *reg, int32_t stall_next, int32_t *fallbacks);
 
+/* Test entry: the 44 sums (h[36] column-major, g[6], e, c -- the out-parameters of perform_registration, registration.cu:347-368)
+ * the LAST Gauss-Newton update of the last ws_register_cloud / ws_register_cloud_peers on `reg` was made from.  Synchronises. */
+int ws_debug_reg_sums(ws_reg *reg, int64_t sums_out[44]);
+
 /* ------------------------------------------------------------------ scan pre-processing ---- */
 /* App::preprocess — src/warpsense/app.cpp:119-148, on the device: sensor points in float metres
  * (x y z first, `stride_floats` floats per point, e.g. 3, or 4 for PointXYZI) are dropped if x, y and z are all

@@ -245,3 +245,52 @@ def test_sharded_driver_on_one_rank_equals_the_resident_loop():
     backend = HipGnBackend(reg.reg_, reg.tsdf(), res)
     T2, it2 = sharded_register_cloud(backend, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03)
     assert it1 == it2 and np.array_equal(T1, T2)
+
+
+@pytest.mark.parametrize("n,res", [(4096, 2000), (131072, 2000), (1000, 50), (200_000, 2000)])
+def test_loop_sums_on_a_map_of_arbitrary_entries(n, res):
+    """The resident loop's sums on inputs that use the whole width of the arithmetic.  The map holds RANDOM raw entries: values
+    over all of int16 (incl. -32768 / 32767), half of them same-sign extremes next to each other (gradients of +-16383), weights
+    of any sign, a fifth unobserved.  The points lie up to 120 m out and the pretransform carries a 54 m translation, so the
+    integer transform wraps for many of them (cu_transform_point, cuda/util.h:11-22: int32) and the cross products q x gradient
+    cover all of int32 -- the test asserts values beyond +-0x7f7f7f80, where a signed-limb split without a bias would fail.
+    Clouds of at most 131 072 points take the matrix-core route (J as byte limbs, v_mfma_i32_32x32x32_i8), the larger one the
+    v_mad_i64_i32 route: h, g, e, c of the last iteration, the pose and the iteration count must be the oracle's, bit for bit,
+    in both loop modes."""
+    import warpsense_amd as W
+    rng = np.random.default_rng(1000 + n)
+    size = (65, 65, 65) if res >= 900 else (129, 129, 65)
+    n_vox = size[0] * size[1] * size[2]
+    value = rng.integers(-32768, 32768, n_vox).astype(np.int64)
+    ext = np.where(rng.random(n_vox) < 0.5, 32767, 1)
+    value = np.where(rng.random(n_vox) < 0.5, np.where((np.arange(n_vox) // (size[1] * size[2])) % 2 == 0, ext, -ext - 1), value)
+    weight = rng.integers(-32768, 32768, n_vox).astype(np.int64)
+    weight[rng.random(n_vox) < 0.2] = 0
+    raw = ((value & 0xffff) | ((weight & 0xffff) << 16)).astype(np.uint32)
+    om = O.OracleMap(size, 0, 0, data=raw.copy())
+    view = W.DeviceMap(om.size.copy(), om.offset.copy(), raw.copy(), om.pos.copy())
+    tsdf = W.TSDFCuda(view, 1000, 640, res)
+    reach = 120_000 if res >= 900 else 3_000
+    q = rng.integers(-reach, reach + 1, (n, 3)).astype(np.int32)
+    T_in = S.perturbation(40_000, -30_000, 20_000, 3.0) if res >= 900 else S.perturbation(20, -15, 10, 3.0)
+    if n == 131072:
+        J = np.asarray(O.calc_jacobis(om, T_in, q, res)[0]).astype(np.int64)
+        assert (J[:, :3] > 0x7F7F7F80).any() and (J[:, :3] < -0x7F7F7F80).any()
+    rc = W.RegistrationCuda(None, tsdf.ctx)
+    rc.prepare_registration(q)
+    for max_it in (1, 2, 6):
+        T_o, it_o, trace = O.register_cloud(om, q, T_in, max_it, 0.1, 0.03, res, trace_cap=8)
+        assert it_o >= 1
+        ho = trace[it_o - 1][:36].reshape(6, 6).T
+        go, eo, co = trace[it_o - 1][36:42], int(trace[it_o - 1][42]), int(trace[it_o - 1][43])
+        assert co > n // 4 and np.abs(ho).max() > 2 ** 50  # observed voxels under most points; sums far beyond 32 bits
+        for mode in (W.WS_REG_LOOP_RESIDENT, W.WS_REG_LOOP_LAUNCHES):
+            rc.set_loop(mode)
+            T, it = rc.register_cloud(tsdf.device_map(), T_in, max_it, 0.1, 0.03, res)
+            h, g, e, c = rc.last_sums()
+            assert it == it_o, (mode, max_it, it, it_o)
+            assert (e, c) == (eo, co), (mode, max_it, e, eo, c, co)
+            assert np.array_equal(g, go), (mode, max_it)
+            assert np.array_equal(h, ho), (mode, max_it)
+            assert np.array_equal(T, T_o.astype(np.float32)), (mode, max_it, np.abs(T - T_o).max())
+    rc.close()

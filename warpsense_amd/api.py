@@ -615,6 +615,12 @@ class RegistrationCuda:
               "ws_register_cloud")
         return out.reshape(4, 4).T.copy(), it.value
 
+    def last_sums(self):
+        """(h 6x6 int64, g[6], e, c) the last Gauss-Newton update of the last register_cloud was made from (test entry)"""
+        out = np.empty(44, dtype=np.int64)
+        check(self._L.ws_debug_reg_sums(self.handle, _ptr(out)), "ws_debug_reg_sums")
+        return out[:36].reshape(6, 6).T.copy(), out[36:42].copy(), int(out[42]), int(out[43])
+
     def set_loop(self, mode: int):
         """WS_REG_LOOP_RESIDENT (one launch, grid barrier; default) or WS_REG_LOOP_LAUNCHES (one launch per iteration)."""
         check(self._L.ws_reg_set_loop(self.handle, int(mode)), "ws_reg_set_loop")

@@ -1204,6 +1204,14 @@ int ws_debug_reg_stall(ws_reg *r, int32_t stall_next, int32_t *fallbacks)
   return WS_OK;
 }
 
+int ws_debug_reg_sums(ws_reg *r, int64_t sums_out[44])
+{
+  if (!r || !sums_out) return invalid("ws_debug_reg_sums: NULL argument");
+  WS_HIP(hipMemcpyAsync(sums_out, r->state[r->latest].sums, 44 * sizeof(int64_t), hipMemcpyDeviceToHost, r->ctx->stream));
+  WS_HIP(hipStreamSynchronize(r->ctx->stream));
+  return WS_OK;
+}
+
 int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status)
 {
   if (!ctx || !A || !b || !x || !status) return invalid("ws_debug_solve6: NULL argument");

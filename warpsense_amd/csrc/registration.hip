@@ -33,6 +33,9 @@ constexpr int REG_BLOCKS = WS_REG_BLOCKS; // one workgroup per CU
 #define WS_REG_THREADS 512
 #endif
 constexpr int REG_THREADS = WS_REG_THREADS; // 8 waves: one point per lane for a 131 072-point scan (4 waves x 2 points: 10.7 vs 10.1 us)
+#ifndef WS_REG_MFMA
+#define WS_REG_MFMA 1 // 0: the resident loop sums with v_mad_i64_i32 + the transposing butterfly for every cloud size
+#endif
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
@@ -595,21 +598,27 @@ __device__ __forceinline__ int32_t central_gradient(uint32_t next, uint32_t last
   return ((nv - lv) / 2) & keep;
 }
 
-__device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[REG_SLOTS])
+// J (registration.cu:224-250), the voxel's value and whether the point counts, all zero for a point that does not
+__device__ __forceinline__ void point_terms(const Gathered &g, int32_t (&J)[6], int32_t &v, int32_t &used)
 {
   // a point outside the map or in an unobserved voxel (registration.cu:217-222) contributes zeros
-  const int32_t used = (g.ok ? 1 : 0) & ((g.cur >> 16) != 0u);
+  used = (g.ok ? 1 : 0) & ((g.cur >> 16) != 0u);
   const int32_t keep = -used;
   const int32_t gx = central_gradient(g.xn, g.xl) & keep, gy = central_gradient(g.yn, g.yl) & keep, gz = central_gradient(g.zn, g.zl) & keep;
   // point.cross(gradient) in int (math/vector3.h:269-277); J = (cross, gradient) as long
-  int32_t J[6];
   J[0] = wsub(wmul(g.qy, gz), wmul(g.qz, gy));
   J[1] = wsub(wmul(g.qz, gx), wmul(g.qx, gz));
   J[2] = wsub(wmul(g.qx, gy), wmul(g.qy, gx));
   J[3] = gx;
   J[4] = gy;
   J[5] = gz;
-  const int32_t v = entry_value(g.cur) & keep;
+  v = entry_value(g.cur) & keep;
+}
+
+__device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[REG_SLOTS])
+{
+  int32_t J[6], v, used;
+  point_terms(g, J, v, used);
   // 21 unique terms of J J^T (registration.cu:55-97); int32 x int32 + int64 maps onto v_mad_i64_i32
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -619,6 +628,169 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
   for (int i = 0; i < 6; ++i) acc[21 + i] = wadd64(acc[21 + i], (int64_t)J[i] * (int64_t)v);
   acc[27] += (v < 0 ? -v : v);
   acc[28] += used;
+}
+
+// ---- the same sums on the matrix cores (resident loop, clouds of at most one point per lane) ---------------------------
+// h = sum J J^T, g = sum J v, e = sum |v|, c = sum 1 are one Gram matrix A A^T over the points, and v_mfma_i32_32x32x32_i8
+// computes exactly that -- in int32, exactly -- for rows of signed bytes.  A point's 32 rows are the bytes of 8 dwords:
+//   d0..d5  J[0..5] ^ 0x00808080   limbs s0 s1 s2 s3 with J = s0 + 256 s1 + 65536 s2 + 2^24 s3 + 0x808080  (s3: the sign byte;
+//           the three low bytes become SIGNED limbs by flipping their top bit, i.e. by carrying a bias of 128 each)
+//   d6      (v ^ 0x80) | (n ^ 0x80) << 16   with n = -|v|: two limbs each (v, n in [-32768, 32767]), bias 128
+//   d7      1 | used << 8                   a row of ones (what multiplies the biases) and the row that counts
+// One instruction multiplies the 32 x 32 rows of 32 points; the SAME register is its A and its B operand (B[k][j] = A[j][k]),
+// so whatever order the hardware gives the 32 points inside the operand, a row meets itself in the same order.  Lane (r, half)
+// must supply row r of 16 points, while a point's rows are computed in ONE lane: the wave's 8 x 64 dwords pass through LDS
+// ([dword][point], rows 68 words apart so that the eight 128-bit reads of a wave land in different banks), lane (r, half) reads
+// the 16 points' dword r / 4 and picks byte r % 4 of each with v_perm_b32.  Two instructions per wave replace 27
+// v_mad_i64_i32 per lane AND the 190-instruction transposing butterfly: the K dimension of the product is the reduction
+// over the lanes.  What comes out, per wave: C[a][b] = sum over its 64 points of limb a x limb b.  Lane (b, half) holds rows
+// 8g + 4 half + t: the four limbs t of dword 2g + half, i.e. (Horner) the sum over the points of Js_i x (limb b % 4 of dword
+// b / 4); shifted by 8 (b % 4) it goes straight into the workgroup's slot with an LDS atomic -- the 4 limb columns of a dword
+// meet there.  The biases: sum (Js_i + B)(Js_j + B) = sum Js_i Js_j + B (T_i + T_j) + B^2 N with T_i = sum Js_i x 1 (the ones
+// column) and N = sum 1 x 1, all from the same product; the first wave adds those terms once per iteration when it reads the
+// slots (mfma_finalize).  Everything is integer arithmetic mod 2^64 like the int64 sums it replaces: bit-identical.
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+typedef int mf_v16i __attribute__((ext_vector_type(16)));
+constexpr int MF_ROW_STRIDE = 68;                  // words between the staged dwords of a point
+constexpr int MF_STAGE_WORDS = 8 * MF_ROW_STRIDE;  // per wave
+constexpr int MF_AUX = 8;                          // behind the 32 slots: T_0..T_5, sum vs, N
+constexpr uint32_t MF_NONE = 0xffffffffu;
+constexpr uint64_t MF_BJ = 0x00808080ull, MF_BV = 0x80ull;
+
+struct MfLane // constants of a lane
+{
+  uint32_t sel;     // v_perm selector: byte (lane % 4) of two dwords
+  uint32_t rd;      // first staged word this lane reads
+  uint32_t shift;   // 8 x (column limb)
+  uint32_t slot[3]; // where the lane's values of g = 0, 1, 2 go (index into wg_sum[32 + MF_AUX]), MF_NONE: nowhere
+  // first wave, lane -> slot (lane & 31): raw + ca * aux[ia] + cb * aux[ib] + cn * N
+  uint32_t ia, ib;
+  uint64_t ca, cb, cn;
+};
+__device__ __forceinline__ MfLane make_mf_lane()
+{
+  MfLane L;
+  const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, jd = j >> 2, m = j & 3;
+  L.sel = (uint32_t)m | ((uint32_t)(4 + m) << 8) | ((uint32_t)m << 16) | ((uint32_t)(4 + m) << 24);
+  L.rd = (uint32_t)(jd * MF_ROW_STRIDE + 16 * half);
+  L.shift = (uint32_t)(8 * m);
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+  {
+    const int i = 2 * g + half;
+    uint32_t t = MF_NONE;
+    if (jd < 6 && i <= jd)
+      t = (uint32_t)tri_index(i, jd);
+    else if (jd == 6 && m < 2)
+      t = (uint32_t)(21 + i); // the value's two limbs as columns: g[i]
+    else if (j == 28)
+      t = (uint32_t)(REG_SLOTS + i); // the ones column: T_i
+    L.slot[g] = t;
+  }
+  const int slot = lane & 31;
+  L.ia = L.ib = 0;
+  L.ca = L.cb = L.cn = 0;
+  if (slot < 21)
+  {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int jj = i; jj < 6; ++jj)
+        if (tri_index(i, jj) == slot)
+        {
+          L.ia = (uint32_t)i;
+          L.ib = (uint32_t)jj;
+        }
+    L.ca = L.cb = MF_BJ;
+    L.cn = MF_BJ * MF_BJ;
+  }
+  else if (slot < 27)
+  {
+    L.ia = (uint32_t)(slot - 21);
+    L.ib = 6; // sum vs
+    L.ca = MF_BV;
+    L.cb = MF_BJ;
+    L.cn = MF_BJ * MF_BV;
+  }
+  else if (slot == 27)
+    L.cn = MF_BV; // e = -(sum ns + 128 N)
+  return L;
+}
+
+// one point per lane (all 64 lanes active; a lane without a point has g.ok == false): C += A A^T of the wave's 64 points
+__device__ __forceinline__ void mfma_consume(const Gathered &g, mf_v16i &C, uint32_t *stage /* this wave's MF_STAGE_WORDS */, const MfLane &L)
+{
+  int32_t J[6], v, used;
+  point_terms(g, J, v, used);
+  const int lane = threadIdx.x & 63;
+  const int32_t n = v < 0 ? v : -v;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) stage[i * MF_ROW_STRIDE + lane] = (uint32_t)J[i] ^ (uint32_t)MF_BJ;
+  stage[6 * MF_ROW_STRIDE + lane] = (((uint32_t)v ^ (uint32_t)MF_BV) & 0xffffu) | (((uint32_t)n ^ (uint32_t)MF_BV) << 16);
+  stage[7 * MF_ROW_STRIDE + lane] = 1u | ((uint32_t)used << 8);
+  __builtin_amdgcn_wave_barrier(); // (LDS serves a wave's accesses in order: the reads below see all 64 lanes' writes)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+  {
+    uint32_t x[16];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+    {
+      const uint4 t = *reinterpret_cast<const uint4 *>(&stage[L.rd + 32 * q + 4 * w]);
+      x[4 * w + 0] = t.x; x[4 * w + 1] = t.y; x[4 * w + 2] = t.z; x[4 * w + 3] = t.w;
+    }
+    mf_v4i a;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+    {
+      const uint32_t t01 = __builtin_amdgcn_perm(x[4 * w + 1], x[4 * w + 0], L.sel);
+      const uint32_t t23 = __builtin_amdgcn_perm(x[4 * w + 3], x[4 * w + 2], L.sel);
+      a[w] = (int)__builtin_amdgcn_perm(t23, t01, 0x05040100u);
+    }
+    C = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, C, 0, 0, 0);
+  }
+  __builtin_amdgcn_wave_barrier(); // the next call's writes stay behind these reads
+}
+
+// the wave's product into the workgroup's slots (wg_sum[32 + MF_AUX], zero before the iteration)
+__device__ __forceinline__ void mfma_flush(const mf_v16i &C, unsigned long long *wg_sum, const MfLane &L)
+{
+  const int lane = threadIdx.x & 63;
+  int32_t lo[4], hi[4]; // |C| <= 2^14 x 64 points: the pairs fit 32 bits
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+  {
+    lo[g] = C[4 * g + 1] * 256 + C[4 * g + 0];
+    hi[g] = C[4 * g + 3] * 256 + C[4 * g + 2];
+  }
+  // The four limb columns of a dword are four adjacent lanes and meet in the slot itself: 48 lanes on 12 addresses per
+  // instruction.  (Summing them over the quad first -- two DPP stages, one lane adds -- is slower: 5.49 vs 5.38 us per iteration.)
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+  {
+    const int64_t P = (int64_t)hi[g] * 65536 + (int64_t)lo[g];
+    if (L.slot[g] != MF_NONE) atomicAdd(&wg_sum[L.slot[g]], (unsigned long long)P << L.shift);
+  }
+  // rows 24..27 (lower half): the limbs of v and n; rows 28, 29 (upper half): ones and used -- against the ones column (28)
+  if (lane == 28 || lane == 60)
+  {
+    const bool up = lane == 60;
+    atomicAdd(&wg_sum[up ? REG_SLOTS + 7 : REG_SLOTS + 6], (unsigned long long)(int64_t)(up ? C[12] : lo[3])); // N : sum vs
+    atomicAdd(&wg_sum[up ? 28 : 27], (unsigned long long)(int64_t)(up ? C[13] : hi[3]));                       // c : sum ns
+  }
+}
+
+// first wave, after the barrier: the value of slot (lane & 31) with the bias terms added; leaves the slots zero
+__device__ __forceinline__ unsigned long long mfma_finalize(unsigned long long *wg_sum, const MfLane &L)
+{
+  const int lane = threadIdx.x & 63, slot = lane & 31;
+  const unsigned long long raw = wg_sum[slot], Ta = wg_sum[REG_SLOTS + L.ia], Tb = wg_sum[REG_SLOTS + L.ib], N = wg_sum[REG_SLOTS + 7];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < REG_SLOTS) wg_sum[slot] = 0;
+  if (lane < MF_AUX) wg_sum[REG_SLOTS + lane] = 0;
+  unsigned long long s = raw + L.ca * Ta + L.cb * Tb + L.cn * N;
+  if (slot == 27) s = 0ull - s;
+  return s;
 }
 
 constexpr uint32_t REG_STRIDE = REG_BLOCKS * REG_THREADS; // points covered by one pass of the grid
@@ -842,12 +1014,19 @@ constexpr long long REG_BARRIER_TIMEOUT_TICKS = 500000ll;
 constexpr long long REG_PEER_TIMEOUT_TICKS = 25000000ll;
 
 // first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
+template <bool MFMA = false>
 __device__ __forceinline__ void counted_publish(uint64_t *accum /* [REG_GROUPS][REG_WORDS] of this parity */, unsigned long long *wg_sum, bool publish,
-                                                const uint32_t per_group = REG_BLOCKS / REG_GROUPS)
+                                                const uint32_t per_group = REG_BLOCKS / REG_GROUPS, const MfLane *mf = nullptr)
 {
   const int lane = threadIdx.x & 63, slot = lane & (REG_SLOTS - 1);
-  const unsigned long long s = wg_sum[slot];
-  if (lane < REG_SLOTS) wg_sum[slot] = 0; // for the next iteration (the same wave read it one instruction ago)
+  unsigned long long s;
+  if (MFMA)
+    s = mfma_finalize(wg_sum, *mf);
+  else
+  {
+    s = wg_sum[slot];
+    if (lane < REG_SLOTS) wg_sum[slot] = 0; // for the next iteration (the same wave read it one instruction ago)
+  }
   if (!publish) return;
   const uint32_t half = lane < REG_SLOTS ? (uint32_t)((uint64_t)s & 0xffffffffull) : (uint32_t)((uint64_t)s >> 32);
   const int group = (int)(blockIdx.x / per_group);
@@ -987,12 +1166,16 @@ constexpr size_t REG_ACCUM_OFFSET = 256; // accumulators behind the abort flag
 
 // PEERS: this rank's shard of the points, a grid of any multiple of REG_GROUPS workgroups (ranks that share one GPU in the
 // tests split the chip), and the cross-GPU exchange behind the on-chip one
-template <bool PEERS>
+// MFMA: the cloud (shard) has at most one point per lane -- every real scan: the reference's RegistrationCuda holds 131 072
+// points -- and the sums come from the matrix cores (mfma_consume above)
+template <bool PEERS, bool MFMA>
 __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 {
   const uint32_t n_blocks = PEERS ? gridDim.x : (uint32_t)REG_BLOCKS, stride = n_blocks * REG_THREADS, per_group = n_blocks / REG_GROUPS;
   uint32_t *const abort_flag = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.accum) - REG_ACCUM_OFFSET);
-  __shared__ unsigned long long wg_sum[REG_SLOTS]; // the workgroup's totals of an iteration (LDS atomics of the eight waves)
+  __shared__ unsigned long long wg_sum[REG_SLOTS + MF_AUX]; // the workgroup's totals of an iteration (LDS atomics of the eight waves)
+  __shared__ alignas(16) uint32_t mf_stage[MFMA ? (REG_THREADS / 64) * MF_STAGE_WORDS : 4];
+  const MfLane mfl = make_mf_lane();
   __shared__ int64_t red[REG_SLOTS];
   __shared__ alignas(16) float T_sh[16];
   __shared__ int stop_sh;
@@ -1036,7 +1219,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #define WS_LSTAMP(i)
 #endif
   if (threadIdx.x < 16) T_sh[threadIdx.x] = a.init.T[threadIdx.x];
-  if (threadIdx.x < REG_SLOTS) wg_sum[threadIdx.x] = 0;
+  if (threadIdx.x < REG_SLOTS + MF_AUX) wg_sum[threadIdx.x] = 0;
   uint32_t k = 0;
   for (;; ++k)
   {
@@ -1076,16 +1259,31 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
       float T[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
-      int64_t acc[REG_SLOTS];
+      if (MFMA)
+      {
+        const IntTransform t = make_int_transform(T);
+        const Gathered g0 = gather_point<true>(a.pts, t, pref.p[0][0], pref.p[0][1], pref.p[0][2], pref.valid[0], &cache[0]);
+        mf_v16i C;
 #pragma unroll
-      for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-      accumulate_points<true>(a.pts, T, pref, acc, cache, stride);
-      WS_LSTAMP(4);
-      wave_reduce32_add(acc, wg_sum);
+        for (int i = 0; i < 16; ++i) C[i] = 0;
+        mfma_consume(g0, C, mf_stage + (threadIdx.x >> 6) * MF_STAGE_WORDS, mfl);
+        WS_LSTAMP(4);
+        mfma_flush(C, wg_sum, mfl);
+      }
+      else
+      {
+        int64_t acc[REG_SLOTS];
+#pragma unroll
+        for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+        accumulate_points<true>(a.pts, T, pref, acc, cache, stride);
+        WS_LSTAMP(4);
+        wave_reduce32_add(acc, wg_sum);
+      }
     }
     __syncthreads();
     WS_LSTAMP(5);
-    if (threadIdx.x < 64) counted_publish(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0), per_group);
+    if (threadIdx.x < 64)
+      counted_publish<MFMA>(a.accum + (size_t)(k & 1) * REG_GROUPS * REG_WORDS, wg_sum, !(a.debug_stall && blockIdx.x == 0 && k == 0), per_group, &mfl);
 #ifdef WS_REG_TIMING
     WS_LSTAMP(6);
     for (int i = 0; i < 6; ++i) tot[i] += ts[i + 1] - ts[i];
@@ -1441,7 +1639,7 @@ int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags
 int reg_loop_supported(int device)
 {
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reg_loop_kernel<false>, REG_THREADS, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reg_loop_kernel<false, true>, REG_THREADS, 0) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   return (long long)per_cu * cus >= REG_BLOCKS ? 1 : 0;
 }
@@ -1475,10 +1673,23 @@ int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, con
   a.debug_stall = r->debug_stall_next;
   r->debug_stall_next = 0;
   prof_begin(ctx, WS_K_REG);
+  const unsigned blocks = peers ? (unsigned)r->peer_blocks : (unsigned)REG_BLOCKS;
+  // at most one point per lane (every scan the reference's 131 072-point buffers can hold): the sums come from the matrix cores
+  const bool mfma = WS_REG_MFMA && (size_t)(a.pts.end - a.pts.first) <= (size_t)blocks * REG_THREADS;
   if (peers)
-    hipLaunchKernelGGL(reg_loop_kernel<true>, dim3((unsigned)r->peer_blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+  {
+    if (mfma)
+      hipLaunchKernelGGL((reg_loop_kernel<true, true>), dim3(blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((reg_loop_kernel<true, false>), dim3(blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+  }
   else
-    hipLaunchKernelGGL(reg_loop_kernel<false>, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  {
+    if (mfma)
+      hipLaunchKernelGGL((reg_loop_kernel<false, true>), dim3(blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((reg_loop_kernel<false, false>), dim3(blocks), dim3(REG_THREADS), 0, ctx->stream, a);
+  }
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;
