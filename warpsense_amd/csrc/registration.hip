@@ -36,6 +36,9 @@ constexpr int REG_THREADS = WS_REG_THREADS; // 8 waves: one point per lane for a
 #ifndef WS_REG_MFMA
 #define WS_REG_MFMA 1 // 0: the resident loop sums with v_mad_i64_i32 + the transposing butterfly for every cloud size
 #endif
+#ifndef WS_LOOP_GATHER
+#define WS_LOOP_GATHER 1
+#endif
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
@@ -439,7 +442,43 @@ __device__ __forceinline__ void pose_product(float (&T)[16], const float (&tr)[1
 // The same product with the pose kept in LDS (reg_loop_kernel): lane 4*j + i of the first wave computes element (i, j)
 // -- one 128-bit LDS read for its column of T, twelve selects for its row of tr, 4 multiply-adds, one LDS write --
 // instead of 112 multiplies and adds in every lane.  Same operations in the same order per element.
-__device__ __forceinline__ void pose_product_lds(float *T_sh, const float (&tr)[16])
+// ---- phase B building blocks (registration.cu:194-257 + :41-118 fused) ----
+struct IntTransform
+{
+  int32_t M[12];
+  int32_t cx, cy, cz;
+};
+
+// The pose as make_int_transform needs it, next to the float pose in LDS: TI[4 j + i] = (int)(T[4 j + i] * 32768) for the rows
+// i < 3, and the integer centre (int)T[12 + i] in the fourth-row places 3, 7, 11.  Written by the lane that has just computed
+// the element (two instructions on the first wave) instead of 22 conversions in each of the eight waves of every iteration.
+__device__ __forceinline__ void store_int_pose(int32_t *TI_sh, int lane /* < 16: element (lane & 3, lane >> 2) */, float v)
+{
+  const int i = lane & 3, j = lane >> 2;
+  if (i < 3) TI_sh[lane] = (int32_t)(v * (float)MATRIX_RESOLUTION);
+  if (j == 3 && i < 3) TI_sh[4 * i + 3] = (int32_t)v;
+}
+__device__ __forceinline__ IntTransform load_int_pose(const int32_t *TI_sh)
+{
+  IntTransform t;
+  int32_t w[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    const int4 v = *reinterpret_cast<const int4 *>(TI_sh + 4 * q);
+    w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t.M[j * 3 + i] = w[j * 4 + i];
+  t.cx = w[3];
+  t.cy = w[7];
+  t.cz = w[11];
+  return t;
+}
+
+__device__ __forceinline__ void pose_product_lds(float *T_sh, const float (&tr)[16], int32_t *TI_sh = nullptr)
 {
   const int lane = threadIdx.x & 63, i = lane & 3, j = (lane >> 2) & 3;
   const float4 col = *reinterpret_cast<const float4 *>(T_sh + 4 * j); // T[j*4 + k], k = 0..3 (old pose: read before any lane writes)
@@ -452,7 +491,11 @@ __device__ __forceinline__ void pose_product_lds(float *T_sh, const float (&tr)[
     const float lo = i1 ? tr[k * 4 + 1] : tr[k * 4 + 0], hi = i1 ? tr[k * 4 + 3] : tr[k * 4 + 2];
     acc = __fadd_rn(acc, __fmul_rn(i2 ? hi : lo, tk[k]));
   }
-  if (lane < 16) T_sh[lane] = acc;
+  if (lane < 16)
+  {
+    T_sh[lane] = acc;
+    if (TI_sh) store_int_pose(TI_sh, lane, acc);
+  }
 }
 
 // One Gauss-Newton update with the whole state in registers, identical in every lane of the wave
@@ -474,14 +517,14 @@ __device__ __forceinline__ void gn_update_terms(GnCore &st, const int64_t *terms
 }
 
 // the same for reg_loop_kernel, whose pose lives in LDS (T_sh); st.T is not touched
-__device__ __forceinline__ void gn_update_terms_lds(GnCore &st, const int64_t *terms, float *T_sh)
+__device__ __forceinline__ void gn_update_terms_lds(GnCore &st, const int64_t *terms, float *T_sh, int32_t *TI_sh = nullptr)
 {
   float tr[16];
   const int32_t e = (int32_t)terms[27], c = (int32_t)terms[28];
   if (!gn_increment(
           st, [terms](int r, int cc) { return terms[r <= cc ? tri_index(r, cc) : tri_index(cc, r)]; }, [terms](int r) { return terms[21 + r]; }, c, tr))
     return;
-  pose_product_lds(T_sh, tr);
+  pose_product_lds(T_sh, tr, TI_sh);
   gn_convergence(st, e, c);
 }
 
@@ -496,11 +539,6 @@ struct PointArgs
 };
 
 // ---- phase B building blocks (registration.cu:194-257 + :41-118 fused) ----
-struct IntTransform
-{
-  int32_t M[12];
-  int32_t cx, cy, cz;
-};
 
 // cu_to_int_mat (cuda/util.h:24-35): (int)(float * 32768); registration.cu:208: center = (int) translation of the CURRENT transform
 __device__ __forceinline__ IntTransform make_int_transform(const float *T)
@@ -582,6 +620,77 @@ __device__ __forceinline__ Gathered gather_point(const PointArgs &a, const IntTr
     g.zn = a.map_data[get_index(a.map, bx, by, bz + 1)];
     g.zl = a.map_data[get_index(a.map, bx, by, bz - 1)];
   }
+  return g;
+}
+
+// The map's constants as the resident loop holds them: uniform values, but in VECTOR registers.  As kernel arguments they
+// live in scalar registers, and the loop has more uniform state than scalar registers: the compiler spilled them to vector
+// lanes and fetched them back (v_readlane + s_nop) in every iteration, and since a vector instruction takes at most one scalar
+// operand it copied a further 28 of them into vector registers per point anyway.
+struct LoopGather
+{
+  int32_t ringK[3]; // offset + size - pos: ring coordinate = ring(x + ringK, size)
+  int32_t size[3];
+  int32_t pos[3];
+  uint32_t lim[3];  // size / 2 - 1: in_bounds_with_buffer_neg(buf, 1)
+  uint32_t divM;    // division by the map resolution (FastDiv)
+  int32_t divK;
+};
+__device__ __forceinline__ LoopGather make_loop_gather(const PointArgs &a)
+{
+  LoopGather c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+  {
+    c.ringK[k] = wsub(wadd(a.map.offset[k], a.map.size[k]), a.map.pos[k]);
+    c.size[k] = a.map.size[k];
+    c.pos[k] = a.map.pos[k];
+    c.lim[k] = (uint32_t)(a.map.size[k] / 2 - 1); // size >= 3 (ws_map_create)
+    pin_vgpr(c.ringK[k]); pin_vgpr(c.size[k]); pin_vgpr(c.pos[k]); pin_vgpr(c.lim[k]);
+  }
+  c.divM = (uint32_t)a.resdiv.M; // < 2^32 (make_fastdiv)
+  c.divK = a.resdiv.k;
+  pin_vgpr(c.divM); pin_vgpr(c.divK);
+  return c;
+}
+__device__ __forceinline__ int64_t loop_index(const LoopGather &c, int32_t x, int32_t y, int32_t z)
+{
+  // get_index (ws_device.h) with x - pos + offset + size folded into one constant per axis (the same bits: wrapping adds)
+  const int32_t xi = ring(wadd(x, c.ringK[0]), c.size[0]), yi = ring(wadd(y, c.ringK[1]), c.size[1]), zi = ring(wadd(z, c.ringK[2]), c.size[2]);
+  const int32_t row = xi * c.size[1] + yi;
+  return (int64_t)row * (int64_t)c.size[2] + zi;
+}
+// gather_point<true> on those constants (same arithmetic, same results)
+__device__ __forceinline__ Gathered gather_point_loop(const PointArgs &a, const LoopGather &c, const IntTransform &t, int32_t px, int32_t py, int32_t pz, bool valid,
+                                                      VoxelCache &vc)
+{
+  Gathered g;
+  int32_t qx = wadd(wadd(wadd(wmul(t.M[0], px), wmul(t.M[3], py)), wmul(t.M[6], pz)), t.M[9]) / MATRIX_RESOLUTION;
+  int32_t qy = wadd(wadd(wadd(wmul(t.M[1], px), wmul(t.M[4], py)), wmul(t.M[7], pz)), t.M[10]) / MATRIX_RESOLUTION;
+  int32_t qz = wadd(wadd(wadd(wmul(t.M[2], px), wmul(t.M[5], py)), wmul(t.M[8], pz)), t.M[11]) / MATRIX_RESOLUTION;
+  const int32_t bx = div_trunc(qx, (uint64_t)c.divM, c.divK, 0), by = div_trunc(qy, (uint64_t)c.divM, c.divK, 0), bz = div_trunc(qz, (uint64_t)c.divM, c.divK, 0);
+  g.qx = wsub(qx, t.cx);
+  g.qy = wsub(qy, t.cy);
+  g.qz = wsub(qz, t.cz);
+  g.ok = valid && (uint32_t)iabs32(wsub(bx, c.pos[0])) <= c.lim[0] && (uint32_t)iabs32(wsub(by, c.pos[1])) <= c.lim[1] &&
+         (uint32_t)iabs32(wsub(bz, c.pos[2])) <= c.lim[2];
+  const bool refill = g.ok && !(vc.filled && vc.bx == bx && vc.by == by && vc.bz == bz);
+  if (refill)
+  {
+    vc.cur = a.map_data[loop_index(c, bx, by, bz)];
+    vc.xn = a.map_data[loop_index(c, bx + 1, by, bz)];
+    vc.xl = a.map_data[loop_index(c, bx - 1, by, bz)];
+    vc.yn = a.map_data[loop_index(c, bx, by + 1, bz)];
+    vc.yl = a.map_data[loop_index(c, bx, by - 1, bz)];
+    vc.zn = a.map_data[loop_index(c, bx, by, bz + 1)];
+    vc.zl = a.map_data[loop_index(c, bx, by, bz - 1)];
+    vc.bx = bx;
+    vc.by = by;
+    vc.bz = bz;
+    vc.filled = true;
+  }
+  const uint32_t keep = g.ok ? 0xffffffffu : 0u;
+  g.cur = vc.cur & keep; g.xn = vc.xn & keep; g.xl = vc.xl & keep; g.yn = vc.yn & keep; g.yl = vc.yl & keep; g.zn = vc.zn & keep; g.zl = vc.zl & keep;
   return g;
 }
 
@@ -1178,10 +1287,12 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
   const MfLane mfl = make_mf_lane();
   __shared__ int64_t red[REG_SLOTS];
   __shared__ alignas(16) float T_sh[16];
+  __shared__ alignas(16) int32_t TI_sh[16];
   __shared__ int stop_sh;
 
   const Prefetched pref = prefetch_points(a.pts, stride);
   const bool wave_has_points = __ballot(pref.valid[0]) != 0ull; // later passes of the grid only have points where the first has
+  const LoopGather lg = make_loop_gather(a.pts);
   GnCore st; // first wave only, identical in all of its lanes
   if (threadIdx.x < 64) st = a.init;
   uint64_t mb_then0 = 0, mb_then1 = 0; // first wave, PEERS: this lane's mailbox words of both parities when last complete
@@ -1218,7 +1329,11 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #else
 #define WS_LSTAMP(i)
 #endif
-  if (threadIdx.x < 16) T_sh[threadIdx.x] = a.init.T[threadIdx.x];
+  if (threadIdx.x < 16)
+  {
+    T_sh[threadIdx.x] = a.init.T[threadIdx.x];
+    store_int_pose(TI_sh, (int)threadIdx.x, a.init.T[threadIdx.x]);
+  }
   if (threadIdx.x < REG_SLOTS + MF_AUX) wg_sum[threadIdx.x] = 0;
   uint32_t k = 0;
   for (;; ++k)
@@ -1242,7 +1357,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
           st.error = 1; // reported by the host
         }
         else
-          gn_update_terms_lds(st, red, T_sh); // the pose itself stays in T_sh
+          gn_update_terms_lds(st, red, T_sh, TI_sh); // the pose itself stays in T_sh
       }
       if (threadIdx.x == 0) stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
     }
@@ -1256,13 +1371,14 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #endif
     if (wave_has_points) // (uniform per wave; point_slot(): a small cloud or shard leaves whole waves of every workgroup without points)
     {
-      float T[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
       if (MFMA)
       {
-        const IntTransform t = make_int_transform(T);
+        const IntTransform t = load_int_pose(TI_sh);
+#if WS_LOOP_GATHER
+        const Gathered g0 = gather_point_loop(a.pts, lg, t, pref.p[0][0], pref.p[0][1], pref.p[0][2], pref.valid[0], cache[0]);
+#else
         const Gathered g0 = gather_point<true>(a.pts, t, pref.p[0][0], pref.p[0][1], pref.p[0][2], pref.valid[0], &cache[0]);
+#endif
         mf_v16i C;
 #pragma unroll
         for (int i = 0; i < 16; ++i) C[i] = 0;
@@ -1272,6 +1388,9 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
       }
       else
       {
+        float T[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
         int64_t acc[REG_SLOTS];
 #pragma unroll
         for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
