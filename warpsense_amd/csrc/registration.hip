@@ -528,6 +528,58 @@ __device__ __forceinline__ void gn_update_terms_lds(GnCore &st, const int64_t *t
   gn_convergence(st, e, c);
 }
 
+// The update fed from REGISTERS (reg_loop_kernel): `total` is what the exchange left in lanes 0 .. 31 (the total of slot
+// `lane`), `Tel` the pose element (lane & 3, (lane >> 2) & 3) in lanes 0 .. 15.  Lane 8 r + c fetches its element of [H | g] with
+// one ds_bpermute pair and the pose's column comes over the quad with DPP: no LDS write -> read round trip between the
+// exchange and the solve, none between the increment and the product.  Same operations per element as gn_update_terms_lds.
+__device__ __forceinline__ void gn_update_total(GnCore &st, int64_t total, float &Tel, float *T_sh, int32_t *TI_sh)
+{
+  const int lane = threadIdx.x & 63, lr = lane >> 3, lc = lane & 7;
+  int src = 29; // an empty slot
+  if (lr < 6 && lc < 6) src = lr <= lc ? tri_index(lr, lc) : tri_index(lc, lr);
+  if (lr < 6 && lc == 6) src = 21 + lr;
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)((uint64_t)total & 0xffffffffull));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)((uint64_t)total >> 32));
+  const int64_t mine = pack64(lo, hi);
+  // (uniform values the vector unit computes with: kept out of the scalar registers, like the loop state)
+  int32_t e = __builtin_amdgcn_ds_bpermute(27 << 2, (int)(uint32_t)((uint64_t)total & 0xffffffffull));
+  int32_t c = __builtin_amdgcn_ds_bpermute(28 << 2, (int)(uint32_t)((uint64_t)total & 0xffffffffull));
+  pin_vgpr(e);
+  pin_vgpr(c);
+  float tr[16];
+  if (!gn_increment(
+          st, [mine](int, int) { return mine; }, [mine](int) { return mine; }, c, tr))
+    return;
+  // T = tr * T: lane 4 j + i computes element (i, j); column j of the old pose sits in the lane's own quad
+  // (the selects are written as v_cndmask on lane masks: as C selects the compiler turned them into an INDEXED read of tr[],
+  // i.e. a copy of tr[] in scratch memory and four round trips to it in the middle of the chain)
+  const unsigned long long m1 = 0xaaaaaaaaaaaaaaaaull, m2 = 0xccccccccccccccccull; // lanes with bit 0 / bit 1 of the row set
+  auto pick = [](float a, float b, unsigned long long mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+  };
+  const int tb = __float_as_int(Tel);
+  const float tk[4] = {__int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x00, 0xf, 0xf, false)),  // quad_perm [0,0,0,0]
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x55, 0xf, 0xf, false)),  // [1,1,1,1]
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0xaa, 0xf, 0xf, false)),  // [2,2,2,2]
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0xff, 0xf, 0xf, false))}; // [3,3,3,3]
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const float lo_ = pick(tr[k * 4 + 0], tr[k * 4 + 1], m1), hi_ = pick(tr[k * 4 + 2], tr[k * 4 + 3], m1);
+    acc = __fadd_rn(acc, __fmul_rn(pick(lo_, hi_, m2), tk[k]));
+  }
+  Tel = acc;
+  if (lane < 16)
+  {
+    T_sh[lane] = acc;
+    store_int_pose(TI_sh, lane, acc);
+  }
+  gn_convergence(st, e, c);
+}
+
 struct PointArgs
 {
   const int32_t *points;
@@ -1211,7 +1263,8 @@ struct PeerBlock
   int32_t pad;
   uint64_t then[2][REG_WORDS];
 };
-__device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, uint64_t &then, int64_t total /* lanes 0..31 */, int64_t *red, uint32_t *abort_flag)
+__device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, uint64_t &then, int64_t &total /* lanes 0..31: in this rank's, out all ranks' */,
+                                              int64_t *red, uint32_t *abort_flag)
 {
   const int lane = threadIdx.x & 63;
   const int world = pb->world;
@@ -1248,7 +1301,8 @@ __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, u
   const uint64_t sum = (w - then) & REG_SUM_MASK;
   then = w;
   const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)sum, 32);
-  if (lane < REG_SLOTS) red[lane] = (int64_t)(sum + (high << 32));
+  total = (int64_t)(sum + (high << 32));
+  if (lane < REG_SLOTS) red[lane] = total;
   return true;
 }
 
@@ -1329,10 +1383,13 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
 #else
 #define WS_LSTAMP(i)
 #endif
+  float Tel = 0.f; // first wave, lanes 0 .. 15: the pose element (lane & 3, lane >> 2)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Tel = (int)threadIdx.x == i ? a.init.T[i] : Tel; // (a dynamic index into the arguments costs a scratch copy)
   if (threadIdx.x < 16)
   {
-    T_sh[threadIdx.x] = a.init.T[threadIdx.x];
-    store_int_pose(TI_sh, (int)threadIdx.x, a.init.T[threadIdx.x]);
+    T_sh[threadIdx.x] = Tel;
+    store_int_pose(TI_sh, (int)threadIdx.x, Tel);
   }
   if (threadIdx.x < REG_SLOTS + MF_AUX) wg_sum[threadIdx.x] = 0;
   uint32_t k = 0;
@@ -1357,7 +1414,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
           st.error = 1; // reported by the host
         }
         else
-          gn_update_terms_lds(st, red, T_sh, TI_sh); // the pose itself stays in T_sh
+          gn_update_total(st, total, Tel, T_sh, TI_sh); // (red[] is only read again at the very end)
       }
       if (threadIdx.x == 0) stop_sh = (st.finished || st.iterations >= st.max_iterations) ? 1 : 0;
     }
