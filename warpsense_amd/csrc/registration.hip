@@ -318,8 +318,17 @@ __device__ long long g_gn_ticks[5];
 
 // First half: solve for xi and build the incremental transform `tr` (column-major 4x4).  false: no update this time
 // (loop already over, no correspondences, singular matrix).
+// what xi_to_transform (registration/util.h:5-39) needs to build the incremental transform
+struct GnStep
+{
+  float L01, L02, L10, L12, L20, L21; // the skew matrix of the unit axis (all +0 for a zero rotation, like the reference's initialiser)
+  float s, omc;                       // (float)sin theta, (float)(1 - cos theta)
+  float t3, t4, t5;                   // (float)xi[3..5]
+};
+
+// Solve for xi and reduce it to GnStep.  false: no update this time (loop already over, no correspondences, singular matrix).
 template <typename HF, typename GF>
-__device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, float (&tr)[16])
+__device__ __forceinline__ bool gn_step(GnCore &st, HF H, GF G, int32_t c, GnStep &o)
 {
   if (st.finished || st.iterations >= st.max_iterations) return false;
   st.iterations += 1;
@@ -347,13 +356,13 @@ __device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, 
 
   // xi_to_transform
   const double theta = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
-  float L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  o.L01 = o.L02 = o.L10 = o.L12 = o.L20 = o.L21 = 0.f;
   if (theta != 0.0)
   {
     const double lx = xi[0] / theta, ly = xi[1] / theta, lz = xi[2] / theta;
-    L[0][1] = (float)-lz; L[0][2] = (float)ly;
-    L[1][0] = (float)lz;  L[1][2] = (float)-lx;
-    L[2][0] = (float)-ly; L[2][1] = (float)lx;
+    o.L01 = (float)-lz; o.L02 = (float)ly;
+    o.L10 = (float)lz;  o.L12 = (float)-lx;
+    o.L20 = (float)-ly; o.L21 = (float)lx;
   }
   double sin_t, cos_t;
   if (theta < 0.25)
@@ -367,12 +376,38 @@ __device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, 
     const double p = -1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880 + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0)))));
     sin_t = theta + theta * z * p;
     const double q = 1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800 + z * (1.0 / 479001600.0 + z * (-1.0 / 87178291200.0)))));
-    const double t = 0.5 * z, u = 1.0 - t, e = (1.0 - u) - t, w = z * z * q;
-    cos_t = u + (e + w);
+    const double t = 0.5 * z, u = 1.0 - t, e = (1.0 - u) - t, ww = z * z * q;
+    cos_t = u + (e + ww);
   }
   else
     sincos(theta, &sin_t, &cos_t); // one argument reduction for both
-  const float s = (float)sin_t, omc = (float)(1 - cos_t);
+  o.s = (float)sin_t;
+  o.omc = (float)(1 - cos_t);
+  o.t3 = (float)xi[3];
+  o.t4 = (float)xi[4];
+  o.t5 = (float)xi[5];
+  WS_GN_STAMP(3);
+#ifdef WS_REG_TIMING_GN
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    g_gn_ticks[0] += gn_t1 - gn_t0;
+    g_gn_ticks[1] += gn_t2 - gn_t1;
+    g_gn_ticks[2] += gn_t3 - gn_t2;
+    g_gn_ticks[4] += 1;
+  }
+#endif
+  return true;
+}
+
+// First half: solve for xi and build the incremental transform `tr` (column-major 4x4).  false: no update this time
+// (loop already over, no correspondences, singular matrix).
+template <typename HF, typename GF>
+__device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, float (&tr)[16])
+{
+  GnStep o;
+  if (!gn_step(st, H, G, c, o)) return false;
+  const float L[3][3] = {{0.f, o.L01, o.L02}, {o.L10, 0.f, o.L12}, {o.L20, o.L21, 0.f}};
+  const float s = o.s, omc = o.omc;
   float R[3][3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -388,25 +423,16 @@ __device__ __forceinline__ bool gn_increment(GnCore &st, HF H, GF G, int32_t c, 
   for (int i = 0; i < 16; ++i) tr[i] = 0.f;
   tr[15] = 1.f;
   const float oc0 = -(float)st.center[0], oc1 = -(float)st.center[1], oc2 = -(float)st.center[2];
+  const float tx[3] = {o.t3, o.t4, o.t5};
 #pragma unroll
   for (int i = 0; i < 3; ++i)
   {
 #pragma unroll
     for (int j = 0; j < 3; ++j) tr[j * 4 + i] = R[i][j];
     const float shift = __fadd_rn(__fadd_rn(__fmul_rn(R[i][0], oc0), __fmul_rn(R[i][1], oc1)), __fmul_rn(R[i][2], oc2));
-    tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), (float)xi[3 + i]);
+    tr[12 + i] = __fadd_rn(__fadd_rn(shift, (float)st.center[i]), tx[i]);
   }
-  WS_GN_STAMP(3);
   st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
-#ifdef WS_REG_TIMING_GN
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    g_gn_ticks[0] += gn_t1 - gn_t0;
-    g_gn_ticks[1] += gn_t2 - gn_t1;
-    g_gn_ticks[2] += gn_t3 - gn_t2;
-    g_gn_ticks[4] += 1;
-  }
-#endif
   return true;
 }
 
@@ -546,31 +572,49 @@ __device__ __forceinline__ void gn_update_total(GnCore &st, int64_t total, float
   int32_t c = __builtin_amdgcn_ds_bpermute(28 << 2, (int)(uint32_t)((uint64_t)total & 0xffffffffull));
   pin_vgpr(e);
   pin_vgpr(c);
-  float tr[16];
-  if (!gn_increment(
-          st, [mine](int, int) { return mine; }, [mine](int) { return mine; }, c, tr))
+  GnStep o;
+  if (!gn_step(
+          st, [mine](int, int) { return mine; }, [mine](int) { return mine; }, c, o))
     return;
-  // T = tr * T: lane 4 j + i computes element (i, j); column j of the old pose sits in the lane's own quad
-  // (the selects are written as v_cndmask on lane masks: as C selects the compiler turned them into an INDEXED read of tr[],
-  // i.e. a copy of tr[] in scratch memory and four round trips to it in the middle of the chain)
+  // T = tr * T: lane 4 j + i computes element (i, j) and needs ROW i of tr only -- built here per lane (the same operations
+  // in the same order as gn_increment does for that row: 60 instructions instead of the 170 of all sixteen elements in every
+  // lane plus twelve selects).  Row 3 of tr is (0, 0, 0, 1): its lanes select zeros and compute exactly that.
+  // (The selects are v_cndmask on lane masks: as C selects over an array the compiler turned them into an INDEXED read, i.e. a
+  // copy in scratch memory and a round trip to it in the middle of the chain.)
   const unsigned long long m1 = 0xaaaaaaaaaaaaaaaaull, m2 = 0xccccccccccccccccull; // lanes with bit 0 / bit 1 of the row set
   auto pick = [](float a, float b, unsigned long long mask) {
     float r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
     return r;
   };
+  auto row4 = [&](float r0, float r1, float r2, float r3) { return pick(pick(r0, r1, m1), pick(r2, r3, m1), m2); };
+  const float L[3][3] = {{0.f, o.L01, o.L02}, {o.L10, 0.f, o.L12}, {o.L20, o.L21, 0.f}};
+  const float Li[3] = {row4(0.f, o.L10, o.L20, 0.f), row4(o.L01, 0.f, o.L21, 0.f), row4(o.L02, o.L12, 0.f, 0.f)}; // L[i][0..2]
+  const float dl[3] = {row4(1.f, 0.f, 0.f, 0.f), row4(0.f, 1.f, 0.f, 0.f), row4(0.f, 0.f, 1.f, 0.f)};            // i == j
+  float row[4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+  {
+    float ll = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ll = __fadd_rn(ll, __fmul_rn(__fmul_rn(o.omc, Li[k]), L[k][j]));
+    row[j] = __fadd_rn(__fadd_rn(dl[j], __fmul_rn(o.s, Li[j])), ll);
+  }
+  {
+    const float oc0 = -(float)st.center[0], oc1 = -(float)st.center[1], oc2 = -(float)st.center[2];
+    const float shift = __fadd_rn(__fadd_rn(__fmul_rn(row[0], oc0), __fmul_rn(row[1], oc1)), __fmul_rn(row[2], oc2));
+    const float ci = row4((float)st.center[0], (float)st.center[1], (float)st.center[2], 0.f), ti = row4(o.t3, o.t4, o.t5, 0.f);
+    row[3] = pick(__fadd_rn(__fadd_rn(shift, ci), ti), 1.f, m1 & m2); // tr[15] = 1
+  }
+  st.alpha = __fadd_rn(st.alpha, st.it_weight_gradient);
   const int tb = __float_as_int(Tel);
-  const float tk[4] = {__int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x00, 0xf, 0xf, false)),  // quad_perm [0,0,0,0]
-                       __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x55, 0xf, 0xf, false)),  // [1,1,1,1]
+  const float tk[4] = {__int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x00, 0xf, 0xf, false)),  // quad_perm [0,0,0,0]: column j of the old
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0x55, 0xf, 0xf, false)),  // [1,1,1,1]     pose sits in the lane's quad
                        __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0xaa, 0xf, 0xf, false)),  // [2,2,2,2]
                        __int_as_float(__builtin_amdgcn_update_dpp(0, tb, 0xff, 0xf, 0xf, false))}; // [3,3,3,3]
   float acc = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-  {
-    const float lo_ = pick(tr[k * 4 + 0], tr[k * 4 + 1], m1), hi_ = pick(tr[k * 4 + 2], tr[k * 4 + 3], m1);
-    acc = __fadd_rn(acc, __fmul_rn(pick(lo_, hi_, m2), tk[k]));
-  }
+  for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(row[k], tk[k]));
   Tel = acc;
   if (lane < 16)
   {
