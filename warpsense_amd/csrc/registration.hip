@@ -370,12 +370,22 @@ __device__ __forceinline__ bool gn_step(GnCore &st, HF H, GF G, int32_t c, GnSte
     // Gauss-Newton steps are small rotations: Taylor polynomials (truncation < 1e-19 below 0.25 rad) instead of the
     // library's sincos with its argument reduction (428 -> 184 cycles on the one wave everybody waits for).  What the
     // update uses are (float)sin and (float)(1 - cos): the cosine is summed with its rounding error carried (u + (e + w)),
-    // so that 1 - cos_t cancels like the host's correctly rounded cos() does -- against glibc on 6 million angles in
+    // so that 1 - cos_t cancels like the host's correctly rounded cos() does -- against glibc on 20 million angles in
     // [1e-9, 0.25] both floats agree in every case (the plain polynomial misses (float)(1 - cos) in 0.2 % of them).
+    // (Horner steps as explicit fused multiply-adds -- half the length of the dependent chain; tools/polycheck.c: both forms
+    // give libm's two floats on 20 million angles.)
     const double z = theta * theta;
-    const double p = -1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880 + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0)))));
-    sin_t = theta + theta * z * p;
-    const double q = 1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800 + z * (1.0 / 479001600.0 + z * (-1.0 / 87178291200.0)))));
+    double p = fma(z, 1.0 / 6227020800.0, -1.0 / 39916800);
+    p = fma(z, p, 1.0 / 362880);
+    p = fma(z, p, -1.0 / 5040);
+    p = fma(z, p, 1.0 / 120);
+    p = fma(z, p, -1.0 / 6);
+    sin_t = fma(theta * z, p, theta);
+    double q = fma(z, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+    q = fma(z, q, -1.0 / 3628800);
+    q = fma(z, q, 1.0 / 40320);
+    q = fma(z, q, -1.0 / 720);
+    q = fma(z, q, 1.0 / 24);
     const double t = 0.5 * z, u = 1.0 - t, e = (1.0 - u) - t, ww = z * z * q;
     cos_t = u + (e + ww);
   }
