@@ -1240,6 +1240,10 @@ static_assert(REG_WORDS == 64 && REG_BLOCKS % REG_GROUPS == 0 && REG_BLOCKS / RE
 #endif
 constexpr int REG_FIRST_POLL_SLEEP = WS_REG_FIRST_POLL_SLEEP; // x 64 clocks before the first poll
 constexpr int REG_POLL_SLEEP = 2;        // between polls
+#ifndef WS_REG_PEER_POLL_SLEEP
+#define WS_REG_PEER_POLL_SLEEP 8 // (two ranks on one GPU: 4 -> 6.7, 12 -> 6.9, 20 -> 7.1, 28 -> 7.3 us per iteration; the mailbox is local memory, its polls are cheap)
+#endif
+constexpr int REG_PEER_POLL_SLEEP = WS_REG_PEER_POLL_SLEEP; // x 64 clocks before the first poll of the mailbox
 // Poll limits on the 100 MHz wall clock.  The workgroups of ONE launch start within microseconds of each other, so an on-chip
 // exchange that is not complete after 5 ms means that some workgroup is not on the chip (another kernel holds its CU):
 // ws_register_cloud then repeats the registration with one launch per iteration, which needs no co-residency -- half a
@@ -1354,7 +1358,7 @@ __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, u
   uint64_t w;
   uint32_t spins = 0;
   long long t0 = 0;
-  __builtin_amdgcn_s_sleep(REG_FIRST_POLL_SLEEP);
+  __builtin_amdgcn_s_sleep(REG_PEER_POLL_SLEEP);
   for (;;)
   {
     w = __hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
