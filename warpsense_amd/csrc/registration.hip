@@ -36,9 +36,6 @@ constexpr int REG_THREADS = WS_REG_THREADS; // 8 waves: one point per lane for a
 #ifndef WS_REG_MFMA
 #define WS_REG_MFMA 1 // 0: the resident loop sums with v_mad_i64_i32 + the transposing butterfly for every cloud size
 #endif
-#ifndef WS_LOOP_GATHER
-#define WS_LOOP_GATHER 1
-#endif
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
@@ -475,9 +472,6 @@ __device__ __forceinline__ void pose_product(float (&T)[16], const float (&tr)[1
   for (int i = 0; i < 16; ++i) T[i] = out[i];
 }
 
-// The same product with the pose kept in LDS (reg_loop_kernel): lane 4*j + i of the first wave computes element (i, j)
-// -- one 128-bit LDS read for its column of T, twelve selects for its row of tr, 4 multiply-adds, one LDS write --
-// instead of 112 multiplies and adds in every lane.  Same operations in the same order per element.
 // ---- phase B building blocks (registration.cu:194-257 + :41-118 fused) ----
 struct IntTransform
 {
@@ -514,26 +508,6 @@ __device__ __forceinline__ IntTransform load_int_pose(const int32_t *TI_sh)
   return t;
 }
 
-__device__ __forceinline__ void pose_product_lds(float *T_sh, const float (&tr)[16], int32_t *TI_sh = nullptr)
-{
-  const int lane = threadIdx.x & 63, i = lane & 3, j = (lane >> 2) & 3;
-  const float4 col = *reinterpret_cast<const float4 *>(T_sh + 4 * j); // T[j*4 + k], k = 0..3 (old pose: read before any lane writes)
-  const float tk[4] = {col.x, col.y, col.z, col.w};
-  const bool i1 = (i & 1) != 0, i2 = (i & 2) != 0;
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-  {
-    const float lo = i1 ? tr[k * 4 + 1] : tr[k * 4 + 0], hi = i1 ? tr[k * 4 + 3] : tr[k * 4 + 2];
-    acc = __fadd_rn(acc, __fmul_rn(i2 ? hi : lo, tk[k]));
-  }
-  if (lane < 16)
-  {
-    T_sh[lane] = acc;
-    if (TI_sh) store_int_pose(TI_sh, lane, acc);
-  }
-}
-
 // One Gauss-Newton update with the whole state in registers, identical in every lane of the wave
 template <typename HF, typename GF>
 __device__ __forceinline__ void gn_update(GnCore &st, HF H, GF G, int32_t e, int32_t c)
@@ -552,22 +526,10 @@ __device__ __forceinline__ void gn_update_terms(GnCore &st, const int64_t *terms
       (int32_t)terms[27], (int32_t)terms[28]);
 }
 
-// the same for reg_loop_kernel, whose pose lives in LDS (T_sh); st.T is not touched
-__device__ __forceinline__ void gn_update_terms_lds(GnCore &st, const int64_t *terms, float *T_sh, int32_t *TI_sh = nullptr)
-{
-  float tr[16];
-  const int32_t e = (int32_t)terms[27], c = (int32_t)terms[28];
-  if (!gn_increment(
-          st, [terms](int r, int cc) { return terms[r <= cc ? tri_index(r, cc) : tri_index(cc, r)]; }, [terms](int r) { return terms[21 + r]; }, c, tr))
-    return;
-  pose_product_lds(T_sh, tr, TI_sh);
-  gn_convergence(st, e, c);
-}
-
 // The update fed from REGISTERS (reg_loop_kernel): `total` is what the exchange left in lanes 0 .. 31 (the total of slot
 // `lane`), `Tel` the pose element (lane & 3, (lane >> 2) & 3) in lanes 0 .. 15.  Lane 8 r + c fetches its element of [H | g] with
 // one ds_bpermute pair and the pose's column comes over the quad with DPP: no LDS write -> read round trip between the
-// exchange and the solve, none between the increment and the product.  Same operations per element as gn_update_terms_lds.
+// exchange and the solve, none between the increment and the product.  Same operations per element as gn_update.
 __device__ __forceinline__ void gn_update_total(GnCore &st, int64_t total, float &Tel, float *T_sh, int32_t *TI_sh)
 {
   const int lane = threadIdx.x & 63, lr = lane >> 3, lc = lane & 7;
@@ -1509,11 +1471,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_loop_kernel(LoopArgs a)
       if (MFMA)
       {
         const IntTransform t = load_int_pose(TI_sh);
-#if WS_LOOP_GATHER
         const Gathered g0 = gather_point_loop(a.pts, lg, t, pref.p[0][0], pref.p[0][1], pref.p[0][2], pref.valid[0], cache[0]);
-#else
-        const Gathered g0 = gather_point<true>(a.pts, t, pref.p[0][0], pref.p[0][1], pref.p[0][2], pref.valid[0], &cache[0]);
-#endif
         mf_v16i C;
 #pragma unroll
         for (int i = 0; i < 16; ++i) C[i] = 0;
