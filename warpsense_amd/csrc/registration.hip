@@ -836,11 +836,13 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
 //   d7      1 | used << 8                   a row of ones (what multiplies the biases) and the row that counts
 // One instruction multiplies the 32 x 32 rows of 32 points; the SAME register is its A and its B operand (B[k][j] = A[j][k]),
 // so whatever order the hardware gives the 32 points inside the operand, a row meets itself in the same order.  Lane (r, half)
-// must supply row r of 16 points, while a point's rows are computed in ONE lane: the wave's 8 x 64 dwords pass through LDS
-// ([dword][point], rows 68 words apart so that the eight 128-bit reads of a wave land in different banks), lane (r, half) reads
-// the 16 points' dword r / 4 and picks byte r % 4 of each with v_perm_b32.  Two instructions per wave replace 27
-// v_mad_i64_i32 per lane AND the 190-instruction transposing butterfly: the K dimension of the product is the reduction
-// over the lanes.  What comes out, per wave: C[a][b] = sum over its 64 points of limb a x limb b.  Lane (b, half) holds rows
+// must supply row r of 16 points, while a point's rows are computed in ONE lane: the wave's 64 x 32 bytes pass through LDS,
+// point-major as they are computed (two 128-bit writes per lane, points 48 bytes apart), and come back TRANSPOSED by the
+// hardware: ds_read_b64_tr_b8 hands every lane of a 16-lane group one byte column of an 8-point x 16-byte block (tools/
+// tr_probe.hip prints what it does), i.e. row r of 8 points per read -- four reads per wave, no byte shuffling in registers
+// (the first version read [dword][point] with eight 128-bit reads and picked bytes with 24 v_perm_b32: +0.05 us).  Two
+// matrix instructions per wave replace 27 v_mad_i64_i32 per lane AND the 190-instruction transposing butterfly: the K
+// dimension of the product is the reduction over the lanes.  What comes out, per wave: C[a][b] = sum over its 64 points of limb a x limb b.  Lane (b, half) holds rows
 // 8g + 4 half + t: the four limbs t of dword 2g + half, i.e. (Horner) the sum over the points of Js_i x (limb b % 4 of dword
 // b / 4); shifted by 8 (b % 4) it goes straight into the workgroup's slot with an LDS atomic -- the 4 limb columns of a dword
 // meet there.  The biases: sum (Js_i + B)(Js_j + B) = sum Js_i Js_j + B (T_i + T_j) + B^2 N with T_i = sum Js_i x 1 (the ones
@@ -848,15 +850,17 @@ __device__ __forceinline__ void consume_point(const Gathered &g, int64_t (&acc)[
 // slots (mfma_finalize).  Everything is integer arithmetic mod 2^64 like the int64 sums it replaces: bit-identical.
 typedef int mf_v4i __attribute__((ext_vector_type(4)));
 typedef int mf_v16i __attribute__((ext_vector_type(16)));
-constexpr int MF_ROW_STRIDE = 68;                  // words between the staged dwords of a point
-constexpr int MF_STAGE_WORDS = 8 * MF_ROW_STRIDE;  // per wave
+#ifndef WS_MF_POINT_STRIDE
+#define WS_MF_POINT_STRIDE 12
+#endif
+constexpr int MF_POINT_STRIDE = WS_MF_POINT_STRIDE;  // words per staged point: 8 used, 48 bytes apart (128-bit writes without bank conflicts)
+constexpr int MF_STAGE_WORDS = 64 * MF_POINT_STRIDE; // per wave
 constexpr int MF_AUX = 8;                          // behind the 32 slots: T_0..T_5, sum vs, N
 constexpr uint32_t MF_NONE = 0xffffffffu;
 constexpr uint64_t MF_BJ = 0x00808080ull, MF_BV = 0x80ull;
 
 struct MfLane // constants of a lane
 {
-  uint32_t sel;     // v_perm selector: byte (lane % 4) of two dwords
   uint32_t rd;      // first staged word this lane reads
   uint32_t shift;   // 8 x (column limb)
   uint32_t slot[3]; // where the lane's values of g = 0, 1, 2 go (index into wg_sum[32 + MF_AUX]), MF_NONE: nowhere
@@ -868,8 +872,11 @@ __device__ __forceinline__ MfLane make_mf_lane()
 {
   MfLane L;
   const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5, jd = j >> 2, m = j & 3;
-  L.sel = (uint32_t)m | ((uint32_t)(4 + m) << 8) | ((uint32_t)m << 16) | ((uint32_t)(4 + m) << 24);
-  L.rd = (uint32_t)(jd * MF_ROW_STRIDE + 16 * half);
+  // ds_read_b64_tr_b8: a 16-lane group reads a block of 8 points x 16 row bytes, every lane 8 contiguous bytes at its OWN
+  // address (lane j of the group: point j / 2, bytes 8 (j % 2) .. of the 16-byte window), and gets back the block's column j:
+  // the row byte (lane & 15) of the window for the 8 points.  Groups 0 / 1 take the windows of rows 0..15 / 16..31, the upper
+  // half of the wave the points 16 further on.
+  L.rd = (uint32_t)((16 * half + ((lane & 15) >> 1)) * MF_POINT_STRIDE * 4 + ((lane >> 4) & 1) * 16 + (lane & 1) * 8); // bytes
   L.shift = (uint32_t)(8 * m);
 #pragma unroll
   for (int g = 0; g < 3; ++g)
@@ -921,29 +928,24 @@ __device__ __forceinline__ void mfma_consume(const Gathered &g, mf_v16i &C, uint
   point_terms(g, J, v, used);
   const int lane = threadIdx.x & 63;
   const int32_t n = v < 0 ? v : -v;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) stage[i * MF_ROW_STRIDE + lane] = (uint32_t)J[i] ^ (uint32_t)MF_BJ;
-  stage[6 * MF_ROW_STRIDE + lane] = (((uint32_t)v ^ (uint32_t)MF_BV) & 0xffffu) | (((uint32_t)n ^ (uint32_t)MF_BV) << 16);
-  stage[7 * MF_ROW_STRIDE + lane] = 1u | ((uint32_t)used << 8);
+  uint4 d0, d1;
+  d0.x = (uint32_t)J[0] ^ (uint32_t)MF_BJ; d0.y = (uint32_t)J[1] ^ (uint32_t)MF_BJ; d0.z = (uint32_t)J[2] ^ (uint32_t)MF_BJ; d0.w = (uint32_t)J[3] ^ (uint32_t)MF_BJ;
+  d1.x = (uint32_t)J[4] ^ (uint32_t)MF_BJ; d1.y = (uint32_t)J[5] ^ (uint32_t)MF_BJ;
+  d1.z = (((uint32_t)v ^ (uint32_t)MF_BV) & 0xffffu) | (((uint32_t)n ^ (uint32_t)MF_BV) << 16);
+  d1.w = 1u | ((uint32_t)used << 8);
+  *reinterpret_cast<uint4 *>(&stage[lane * MF_POINT_STRIDE]) = d0;
+  *reinterpret_cast<uint4 *>(&stage[lane * MF_POINT_STRIDE + 4]) = d1;
   __builtin_amdgcn_wave_barrier(); // (LDS serves a wave's accesses in order: the reads below see all 64 lanes' writes)
+  typedef int mf_v2i __attribute__((ext_vector_type(2)));
+  const char *base = reinterpret_cast<const char *>(stage) + L.rd;
 #pragma unroll
   for (int q = 0; q < 2; ++q)
   {
-    uint32_t x[16];
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-    {
-      const uint4 t = *reinterpret_cast<const uint4 *>(&stage[L.rd + 32 * q + 4 * w]);
-      x[4 * w + 0] = t.x; x[4 * w + 1] = t.y; x[4 * w + 2] = t.z; x[4 * w + 3] = t.w;
-    }
+    // the transposing read delivers the operand as the instruction wants it: row (lane & 31) of 8 points per read
+    const mf_v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) mf_v2i *)(base + (32 * q) * MF_POINT_STRIDE * 4));
+    const mf_v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) mf_v2i *)(base + (32 * q + 8) * MF_POINT_STRIDE * 4));
     mf_v4i a;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-    {
-      const uint32_t t01 = __builtin_amdgcn_perm(x[4 * w + 1], x[4 * w + 0], L.sel);
-      const uint32_t t23 = __builtin_amdgcn_perm(x[4 * w + 3], x[4 * w + 2], L.sel);
-      a[w] = (int)__builtin_amdgcn_perm(t23, t01, 0x05040100u);
-    }
+    a[0] = lo[0]; a[1] = lo[1]; a[2] = hi[0]; a[3] = hi[1];
     C = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, a, C, 0, 0, 0);
   }
   __builtin_amdgcn_wave_barrier(); // the next call's writes stay behind these reads
