@@ -36,6 +36,9 @@ constexpr int REG_THREADS = WS_REG_THREADS; // 8 waves: one point per lane for a
 #ifndef WS_REG_MFMA
 #define WS_REG_MFMA 1 // 0: the resident loop sums with v_mad_i64_i32 + the transposing butterfly for every cloud size
 #endif
+#ifndef WS_SOLVE_DIAG_FIRST
+#define WS_SOLVE_DIAG_FIRST 1
+#endif
 constexpr int REG_TERMS = 29;    // 21 h + 6 g + e + c (slots 29..31 are padding)
 static_assert(REG_TERMS <= 32, "slots");
 constexpr int REG_SLOTS = 32;    // padded to a power of two for the transposing reduction
@@ -264,6 +267,25 @@ __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
   for (int k = 0; k < 6; ++k)
   {
     // pivot: first row of maximal |A[i][k]|, i >= k
+#if WS_SOLVE_DIAG_FIRST
+    // The diagonal element keeps its place unless an element BELOW it is strictly larger (the search takes the first maximum):
+    // every lane of the column compares its own element with the diagonal, one ballot decides.  Then nothing changes places
+    // -- no candidate chain (8 instructions per candidate), no gather of the swapped row.  The normal equations of a scan put
+    // the large rotational terms first, so this is the usual case; otherwise the general search below runs.
+    const double dk = lane_read(a, 8 * k + k);
+    const bool below_larger = c == k && r > k && r < 6 && fabs(a) > fabs(dk);
+    if (__ballot(below_larger) == 0ull)
+    {
+      const double pv = in_vgpr(dk);
+      singular |= pv == 0.0 ? 1 : 0;
+      if (k == 5) break;
+      const double rowk = lane_gather(a, 8 * k + c);
+      const double colk = lane_gather(a, 8 * r + k);
+      const double f = colk / pv;
+      a = (r > k && c >= k) ? a - f * rowk : a;
+      continue;
+    }
+#endif
     int piv = k;
     double pv = in_vgpr(lane_read(a, 8 * k + k));
 #pragma unroll
