@@ -514,7 +514,7 @@ __device__ __forceinline__ uint32_t lds_append(uint32_t *cursor)
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-  base = (uint32_t)__shfl((int)base, leader, 64);
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader); // (the leader is uniform: no trip through LDS for the broadcast, -3 us in the tail march)
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
