@@ -784,16 +784,17 @@ __device__ __forceinline__ Gathered gather_point_loop(const PointArgs &a, const 
       rn[k] = min(v + 1u, v + 1u - sz);      // v + 1 == size -> 0
       rl[k] = min(v - 1u, v - 1u + sz);      // v == 0 -> size - 1 (v - 1 wraps)
     }
-    const uint32_t sy = (uint32_t)c.size[1];
-    const int64_t szz = (int64_t)c.size[2];
+    const uint32_t sy = (uint32_t)c.size[1], sz = (uint32_t)c.size[2];
+    // (row * size_z + z as ONE v_mad_u64_u32: all three operands unsigned 32-bit, the index 64-bit for 2049^3)
+    auto at = [&](uint32_t row, uint32_t z) { return a.map_data[(uint64_t)row * (uint64_t)sz + (uint64_t)z]; };
     const uint32_t row_c = rc[0] * sy + rc[1];
-    vc.cur = a.map_data[(int64_t)row_c * szz + rc[2]];
-    vc.xn = a.map_data[(int64_t)(rn[0] * sy + rc[1]) * szz + rc[2]];
-    vc.xl = a.map_data[(int64_t)(rl[0] * sy + rc[1]) * szz + rc[2]];
-    vc.yn = a.map_data[(int64_t)(rc[0] * sy + rn[1]) * szz + rc[2]];
-    vc.yl = a.map_data[(int64_t)(rc[0] * sy + rl[1]) * szz + rc[2]];
-    vc.zn = a.map_data[(int64_t)row_c * szz + rn[2]];
-    vc.zl = a.map_data[(int64_t)row_c * szz + rl[2]];
+    vc.cur = at(row_c, rc[2]);
+    vc.xn = at(rn[0] * sy + rc[1], rc[2]);
+    vc.xl = at(rl[0] * sy + rc[1], rc[2]);
+    vc.yn = at(rc[0] * sy + rn[1], rc[2]);
+    vc.yl = at(rc[0] * sy + rl[1], rc[2]);
+    vc.zn = at(row_c, rn[2]);
+    vc.zl = at(row_c, rl[2]);
     vc.bx = bx;
     vc.by = by;
     vc.bz = bz;
