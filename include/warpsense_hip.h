@@ -47,9 +47,10 @@ typedef enum
   WS_ERR_INVALID = -1,     /* bad argument                                             */
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
-  WS_ERR_CAPACITY = -4,    /* run descriptors / free-space hash exhausted: a TSDF update is not exact (sticky, see below);
-                              also returned at once by ws_tsdf_update* for a scan that needs more than 2^32 records */
-  WS_ERR_RANGE = -5,       /* ray too long for the order key; the ray was dropped (sticky)       */
+  WS_ERR_CAPACITY = -4,    /* returned at once by ws_tsdf_update* for a scan that needs more than 2^32 record chunks (the record
+                              buffer itself cannot overflow: every scan sizes it, or is repeated with a larger one) */
+  WS_ERR_RANGE = -5,       /* ray of more than 8192 steps or 31 fan steps: outside the record's fields; the
+                              ray was dropped (sticky)                                                                */
   WS_ERR_TIMEOUT = -6,     /* ws_register_cloud_peers: a peer rank did not deliver (ws_register_cloud itself retries with one
                               launch per iteration instead of returning this) */
   WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
@@ -57,10 +58,12 @@ typedef enum
 
 /* Sticky device-side errors.  ws_tsdf_update* return after ENQUEUEING the kernels (like the reference,
  * update_tsdf.cu:165; before returning they read the record bound the set-up pass has reported meanwhile -- the reference
- * blocks on its cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_CAPACITY / RANGE / INTERNAL: the map is then not bit-exact)
- * cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the first call on the same map that
- * synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.  compat.hpp turns it into
- * the reference's print-and-exit (common.cuh:10-21). */
+ * blocks on its cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_RANGE / INTERNAL: the
+ * map is then not bit-exact) cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the
+ * first call on the same map that synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.
+ * compat.hpp turns it into the reference's print-and-exit (common.cuh:10-21).  Capacity is not among them: a scan either
+ * fits the record buffer by construction (its set-up pass bounds it, the buffer grows first) or -- maps so large that the
+ * buffer is sized by estimate -- is aborted without touching the maps and repeated with a larger buffer inside the call. */
 
 #define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
 #define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
@@ -151,24 +154,30 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* Candidate-record capacity of the scatter (records of 16 bytes, two buffers; default 32 Mi).  EVERY scan sizes the buffers
- * itself: the march kernels compare the bound its set-up pass computes with the capacity and do nothing at all if the scan
- * does not fit, ws_tsdf_update* reads the bound before it returns and in that case grows the buffers and runs the update
- * again -- the records cannot overflow whatever the previous scan looked like.  Reserving up front only avoids that re-run. */
+/* Candidate-record capacity of the scatter: records of 8 bytes in chunks of 256 that belong to one 4x4x64-voxel tile each.
+ * EVERY scan sizes the buffer itself: its set-up pass bounds the records it can make, the march kernels compare the chunks
+ * that bound can need (bound / 256 + one partly filled chunk per tile) with the capacity and do nothing at all if the scan
+ * does not fit, ws_tsdf_update* reads the bound before it returns and in that case grows the buffer and runs the update
+ * again.  Maps whose tile term alone would cost gigabytes (2049^3) size the buffer by an estimate instead; a scan that runs
+ * out of chunks there is aborted -- the maps stay untouched -- and repeated with twice the buffer, inside the same call.
+ * Reserving up front only avoids such a re-run. */
 int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
+/* Test entry: chunk buffers above `budget_bytes` are sized by the estimate (record bound / 256 >> (est_shift - 1)) instead of
+ * by the hard bound (0, 0: the defaults) -- a tiny budget and a large shift force the abort-and-repeat route on a small map. */
+int ws_debug_tsdf_chunk_policy(ws_map *map, uint64_t budget_bytes, uint32_t est_shift);
 
 typedef struct
 {
   int64_t contested_voxels; /* voxels of the last update decided by the exact ordered rounds (a negative-weight
                                candidate could have blocked the earliest positive one)                         */
-  int64_t records;          /* scatter targets of the ray tails that went through the order keys                */
+  int64_t records;          /* scatter targets that became records (ray tails + free-space candidates on keyed voxels) */
   int64_t tiles;            /* touched 4x4x64-voxel tiles (resolved and integrated)                             */
-  int32_t error_flags;      /* device error bits since the last call: 1 capacity, 2 key range, 4 free-space bound, 8 internal */
+  int32_t error_flags;      /* device error bits since the last call: 2 record-field range, 4 free-space bound, 8 internal */
   int32_t pad;
-  int64_t runs;             /* (workgroup, tile) runs of records                                                */
-  int64_t free_space_hits;  /* voxels where a free-space candidate met ordered candidates                       */
-  int64_t record_slots;     /* record slots reserved (upper bounds) out of ...                                  */
-  int64_t record_capacity;  /* ... this capacity                                                                */
+  int64_t runs;             /* (workgroup flush, tile) groups of records: one reservation in the tile's sequence each */
+  int64_t free_space_hits;  /* free-space candidates that met ordered candidates (and joined that tile's records)   */
+  int64_t record_slots;     /* the scan's record bound (from its set-up pass) ...                                 */
+  int64_t record_capacity;  /* ... and the records the chunk buffer holds                                         */
 } ws_tsdf_stats_t;
 int ws_tsdf_stats(ws_map *map, ws_tsdf_stats_t *out); /* synchronises */
 
@@ -218,8 +227,11 @@ int ws_reg_poll(ws_reg *reg, int32_t *finished, int32_t *iterations, float T_out
  *   ws_reg_peer_connect(reg, rank, world, handles (world x 64 bytes), blocks)
  * then all ranks call ws_register_cloud_peers together for every cloud (every rank has prepared the WHOLE cloud; the map is
  * replicated).  `blocks`: workgroups of the loop on this rank, 0 = 256 (one per CU); ranks that share one GPU (tests) pass
- * 256 / ranks-per-GPU so that all of them are resident at once.  WS_ERR_TIMEOUT: a peer did not deliver within 0.25 s -- all
- * ranks see it; call ws_reg_peer_reset on every rank (between two barriers of the caller's) and fall back to the RCCL route.
+ * 256 / ranks-per-GPU so that all of them are resident at once.  WS_ERR_TIMEOUT: a peer did not deliver within 20 ms
+ * (WS_REG_PEER_TIMEOUT_MS in the environment at connect time changes the limit) -- all ranks see it; call ws_reg_peer_reset
+ * on every rank (between two barriers of the caller's) and fall back to the RCCL route.  Until then every further
+ * ws_register_cloud_peers on this handle is refused (WS_ERR_INVALID): the mailboxes hold the partial additions of the
+ * exchange that was given up.
  * ws_reg_peer_connect_local connects ws_reg handles of ONE process (several contexts / streams on one GPU) without IPC. */
 #define WS_IPC_HANDLE_BYTES 64
 int ws_reg_peer_mailbox(ws_reg *reg, void *ipc_handle_out /* WS_IPC_HANDLE_BYTES, may be NULL */);
@@ -236,9 +248,8 @@ int ws_register_cloud_peers(ws_reg *reg, const ws_map *map, size_t first, size_t
  * x n x 6, status n (0, or -1 for a singular matrix). Host pointers; synchronises. */
 int ws_debug_solve6(ws_context *ctx, const double *A, const double *b, size_t n, double *x, int32_t *status);
 
-/* Diagnostics: the per-workgroup statistics slots of the last TSDF update (records per tail workgroup; with a library built
- * with -DWS_TAIL_TIMING also start / middle / end of every tail workgroup on the 100 MHz wall clock at +16384 / +32768 / +49152;
- * tools/tail_schedule.py).  Synchronises. */
+/* Diagnostics: the per-workgroup statistics slots of the last TSDF update (records per tail workgroup, then at +65536 its
+ * flush groups, then at +131072 the contested voxels per resolve workgroup).  Synchronises. */
 int ws_debug_block_stats(ws_map *map, uint32_t *out, size_t words);
 
 /* Test entry: make the NEXT resident registration of `reg` lose one workgroup's contribution to the first exchange, as if

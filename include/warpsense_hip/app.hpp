@@ -358,6 +358,23 @@ public:
     const int np[3] = {new_pos.x, new_pos.y, new_pos.z};
     ws_shift *ticket = nullptr;
     WS_CHECK(ws_shift_begin(gpu_.tsdf().handle(), np, local_map_.global_map().get_default_tsdf_entry().raw(), &ticket));
+    // Between ws_shift_begin and the start of the worker, loading the entering boxes can throw: the window has moved on the
+    // device by then, so the leaving slabs are still filed (synchronously, by this guard) and the ticket is closed -- an
+    // open ticket would make every later ws_shift_begin fail.
+    GlobalMap *gm = &local_map_.global_map();
+    std::string *err = &shift_error_;
+    struct Owner
+    {
+      ws_shift *t;
+      int n;
+      GlobalMap *gm;
+      std::string *err;
+      bool armed;
+      ~Owner()
+      {
+        if (armed) file_leaving_slabs(t, n, gm, err);
+      }
+    } owner{ticket, ws_shift_count(ticket), gm, err, true};
     for (int axis = 0; axis < 3; ++axis)
     {
       const int d = np[axis] - ps[axis];
@@ -387,13 +404,15 @@ public:
             avg.insert_box(a, b, part);
           }
     }
-    GlobalMap *gm = &local_map_.global_map();
     shift_error_.clear();
-    std::string *err = &shift_error_;
-    shift_worker_ = std::thread([ticket, n, gm, err]() {
-      // the ticket is closed whatever happens (an open ticket makes the next ws_shift_begin fail), and a failure -- a HIP
-      // error while waiting for the slabs, an exception out of the global map -- is kept for wait_shift() instead of being
-      // swallowed or ending the process through std::terminate
+    owner.armed = false; // from here on the worker owns the ticket
+    shift_worker_ = std::thread(file_leaving_slabs, ticket, n, gm, err);
+  }
+  // The leaving slabs of an asynchronous shift -> the global map; closes the ticket whatever happens (an open ticket makes
+  // the next ws_shift_begin fail), and a failure -- a HIP error while waiting for the slabs, an exception out of the global
+  // map -- is kept for wait_shift() instead of being swallowed or ending the process through std::terminate.
+  static void file_leaving_slabs(ws_shift *ticket, int n, GlobalMap *gm, std::string *err)
+  {
       struct Closer
       {
         ws_shift *t;
@@ -448,7 +467,6 @@ public:
       {
         *err = "filing the leaving slabs: unknown exception";
       }
-    });
   }
   // joins the worker of the last asynchronous shift; throws if its slabs did not reach the global map
   void wait_shift()

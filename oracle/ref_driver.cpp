@@ -10,6 +10,9 @@
 //   rmagine::Vector3<int|long>::{l2norm,cross}, operators                 include/warpsense/math/vector3.h
 //   TSDFEntry bit layout                                                  include/map/tsdf.h:16-46
 //   Matrix4x4 / Matrix6x6 storage order                                   include/warpsense/math/matrix{4x4,6x6}.h
+//   cu_avg_tsdf_krnl's per-voxel body through TSDFEntry's accessors       src/warpsense/cuda/update_tsdf.cu:19-41
+//   calc_jacobis_krnl's lookups, gradient rule and cross product          src/warpsense/cuda/registration.cu:217-253
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 
@@ -91,6 +94,60 @@ int ref_ray_setup(const int32_t *point, const int32_t *pos_mm, const int32_t *up
   iv = (iv * (long)MATRIX_RESOLUTION) / inorm;
   interp_out[0] = iv.x; interp_out[1] = iv.y; interp_out[2] = iv.z;
   return 0;
+}
+
+// The per-voxel body of cu_avg_tsdf_krnl (update_tsdf.cu:19-41) on ONE pair of entries, written with the reference's own
+// TSDFEntry accessors: value() / weight() getters, the ValueType / WeightType conversions of the setters.  Only the
+// expression shapes are restated (`min` of the kernel = std::min<int> here); the int16 truncation of the average and the
+// promotion rules all come from tsdf.h.  Returns the updated existing entry; *fresh_io is reset like the kernel does.
+uint32_t ref_integrate_entry(uint32_t existing_raw, uint32_t *fresh_io, int max_weight, int tau)
+{
+  TSDFEntry existing_entry(existing_raw), new_entry(*fresh_io);
+  if (new_entry.weight() > 0 && existing_entry.weight() > 0)
+  {
+    existing_entry.value((existing_entry.value() * existing_entry.weight() + new_entry.value() * new_entry.weight()) / (existing_entry.weight() + new_entry.weight()));
+    existing_entry.weight(std::min<int>(max_weight, existing_entry.weight() + new_entry.weight()));
+  }
+  else if (new_entry.weight() != 0 && existing_entry.weight() <= 0)
+  {
+    existing_entry.value(new_entry.value());
+    existing_entry.weight(new_entry.weight());
+  }
+  new_entry.value(tau);
+  new_entry.weight(0);
+  *fresh_io = new_entry.raw();
+  return existing_entry.raw();
+}
+
+// The map-lookup half of calc_jacobis_krnl (registration.cu:217-253) for one transformed point: `buf` = the point's voxel,
+// `point` = the point minus the centre, both as the kernel has them after cu_transform_point.  Bounds test, the seven
+// lookups and the cross product run through cuda::DeviceMap and rmagine::Vector3 of the reference; the gradient rule is
+// restated.  Returns the mask; jacobi_out = (cross, gradient) widened to long, *value_out = the voxel's value.
+int ref_jacobi(void *m, const int32_t *buf_in, const int32_t *point_in, int64_t *jacobi_out, int16_t *value_out)
+{
+  const cuda::DeviceMap *map = &static_cast<RefMap *>(m)->map;
+  rm::Pointi buf(buf_in[0], buf_in[1], buf_in[2]), point(point_in[0], point_in[1], point_in[2]);
+  if (!map->in_bounds_with_buffer_neg(buf, 1)) return 0;
+  const auto &current = map->value_unchecked(buf);
+  if (current.weight() == 0) return 0;
+  const auto &x_next = map->value_unchecked(buf.x + 1, buf.y, buf.z);
+  const auto &x_last = map->value_unchecked(buf.x - 1, buf.y, buf.z);
+  const auto &y_next = map->value_unchecked(buf.x, buf.y + 1, buf.z);
+  const auto &y_last = map->value_unchecked(buf.x, buf.y - 1, buf.z);
+  const auto &z_next = map->value_unchecked(buf.x, buf.y, buf.z + 1);
+  const auto &z_last = map->value_unchecked(buf.x, buf.y, buf.z - 1);
+  rm::Pointi gradient;
+  if (x_next.weight() != 0 && x_last.weight() != 0 && !((x_next.value() > 0 && x_last.value() < 0) || (x_next.value() < 0 && x_last.value() > 0)))
+    gradient.x = (x_next.value() - x_last.value()) / 2;
+  if (y_next.weight() != 0 && y_last.weight() != 0 && !((y_next.value() > 0 && y_last.value() < 0) || (y_next.value() < 0 && y_last.value() > 0)))
+    gradient.y = (y_next.value() - y_last.value()) / 2;
+  if (z_next.weight() != 0 && z_last.weight() != 0 && !((z_next.value() > 0 && z_last.value() < 0) || (z_next.value() < 0 && z_last.value() > 0)))
+    gradient.z = (z_next.value() - z_last.value()) / 2;
+  auto cross = point.cross(gradient);
+  rm::Point6l jacobi((long)cross.x, (long)cross.y, (long)cross.z, (long)gradient.x, (long)gradient.y, (long)gradient.z);
+  std::memcpy(jacobi_out, &jacobi, 6 * sizeof(int64_t));
+  *value_out = current.value();
+  return 1;
 }
 
 // Matrix storage order probes: write at(i,j)=10*i+j, return the flat arrays

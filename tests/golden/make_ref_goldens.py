@@ -8,6 +8,9 @@ The fixture holds inputs and the reference's outputs only (data, no reference so
   vector math                   rmagine::Vector3<int|long>::l2norm / cross and the ray set-up expressions
                                 of update_tsdf.cu:57-63 evaluated through vector3.h's operators
   layouts                       TSDFEntry packing, Matrix4x4f / Matrix6x6l storage order, consts
+  integrate                     cu_avg_tsdf_krnl's per-voxel body (update_tsdf.cu:19-41) through TSDFEntry's accessors, 12 000 pairs
+  Jacobians                     calc_jacobis_krnl's lookups / gradient rule / cross product (registration.cu:217-253) through
+                                cuda::DeviceMap::value_unchecked and Vector3::cross, 24 maps x 500 points
 """
 import ctypes as C
 import os
@@ -79,6 +82,78 @@ def main():
         dist[i] = d.value
     out["ray_points"], out["ray_pos"], out["ray_up"] = pts, pos_mm, ups
     out["ray_distance"], out["ray_interp"], out["ray_rc"] = dist, interp, rc
+
+    # ---- cu_avg_tsdf_krnl's per-voxel body through TSDFEntry's accessors (update_tsdf.cu:19-41)
+    n_int = 12000
+    tau_i, mw_i = 600, 640
+    ex = np.stack([rng.integers(-tau_i, tau_i + 1, n_int), rng.integers(-80, 700, n_int)], axis=1).astype(np.int16)
+    fr = np.stack([rng.integers(-tau_i, tau_i + 1, n_int), rng.integers(-80, 80, n_int)], axis=1).astype(np.int16)
+    # int16 wrap of the stored average / weight sum, extreme values and weights, untouched and negative-weight cases
+    ex[:2000] = rng.integers(-32768, 32768, (2000, 2))
+    fr[:2000] = rng.integers(-32768, 32768, (2000, 2))
+    fr[2000:2600, 1] = 0
+    ex[2600:3200, 1] = 0
+    ex[3200:3800, 1] = rng.integers(-64, 1, 600)
+    fr[3800:4400, 1] = rng.integers(-64, 0, 600)
+    ex[4400:5000] = np.stack([np.full(600, tau_i), np.zeros(600)], axis=1)  # the default entry
+    ex_raw = np.array([R.ref_pack(int(v), int(w)) for v, w in ex], dtype=np.uint32)
+    fr_raw = np.array([R.ref_pack(int(v), int(w)) for v, w in fr], dtype=np.uint32)
+    ex_out = np.zeros(n_int, dtype=np.uint32)
+    fr_out = np.zeros(n_int, dtype=np.uint32)
+    for i in range(n_int):
+        f = C.c_uint32(int(fr_raw[i]))
+        ex_out[i] = R.ref_integrate_entry(int(ex_raw[i]), C.byref(f), mw_i, tau_i)
+        fr_out[i] = f.value
+    out["avg_existing"], out["avg_fresh"] = ex_raw, fr_raw
+    out["avg_existing_out"], out["avg_fresh_out"] = ex_out, fr_out
+    out["avg_params"] = np.array([mw_i, tau_i], dtype=np.int32)
+
+    # ---- calc_jacobis_krnl's lookups, gradient rule and cross product (registration.cu:217-253) on maps of random entries.
+    # The kernel's fixed-point transform is exact for a pure integer translation t (M = 32768 I, q = p + t, centre = t), so
+    # (buf, point) = (trunc((p + t) / res), p) are what it hands to this half; `jac_T` lets the oracle be driven the same way.
+    jm, jpts, jT, jres_, jout = [], [], [], [], []
+    for case in range(24):
+        size = rng.integers(4, 12, 3) * 2 + 1
+        pos = rng.integers(-40, 40, 3)
+        offset = np.array([rng.integers(0, s) for s in size])
+        n_v = int(np.prod(size))
+        vals = rng.integers(-600, 601, n_v)
+        wts = rng.integers(-20, 60, n_v)
+        wts[rng.random(n_v) < 0.25] = 0           # unobserved voxels
+        vals[rng.random(n_v) < 0.10] = 0          # a zero on one side is not "opposite sign"
+        if case % 4 == 3:                         # arbitrary raw entries: int32 wrap in the cross product
+            vals = rng.integers(-32768, 32768, n_v)
+        data = ((vals.astype(np.int64) & 0xffff) | ((wts.astype(np.int64) & 0xffff) << 16)).astype(np.uint32)
+        res = int(rng.choice([20, 50, 64]))
+        t = rng.integers(-3, 4, 3) * res + rng.integers(0, res, 3)
+        s32, p32, o32 = size.astype(np.int32), pos.astype(np.int32), offset.astype(np.int32)
+        h = R.ref_map_create(s32.ctypes.data, p32.ctypes.data, o32.ctypes.data, data.ctypes.data)
+        lo = (pos - size // 2 - 2) * res
+        hi = (pos + size // 2 + 3) * res
+        q = rng.integers(lo, hi, (500, 3))        # transformed points, a margin outside the window included
+        if case % 4 == 3:
+            q[:100] += rng.integers(-40000, 40000, (100, 3)) * 0  # (kept inside: wrap comes from the entries)
+        pts_c = (q - t).astype(np.int32)           # what the kernel is given
+        buf = np.trunc(q / res).astype(np.int32)   # C truncation of q / res
+        assert np.array_equal(buf, np.where(q >= 0, q // res, -((-q) // res)))
+        rows = np.zeros((500, 8), dtype=np.int64)
+        for i in range(500):
+            J = np.zeros(6, dtype=np.int64)
+            v = C.c_int16(0)
+            pnt = pts_c[i].copy()
+            mk = R.ref_jacobi(h, buf[i].ctypes.data, pnt.ctypes.data, J.ctypes.data, C.byref(v))
+            rows[i, 0] = mk
+            if mk:
+                rows[i, 1] = v.value
+                rows[i, 2:] = J
+        R.ref_map_destroy(h)
+        jm.append(np.concatenate([size, pos, offset, [res], t]))
+        jpts.append(pts_c)
+        jout.append(rows)
+        out[f"jac_data_{case}"] = data
+    out["jac_maps"] = np.array(jm, dtype=np.int32)      # size(3) pos(3) offset(3) res t(3)
+    out["jac_points"] = np.array(jpts, dtype=np.int32)  # [case][500][3]
+    out["jac_out"] = np.array(jout, dtype=np.int64)     # [case][500][mask, value, J(6)]
 
     # ---- layouts
     vw = rng.integers(-32768, 32768, (200, 2)).astype(np.int16)

@@ -279,6 +279,9 @@ def ref_lib():
     L.ref_l2norm_l.argtypes = [C.c_int64] * 3
     L.ref_cross_i.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ref_ray_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_integrate_entry.restype = C.c_uint32
+    L.ref_integrate_entry.argtypes = [C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+    L.ref_jacobi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ref_matrix4_layout.argtypes = [C.c_void_p]
     L.ref_matrix6_layout.argtypes = [C.c_void_p]
     return L

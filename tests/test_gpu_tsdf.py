@@ -308,20 +308,20 @@ def test_room_larger_than_the_window_with_ring_seam():
 
 
 def test_record_buffers_are_sized_by_the_scan_itself():
-    """The record buffers never rest on a guess: every scan reports the slots it can need from its set-up pass and
-    the host grows the buffers BEFORE the tail march is enqueued.  A reservation far too small for the scan, and a small
-    scan followed by one that needs ~60x more (a door opens: every step beyond ~3.3 m at 20 mm carries a fan), are both
+    """The record buffer never rests on a guess: every scan reports the records it can make from its set-up pass
+    and the host grows the chunk buffer before the marches do anything.  A reservation far too small for the scan, and a
+    small scan followed by one that needs ~60x more (a door opens: every step beyond ~3.3 m at 20 mm carries a fan), are both
     exact, with no error to report afterwards."""
     torch = _torch()
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
     lm, t, oa, on = make_pair(size, tau, res, mw)
-    t.set_capacity(1 << 20)  # 1 Mi records; the second scan reserves ~10 Mi
+    t.set_capacity(1 << 20)  # 1 Mi records; the tile term of the bound alone is larger
     near = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=16, azimuths=256, half_extents_mm=(900.0, 800.0, 500.0), seed=10)
     far = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
     slots = []
     for pts in (near, far, near):
         t.update_tsdf(torch.from_numpy(pts).cuda(), (6, -4, 2), (0, 0, 32768))
-        t.ctx.sync()  # would raise a sticky capacity error
+        t.ctx.sync()  # would raise a sticky error
         st = t.stats()
         assert st["status"] == 0 and st["error_flags"] == 0 and st["record_capacity"] >= st["record_slots"]
         slots.append(st["record_slots"])
@@ -331,8 +331,33 @@ def test_record_buffers_are_sized_by_the_scan_itself():
     assert t.stats()["record_capacity"] > 1 << 20
 
 
+def test_a_scan_that_runs_out_of_chunks_is_aborted_and_repeated():
+    """Maps so large that the chunk buffer is sized by estimate (2049^3: the hard bound's tile term alone is 18 GB) can run
+    out of chunks in the middle of the marches.  Such a scan leaves NO trace -- the resolve only puts the scratch back -- and
+    ws_tsdf_update repeats it with twice the buffer inside the same call (no inexact scans, ever).  Forced
+    here on a small map: a budget of one byte selects the estimate, a shift of 9 makes it ~1/256 of the bound."""
+    torch = _torch()
+    tau, res, mw, size = 600, 20, 640, (400, 400, 100)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    t.debug_chunk_policy(1, 9)
+    t.set_capacity(4096 * 256)
+    far = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    cap0 = t.stats()["record_capacity"]
+    for k in range(2):
+        t.update_tsdf(torch.from_numpy(far).cuda(), (6, -4, 2), (0, 0, 32768))
+        t.ctx.sync()
+        st = t.stats()
+        assert st["status"] == 0 and st["error_flags"] == 0
+        O.update_tsdf(oa, on, far, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+        got = download(t, lm, 0)
+        mism = np.nonzero(got != oa.data)[0]
+        assert mism.size == 0, f"scan {k}: {mism.size} voxels differ"
+    assert t.stats()["record_capacity"] > cap0, "the first scan must have outgrown the deliberately small buffer"
+    assert st["records"] > cap0 // 2
+
+
 def test_ray_beyond_the_key_range_is_reported():
-    """a ray of more than 65 536 steps cannot be ordered by the 16-bit step field of the key: it is dropped and the map's
+    """a ray of more than 8 192 steps cannot be ordered by the 13-bit step field of the record: it is dropped and the map's
     next synchronising call says so (WS_ERR_RANGE), instead of returning a map that silently lacks it"""
     torch = _torch()
     import warpsense_amd as W
@@ -340,6 +365,6 @@ def test_ray_beyond_the_key_range_is_reported():
     view, t, oa, on = _pair_at((64, 64, 64), tau, res, mw, (0, 0, 0), (32, 32, 32))
     pts = np.array([[60, 0, 0], [0, 61, 3]], dtype=np.int32)
     t.update_tsdf(torch.from_numpy(pts).cuda(), (-20000, 0, 0), (0, 0, 32768))
-    with pytest.raises(W.WsError, match="65536 steps"):
+    with pytest.raises(W.WsError, match="8192 steps"):
         t.ctx.sync()
     assert np.all(_download_view(t, view, 0) == O.pack(tau, 0))

@@ -24,7 +24,7 @@ EXPORTS = [
     "ws_device_reset", "ws_map_create", "ws_map_destroy", "ws_map_upload", "ws_map_set_params", "ws_map_download",
     "ws_map_extract_box", "ws_map_insert_box", "ws_shift_begin", "ws_shift_reserve", "ws_shift_count", "ws_shift_entering", "ws_shift_wait", "ws_shift_slab",
     "ws_shift_end", "ws_map_get_params", "ws_map_device_data", "ws_map_n_voxels", "ws_tsdf_update", "ws_tsdf_update_dev", "ws_tsdf_scatter_dev",
-    "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
+    "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_debug_tsdf_chunk_policy", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_points_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
     "ws_reg_solve_dev", "ws_reg_iterate_shard_dev", "ws_reg_poll", "ws_reg_peer_mailbox", "ws_reg_peer_connect", "ws_reg_peer_connect_local",
     "ws_reg_peer_disconnect", "ws_reg_peer_reset", "ws_register_cloud_peers", "ws_reg_set_loop", "ws_debug_solve6", "ws_debug_reg_stall", "ws_debug_reg_sums", "ws_debug_block_stats", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
@@ -153,6 +153,7 @@ def load() -> C.CDLL:
     L.ws_debug_reg_stall.argtypes = [vp, C.c_int32, vp]
     L.ws_debug_reg_sums.argtypes = [vp, vp]
     L.ws_debug_block_stats.argtypes = [vp, vp, sz]
+    L.ws_debug_tsdf_chunk_policy.argtypes = [vp, C.c_uint64, u32]
     L.ws_scan_create.argtypes = [vp, sz, P(vp)]
     L.ws_scan_destroy.argtypes = [vp]
     L.ws_scan_preprocess.argtypes = [vp, vp, sz, sz, vp, i32, P(sz)]

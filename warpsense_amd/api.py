@@ -106,10 +106,32 @@ class Context:
         import torch
         cur = torch.cuda.current_stream()
         if cur.cuda_stream == 0:
-            cur = torch.cuda.Stream()
-            torch.cuda.set_stream(cur)
+            # SIDE EFFECT, for the calling thread: torch's current stream becomes a new stream (restored by
+            # restore_torch_stream() / close()).  The new stream first waits for everything already queued on the default
+            # stream -- uploads or preprocessing the caller enqueued there -- so nothing queued earlier can race with later work.
+            self._torch_prev_stream = cur
+            new = torch.cuda.Stream()
+            new.wait_stream(cur)
+            torch.cuda.set_stream(new)
+            cur = new
         self._torch_stream = cur  # keep it alive
         self.set_stream(cur.cuda_stream)
+
+    def restore_torch_stream(self):
+        """Undo use_torch_stream()'s stream switch: the library goes back to its own stream (after the work queued so far)
+        and torch's current stream for this thread is the one it was before."""
+        prev = getattr(self, "_torch_prev_stream", None)
+        if prev is None:
+            return
+        import torch
+        cur = getattr(self, "_torch_stream", None)
+        if self.handle:
+            self.set_stream(None)  # synchronises the stream it leaves
+        if cur is not None:
+            prev.wait_stream(cur)
+        torch.cuda.set_stream(prev)
+        self._torch_prev_stream = None
+        self._torch_stream = None
 
     def sync(self):
         check(self._L.ws_sync(self.handle), "ws_sync")
@@ -128,6 +150,10 @@ class Context:
 
     def close(self):
         if self.handle:
+            try:
+                self.restore_torch_stream()
+            except Exception:  # noqa: BLE001 - closing must not fail on a torch that is already shutting down
+                pass
             self._L.ws_ctx_destroy(self.handle)
             self.handle = None
 
@@ -544,6 +570,10 @@ class TSDFCuda:
     def set_capacity(self, records: int):
         check(self._L.ws_tsdf_set_capacity(self.handle, int(records)), "ws_tsdf_set_capacity")
 
+    def debug_chunk_policy(self, budget_bytes: int, est_shift: int):
+        """test entry: size the chunk buffer by estimate (see ws_debug_tsdf_chunk_policy)"""
+        check(self._L.ws_debug_tsdf_chunk_policy(self.handle, int(budget_bytes), int(est_shift)), "ws_debug_tsdf_chunk_policy")
+
     def stats(self, raise_on_error: bool = False) -> dict:
         st = _lib.TsdfStats()
         rc = self._L.ws_tsdf_stats(self.handle, C.byref(st))
@@ -814,37 +844,8 @@ class TSDFMapping:
         lm, avg = self.local_map_, self.tsdf_.avg_map()
         new_pos = _i3(new_pos)
         L = self.tsdf_._L
-        with self.mutex_:
-            ticket = C.c_void_p()
-            check(L.ws_shift_begin(self.tsdf_.handle, _ptr(new_pos), int(lm.map_.default_raw), C.byref(ticket)), "ws_shift_begin")
-            n = L.ws_shift_count(ticket)
-            # the host view of the window follows (pos / offset per axis exactly like HDF5LocalMap::shift)
-            diff = new_pos.astype(np.int64) - lm.pos
-            for axis in range(3):
-                d = int(diff[axis])
-                lm.pos[axis] += d
-                lm.offset[axis] = (lm.offset[axis] + d + lm.size[axis]) % lm.size[axis]
-            # revisited space: chunks the global map already has overwrite the default fill
-            cs = GlobalMap.CHUNK_SIZE
-            lo, hi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
-            for i in range(n):
-                check(L.ws_shift_entering(ticket, i, _ptr(lo), _ptr(hi)), "ws_shift_entering")
-                # a later axis step moves the window again: only the part of the slab still inside the FINAL window counts
-                half = lm.size.astype(np.int64) // 2
-                a = np.maximum(lo.astype(np.int64), lm.pos.astype(np.int64) - half)
-                b = np.minimum(hi.astype(np.int64), lm.pos.astype(np.int64) + half)
-                if np.any(a > b):
-                    continue
-                c0, c1 = np.floor_divide(a, cs), np.floor_divide(b, cs)
-                for cx in range(int(c0[0]), int(c1[0]) + 1):
-                    for cy in range(int(c0[1]), int(c1[1]) + 1):
-                        for cz in range(int(c0[2]), int(c1[2]) + 1):
-                            if not lm.map_.has_chunk(cx, cy, cz):
-                                continue
-                            base = np.array([cx, cy, cz], dtype=np.int64) * cs
-                            sa, sb = np.maximum(a, base), np.minimum(b, base + cs - 1)
-                            avg.insert_box(sa, sb, lm.map_.load_box(sa, sb))
-
+        ticket = C.c_void_p()
+        n = 0
         self._shift_error = None
 
         def file_slabs():
@@ -879,8 +880,47 @@ class TSDFMapping:
                         box[sl] = lm.map_.load_box(a, b).reshape(int(e[0]), int(e[1]), int(e[2]))
                 lm.map_.save_box(slo.copy(), shi.copy(), buf)
 
+        with self.mutex_:
+            check(L.ws_shift_begin(self.tsdf_.handle, _ptr(new_pos), int(lm.map_.default_raw), C.byref(ticket)), "ws_shift_begin")
+            n = L.ws_shift_count(ticket)
+            try:
+                self._shift_enter(L, ticket, n, new_pos, lm, avg)
+            except BaseException:
+                # the window has moved on the device: the leaving slabs are still filed and the ticket is closed (an open
+                # ticket makes every later ws_shift_begin fail); the failure itself goes to the caller
+                file_slabs()
+                raise
         self._shift_worker = threading.Thread(target=file_slabs, name="warpsense-map-shift", daemon=True)
         self._shift_worker.start()
+
+    def _shift_enter(self, L, ticket, n, new_pos, lm, avg):
+        """the host side of an asynchronous shift between ws_shift_begin and the start of the worker"""
+        # the host view of the window follows (pos / offset per axis exactly like HDF5LocalMap::shift)
+        diff = new_pos.astype(np.int64) - lm.pos
+        for axis in range(3):
+            d = int(diff[axis])
+            lm.pos[axis] += d
+            lm.offset[axis] = (lm.offset[axis] + d + lm.size[axis]) % lm.size[axis]
+        # revisited space: chunks the global map already has overwrite the default fill
+        cs = GlobalMap.CHUNK_SIZE
+        lo, hi = np.zeros(3, dtype=np.int32), np.zeros(3, dtype=np.int32)
+        for i in range(n):
+            check(L.ws_shift_entering(ticket, i, _ptr(lo), _ptr(hi)), "ws_shift_entering")
+            # a later axis step moves the window again: only the part of the slab still inside the FINAL window counts
+            half = lm.size.astype(np.int64) // 2
+            a = np.maximum(lo.astype(np.int64), lm.pos.astype(np.int64) - half)
+            b = np.minimum(hi.astype(np.int64), lm.pos.astype(np.int64) + half)
+            if np.any(a > b):
+                continue
+            c0, c1 = np.floor_divide(a, cs), np.floor_divide(b, cs)
+            for cx in range(int(c0[0]), int(c1[0]) + 1):
+                for cy in range(int(c0[1]), int(c1[1]) + 1):
+                    for cz in range(int(c0[2]), int(c1[2]) + 1):
+                        if not lm.map_.has_chunk(cx, cy, cz):
+                            continue
+                        base = np.array([cx, cy, cz], dtype=np.int64) * cs
+                        sa, sb = np.maximum(a, base), np.minimum(b, base + cs - 1)
+                        avg.insert_box(sa, sb, lm.map_.load_box(sa, sb))
 
     def reserve_shift(self, shift_voxels: int):
         """staging for asynchronous shifts of up to `shift_voxels` per axis (plus slack), allocated now instead of inside

@@ -177,30 +177,28 @@ int ws_device_reset(void)
 // ------------------------------------------------------------------ maps
 static void map_free_records(ws_map *m)
 {
-  void *ptrs[] = {m->rec_raw, m->rec_sorted, m->desc, m->sorted_desc};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
-  m->rec_raw = m->rec_sorted = nullptr;
-  m->desc = nullptr;
-  m->sorted_desc = nullptr;
-  m->rec_cap = m->desc_cap = 0;
+  if (m->rec) (void)hipFree(m->rec);
+  if (m->big_keys) (void)hipFree(m->big_keys);
+  m->rec = nullptr;
+  m->big_keys = nullptr;
+  m->chunk_cap = 0;
+  m->big_slots = 0;
 }
 
-// candidate-record buffers of the tail march: two record arrays (as emitted / sorted by tile) + run descriptors
-static int map_alloc_records(ws_map *m, uint64_t records)
+// candidate records of the ray tails: chunks of 256 x 8 bytes that belong to one tile each, and the (tile, chunk number) ->
+// chunk hash for tiles of more than TILE_DIRECT chunks (two slots per chunk; keys, then uint32 values)
+static int map_alloc_records(ws_map *m, uint64_t chunks)
 {
-  if (records < (1u << 20)) records = 1u << 20;
-  if (records > 0xfffffff0ull) records = 0xfffffff0ull;
+  if (chunks < 4096) chunks = 4096;
+  if (chunks > 0xfffffff0ull) chunks = 0xfffffff0ull;
   map_free_records(m);
-  uint64_t descs = records / 8 * m->desc_scale; // a run holds ~100 records on LiDAR scans; 8 leaves room for scattered clouds
-  if (descs > records) descs = records;          // (one run per record is the most there can be)
-  if (descs < (1u << 18)) descs = 1u << 18;
-  WS_HIP(hipMalloc((void **)&m->rec_raw, (size_t)records * sizeof(CandRecord)));
-  WS_HIP(hipMalloc((void **)&m->rec_sorted, (size_t)records * sizeof(CandRecord)));
-  WS_HIP(hipMalloc((void **)&m->desc, (size_t)descs * sizeof(RunDesc)));
-  WS_HIP(hipMalloc((void **)&m->sorted_desc, (size_t)descs * 2 * sizeof(uint32_t)));
-  m->rec_cap = (uint32_t)records;
-  m->desc_cap = (uint32_t)descs;
+  uint64_t slots = 1u << 16;
+  while (slots < 2 * chunks && slots < (1ull << 31)) slots <<= 1;
+  WS_HIP(hipMalloc((void **)&m->rec, (size_t)chunks * CHUNK_RECS * sizeof(unsigned long long)));
+  WS_HIP(hipMalloc((void **)&m->big_keys, (size_t)slots * (sizeof(unsigned long long) + sizeof(uint32_t))));
+  m->chunk_cap = (uint32_t)chunks;
+  m->big_slots = (uint32_t)slots;
+  m->prepped = false; // the new hash is filled by the stand-alone preparation pass
   return WS_OK;
 }
 
@@ -216,8 +214,8 @@ static int map_free(ws_map *m)
       break;
     }
   map_free_records(m);
-  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nruns,
-                  m->tile_begin, m->tile_dirty, m->tile_list, m->block_sums, m->fk_keys, m->block_stats, m->box_stage};
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_fill,
+                  m->tile_chunk, m->tile_dirty, m->tile_list, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -244,7 +242,7 @@ static int map_take_error(ws_map *m)
   m->last_error_bits |= bits;
   if (bits & 8u)
   {
-    set_error("TSDF update: internal consistency check failed on the device (record slice bound / free-space hash); the map is not exact");
+    set_error("TSDF update: internal consistency check failed on the device (chunk table); the map is not exact");
     return WS_ERR_INTERNAL;
   }
   if (bits & 4u)
@@ -254,12 +252,10 @@ static int map_take_error(ws_map *m)
   }
   if (bits & 1u)
   {
-    m->grow_aux = true;
-    set_error("TSDF update: run-descriptor / free-space-hash capacity exceeded, a TSDF update since the last check is not exact "
-              "(both are doubled before the next scan)");
+    set_error("TSDF update: record capacity exceeded, a TSDF update since the last check is not exact");
     return WS_ERR_CAPACITY;
   }
-  set_error("TSDF update: a ray needs more than 65536 steps or 256 fan steps (outside the order-key range) and was dropped");
+  set_error("TSDF update: a ray needs more than 8192 steps or 31 fan steps (outside the range of the record fields) and was dropped");
   return WS_ERR_RANGE;
 }
 
@@ -305,11 +301,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     delete m;
     return invalid("ws_map_create: more than 2^31 tiles");
   }
-  m->scan_blocks = tile_scan_blocks(m->n_tiles);
   m->tau = tau;
   m->max_weight = max_weight;
   m->res = res;
-  m->fk_slots = 1u << 20;
 
   hipStream_t s = ctx->stream;
   int rc = WS_OK;
@@ -328,8 +322,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   // 16 bytes of slack: the tile kernels read the four voxels of a column as one access, also at the very end
   TRY(hipMalloc((void **)&m->data[0], map_bytes + 16));
   TRY(hipMalloc((void **)&m->data[1], map_bytes + 16));
-  TRY(hipMalloc((void **)&m->vstate, (size_t)m->n_vox + 16));
-  TRY(hipMemsetAsync(m->vstate, 0, (size_t)m->n_vox, s));
+  TRY(hipMalloc((void **)&m->vstate, 2 * vstate_plane_bytes(m->n_vox)));
+  TRY(hipMemsetAsync(m->vstate, 0, 2 * vstate_plane_bytes(m->n_vox), s));
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
@@ -343,26 +337,23 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
   TRY(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
-  // per-tile bookkeeping of the scatter: 9 bytes + one 16-byte list entry per 1024 voxels
-  TRY(hipMalloc((void **)&m->tile_nruns, (size_t)m->n_tiles * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->tile_begin, (size_t)m->n_tiles * sizeof(uint32_t)));
+  // per-tile bookkeeping of the scatter: record count, chunk table, a byte, one 16-byte list entry per 1024 voxels
+  TRY(hipMalloc((void **)&m->tile_fill, (size_t)m->n_tiles * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->tile_chunk, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->tile_dirty, (size_t)m->n_tiles));
   TRY(hipMalloc((void **)&m->tile_list, (size_t)m->n_tiles * sizeof(TileEntry)));
-  TRY(hipMalloc((void **)&m->block_sums, (size_t)m->scan_blocks * 4 * sizeof(uint32_t)));
-  TRY(hipMemsetAsync(m->tile_nruns, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->tile_fill, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->tile_chunk, 0, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->tile_dirty, 0, (size_t)m->n_tiles, s));
-  // keys, values, then one bit per slot: claimed by the current scan (so that the clean-up clears ~25 000 entries, not 2 x 2^20)
-  TRY(hipMalloc((void **)&m->fk_keys, (size_t)m->fk_slots * 2 * sizeof(unsigned long long) + m->fk_slots / 8));
-  m->fk_vals = m->fk_keys + m->fk_slots;
   TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
   TRY(hipHostMalloc((void **)&m->status_host, 64, hipHostMallocMapped));
   std::memset(m->status_host, 0, 64);
   TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
-  // records of the ray tails: 32 Mi by default (a 131 072-point OS1 scan at 50 mm reserves ~29 Mi slots);
-  // grows on demand from the previous scan's need, ws_tsdf_set_capacity() reserves up front
-  rc = map_alloc_records(m, 32ull << 20);
+  // chunks of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
+  // every scan checks the buffer against its own bound and grows it first if it must, ws_tsdf_set_capacity() reserves up front
+  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20));
   if (rc != WS_OK)
   {
     map_free(m);
@@ -684,31 +675,14 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  return map_alloc_records(m, records);
+  return map_alloc_records(m, (records + CHUNK_RECS - 1) / CHUNK_RECS);
 }
 
-// A scan that overflowed the run descriptors or the free-space hash (WS_ERR_CAPACITY, reported by the first call that
-// synchronised afterwards) doubles both before the next scan.  The RECORD buffers never overflow: every scan sizes them
-// itself (launch_tsdf_scatter waits for the bound its set-up pass computes).
-static int grow_aux_for_next_scan(ws_map *m)
+int ws_debug_tsdf_chunk_policy(ws_map *m, uint64_t budget_bytes, uint32_t est_shift)
 {
-  if (!m->grow_aux) return WS_OK;
-  m->grow_aux = false;
-  WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  m->desc_scale *= 2;
-  int rc = map_alloc_records(m, m->rec_cap);
-  if (rc != WS_OK) return rc;
-  if (m->fk_slots < (1u << 28))
-  {
-    unsigned long long *fk = nullptr;
-    const uint32_t slots = m->fk_slots * 2;
-    WS_HIP(hipMalloc((void **)&fk, (size_t)slots * 2 * sizeof(unsigned long long) + slots / 8));
-    (void)hipFree(m->fk_keys);
-    m->fk_keys = fk;
-    m->fk_vals = fk + slots;
-    m->fk_slots = slots;
-    m->prepped = false; // the new hash is filled by the stand-alone preparation pass
-  }
+  if (!m) return invalid("ws_debug_tsdf_chunk_policy: map is NULL");
+  m->chunk_budget_bytes = budget_bytes;
+  m->est_shift = est_shift;
   return WS_OK;
 }
 
@@ -725,9 +699,7 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
-  int rc = grow_aux_for_next_scan(m);
-  if (rc != WS_OK) return rc;
-  rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
+  int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
   if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
   return rc;
 }
@@ -742,8 +714,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_update_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
-  int rc = grow_aux_for_next_scan(m);
-  if (rc != WS_OK) return rc;
+  int rc;
   // with the default (sparse) integrate the tile resolve folds cu_avg_tsdf_krnl into its write-back (new_map stays
   // (tau, 0)); a non-default new_map is resolved on top of its entries and integrated by the dense pass
   prof_begin(m->ctx, WS_K_UPDATE);
@@ -780,8 +751,8 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   out->tiles = c->last_listed;
   out->runs = c->last_runs;
   out->free_space_hits = c->last_free_keyed;
-  out->record_slots = c->last_slots;
-  out->record_capacity = m->rec_cap;
+  out->record_slots = (int64_t)c->last_need;
+  out->record_capacity = (int64_t)m->chunk_cap * CHUNK_RECS;
   const int rc = map_take_error(m);
   out->error_flags = (int32_t)m->last_error_bits;
   out->pad = 0;
@@ -1082,6 +1053,7 @@ static int peer_finish_connect(ws_reg *r, int rank, int world, int blocks)
   r->peer_rank = rank;
   r->peer_world = world;
   r->peer_blocks = blocks;
+  r->peer_dirty = false;
   return WS_OK;
 }
 
@@ -1152,6 +1124,9 @@ int ws_register_cloud_peers(ws_reg *r, const ws_map *m, size_t first, size_t cou
 {
   if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud_peers: NULL argument");
   if (!r->peer_world) return invalid("ws_register_cloud_peers: ws_reg_peer_connect first");
+  // An exchange that was given up leaves partial additions in the mailboxes and no saved snapshot: a rank's stale addition
+  // plus its next one would reach count == world and pass for the all-rank total.  Nothing runs until the mailboxes are fresh.
+  if (r->peer_dirty) return invalid("ws_register_cloud_peers: the last exchange failed; call ws_reg_peer_reset on every rank (between two barriers) or reconnect first");
   if (res < 1) return invalid("ws_register_cloud_peers: map_resolution must be positive");
   GnCore init;
   std::memset(&init, 0, sizeof init);
@@ -1161,6 +1136,7 @@ int ws_register_cloud_peers(ws_reg *r, const ws_map *m, size_t first, size_t cou
   init.epsilon = epsilon;
   init.max_iterations = max_iterations;
   *(volatile int32_t *)r->host_flag = 0;
+  r->peer_dirty = true; // until this exchange has completed on this rank
   int rc = launch_reg_loop(r, m, res, flags, init, true, first, count);
   if (rc != WS_OK) return rc;
   r->latest = 0;
@@ -1175,6 +1151,7 @@ int ws_register_cloud_peers(ws_reg *r, const ws_map *m, size_t first, size_t cou
     set_error("ws_register_cloud_peers: the exchange with the peer ranks timed out");
     return WS_ERR_TIMEOUT;
   }
+  r->peer_dirty = false;
   std::memcpy(T_out, h->T, 16 * sizeof(float));
   if (iterations) *iterations = h->iterations;
   return map_take_error(const_cast<ws_map *>(m));
@@ -1382,9 +1359,9 @@ int ws_prof_reset(ws_context *ctx)
 
 namespace ws
 {
-int resize_records(ws_map *m, uint64_t records)
+int resize_records(ws_map *m, uint64_t chunks)
 {
   WS_HIP(hipStreamSynchronize(m->ctx->stream)); // nothing enqueued may still use the old buffers
-  return map_alloc_records(m, records);
+  return map_alloc_records(m, chunks);
 }
 } // namespace ws

@@ -19,6 +19,7 @@
 // wrapping group accumulators whose words count their additions (the exchange is the barrier), a per-lane voxel cache.
 // reg_iter_kernel is one launch per iteration (state and 256 x 32 partials double buffered by launch parity, so no
 // fences or atomics are needed); it is the fallback when the grid cannot be resident, and the A/B reference.
+#include <cstdlib>
 #include <cstring>
 
 #include "ws_device.h"
@@ -1235,9 +1236,10 @@ constexpr int REG_PEER_POLL_SLEEP = WS_REG_PEER_POLL_SLEEP; // x 64 clocks befor
 // exchange that is not complete after 5 ms means that some workgroup is not on the chip (another kernel holds its CU):
 // ws_register_cloud then repeats the registration with one launch per iteration, which needs no co-residency -- half a
 // frame at 100 Hz lost, not the 2.5 frames at 10 Hz the 0.25 s of round 2 cost.  Ranks of a multi-GPU loop are launched by
-// different processes: their mailboxes wait 0.25 s.
+// different processes that have just been handed the same scan: their mailboxes wait 20 ms (round 3: 0.25 s; WS_REG_PEER_TIMEOUT_MS
+// in the environment at connect time changes it -- ranks that SHARE a GPU in the tests start further apart), kept in the PeerBlock.
 constexpr long long REG_BARRIER_TIMEOUT_TICKS = 500000ll;
-constexpr long long REG_PEER_TIMEOUT_TICKS = 25000000ll;
+constexpr long long REG_PEER_TIMEOUT_TICKS = 2000000ll;
 
 // first wave (all 64 lanes), after wave_reduce32: workgroup total of every slot, one half per lane, into the group accumulator
 template <bool MFMA = false>
@@ -1325,7 +1327,7 @@ struct PeerBlock
   int32_t rank, world;
   uint32_t exchanges; // exchanges completed by all launches so far: the mailbox parity CONTINUES across launches (a rank that
                       // is already in the next registration adds into the parity its slower peers are NOT still polling)
-  int32_t pad;
+  int32_t timeout_ticks; // poll limit of one exchange on the 100 MHz wall clock
   uint64_t then[2][REG_WORDS];
 };
 __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, uint64_t &then, int64_t &total /* lanes 0..31: in this rank's, out all ranks' */,
@@ -1345,6 +1347,7 @@ __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, u
   uint64_t w;
   uint32_t spins = 0;
   long long t0 = 0;
+  const long long limit = pb->timeout_ticks;
   __builtin_amdgcn_s_sleep(REG_PEER_POLL_SLEEP);
   for (;;)
   {
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ bool peer_exchange(const PeerBlock *pb, int parity, u
     {
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
-      const bool give_up = now - t0 > REG_PEER_TIMEOUT_TICKS || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      const bool give_up = now - t0 > limit || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
       if (__any(give_up))
       {
         if (lane == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1941,6 +1944,13 @@ void reg_peer_block_fill(void *host_image, void *const mailbox[8], int rank, int
   for (int i = 0; i < 8; ++i) pb->mailbox[i] = reinterpret_cast<uint64_t *>(i < world ? mailbox[i] : nullptr);
   pb->rank = rank;
   pb->world = world;
+  long long ticks = REG_PEER_TIMEOUT_TICKS;
+  if (const char *ms = std::getenv("WS_REG_PEER_TIMEOUT_MS"))
+  {
+    const long long v = std::atoll(ms);
+    if (v >= 1 && v <= 20000) ticks = v * 100000ll;
+  }
+  pb->timeout_ticks = (int32_t)ticks;
 }
 size_t reg_mailbox_bytes() { return sizeof(uint64_t) * 2 * REG_WORDS; }
 int reg_groups() { return REG_GROUPS; }

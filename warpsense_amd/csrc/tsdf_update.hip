@@ -7,17 +7,17 @@
 // implementation computes the result of ONE fixed legal schedule — the serial one, ascending
 // (point, ray step, fan step) — deterministically, without a single global atomic per candidate:
 //
-//   ray_setup/scan/scatter   per-ray constants (update_tsdf.cu:52-63), rays grouped by direction.
+//   ray_setup / ray_sort     per-ray constants (update_tsdf.cu:52-63), rays grouped by direction.
 //   march_tail_kernel        walks the ray TAILS once (near-surface and fan candidates: everything whose result
-//                            depends on the order).  Every scatter target becomes a 16-byte record
-//                            (order key, tile, voxel-in-tile) appended to the workgroup's private slice with
-//                            coalesced stores; the workgroup then sorts its own records by tile through an LDS hash
-//                            and publishes one run descriptor per (workgroup, tile).
+//                            depends on the order).  Every scatter target becomes an 8-byte record staged in LDS; when
+//                            the staging area fills up (and at the end) the workgroup reserves, with one atomic per tile
+//                            it touched, a range of that tile's record sequence and copies its records there: records
+//                            live in 2 KB chunks that belong to one tile each, HBM sees every record once.  Off-ray
+//                            candidates of value +tau are (tau, -64) whoever makes them and never take part in the
+//                            order: a byte in the second voxel plane instead of a record.
 //   march_free_kernel        walks the steps before the tails: all free space (tau, +64) whoever comes first ->
-//                            one byte per voxel.  A free-space candidate landing on a voxel the tails marked goes
-//                            into a small (voxel -> earliest key) hash instead.
-//   tile_count/scan/list     runs per tile -> contiguous descriptor ranges + the list of touched tiles.
-//   desc_place_kernel        run descriptors grouped by tile.
+//                            one byte per voxel.  A free-space candidate landing on a voxel the tails marked joins that
+//                            tile's records instead.
 //   tile_resolve_kernel      ONE workgroup per touched 4x4x64-voxel tile: all candidates of the tile are present,
 //                            so the canonical accept rule is a local fold in LDS (earliest positive / smallest
 //                            negative keys, then exact rounds for the voxels where a negative-weight candidate
@@ -26,8 +26,9 @@
 //   integrate_*_kernel       weighted average of new_map into avg_map and reset of new_map, over the touched
 //                            tiles only (sparse) or over every voxel (dense, the reference's kernel).
 //
-// new_map after the resolve is bit-identical to what the reference kernel leaves there when its threads
-// run one after the other (oracle/ws_oracle.c: wso_update_min).
+// The list of touched tiles is built on the way (the first reservation / the first free-space mark of a tile appends
+// it): no scan over the tile grid, no descriptors.  new_map after the resolve is bit-identical to what the reference
+// kernel leaves there when its threads run one after the other (oracle/ws_oracle.c: wso_update_min).
 #include <atomic>
 #include <chrono>
 #include <cstddef>
@@ -56,26 +57,26 @@ struct ScatterArgs
   uint2 *ray_bin;      // [n] (direction bin, rank inside the bin) of every ray: set-up blocks -> sort blocks of the same launch
   uint32_t *ray_order; // ray indices sorted by direction bin
   const int32_t *fan_steps; // [256], see tail_bound
-  uint8_t *vstate;     // one byte per voxel: VOX_*
+  uint8_t *vstate;     // two planes of one byte per voxel: VOX_* / off-ray free-space mark
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
-  uint32_t *tile_nruns;
-  CandRecord *rec_raw;
-  CandRecord *rec_sorted;
-  uint32_t rec_cap;
-  uint32_t scan_seq; // sequence number of this scatter (in the padding behind rec_cap: the arguments stay within 256 bytes)
-  RunDesc *desc;
-  uint32_t desc_cap;
-  unsigned long long *fk_keys; // the values follow the keys (fk_keys + fk_mask + 1): one allocation, and the arguments stay within 256 bytes
-  int32_t fk_shift; // 64 - log2(slots)
-  uint32_t fk_mask;
-  uint32_t *tail_stats; // records per workgroup of the tail march
+  uint32_t *tile_fill;  // [tiles] records of the tile | FILL_DIRTY
+  uint32_t *tile_chunk; // [tiles][TILE_DIRECT] chunk id + 1
+  TileEntry *tile_list;
+  unsigned long long *rec; // chunks of CHUNK_RECS records
+  uint32_t chunk_cap;
+  uint32_t scan_seq;  // sequence number of this scatter
+  unsigned long long *big_keys; // (tile, chunk number) -> chunk id beyond TILE_DIRECT: keys, then uint32 values (big_mask + 1 slots)
+  uint32_t big_mask;
+  uint32_t est_shift; // != 0: the chunk buffer is sized by estimate (need >> (est_shift - 1)), not by the hard bound: see chunks_needed()
+  uint32_t *tail_stats; // records / flush groups per workgroup of the tail march
   TsdfCounters *counters;
-  uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number
+  uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number, [8] / [9] see ws_map::status_host
 };
 // 264 bytes of kernel arguments instead of 256 cost reg_loop_kernel 30 % (registration.hip); the same bound here
 static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of kernel arguments");
 
-constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2, VOX_FREEHIT = 4;
+constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
+constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
 #ifndef WS_FUSE_SETUP
@@ -84,17 +85,6 @@ constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTE
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
 #endif
-#ifndef WS_FUSE_PLACE
-#define WS_FUSE_PLACE 1 // 1: tile scan and descriptor placement in one launch
-#endif
-#ifndef WS_TAIL_PERSISTENT
-#define WS_TAIL_PERSISTENT 0 // (measured: 216-222 us against 187-195 us for one workgroup per item: resident workgroups run in lock step and their sort phases collide)
-//  1: the tail march runs as resident workgroups that take (64 rays x 4 parts) items from a counter
-#endif
-#ifndef WS_SORT_U
-#define WS_SORT_U 8 // (4: 188-191 us, 8: 185-187 us, 2: 196-198 us) records a thread of the tail march has in flight while it copies the workgroup's records into tile order
-#endif
-constexpr int SORT_U = WS_SORT_U;
 #ifndef WS_FREE_PIPE
 #define WS_FREE_PIPE 1 // 1: the voxel byte of a free-space candidate is requested one emit phase before it is used (126 -> 122 us)
 #endif
@@ -136,51 +126,48 @@ __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
   return (uint32_t)(((sx & ((1 << TILE_XB) - 1)) << (TILE_YB + TILE_ZB)) | ((sy & ((1 << TILE_YB) - 1)) << TILE_ZB) | (sz & ((1 << TILE_ZB) - 1)));
 }
 
-// everything the scatter expects to be zero / empty, in ONE launch (five memsets cost five launch gaps)
+// everything the scatter expects to be zero / empty, in ONE launch (after map creation and after the buffers were resized:
+// in steady state every kernel of a scan puts back the scratch it has consumed, there is no clean-up launch)
 struct PrepArgs
 {
   TsdfCounters *counters;
   uint32_t *az_hist;
   uint32_t n_hist;
-  uint32_t *tile_nruns;
+  uint32_t *tile_fill;
+  uint32_t *tile_chunk;
+  uint8_t *tile_dirty;
   int64_t n_tiles;
-  unsigned long long *fk; // keys and values: one allocation
-  int64_t n_fk;
-  unsigned long long *look; // look-back words of the tile scan
-  uint32_t n_look;
+  unsigned long long *big_keys;
+  uint32_t big_slots;
 };
-__device__ __forceinline__ void scatter_prep(const PrepArgs &p, bool counters_too)
+__global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
 {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
-  if (counters_too && tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
+  if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
   for (int64_t i = tid; i < p.n_hist; i += stride) p.az_hist[i] = 0;
-  for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nruns[i] = 0;
-  // the free-space key hash: all of it (the scans themselves only clear the slots they claimed, fk_clear_claimed)
-  uint32_t *claimed = reinterpret_cast<uint32_t *>(p.fk + p.n_fk);
-  for (int64_t i = tid; i < p.n_fk; i += stride) p.fk[i] = KEY_INF;
-  for (int64_t i = tid; i < p.n_fk / 64; i += stride) claimed[i] = 0;
-  for (int64_t i = tid; i < p.n_look; i += stride) p.look[i] = 0;
-}
-// the slots of the free-space key hash the PREVIOUS scan claimed (one bit per slot behind the hash) back to empty; run
-// by the set-up blocks of a scan, long before its free-space pass
-__device__ __forceinline__ void fk_clear_claimed(unsigned long long *fk, uint32_t slots, int64_t tid, int64_t stride)
-{
-  uint32_t *claimed = reinterpret_cast<uint32_t *>(fk + 2 * (size_t)slots);
-  for (int64_t i = tid; i < (int64_t)(slots / 32); i += stride)
+  for (int64_t i = tid; i < p.n_tiles; i += stride)
   {
-    uint32_t bits = claimed[i];
-    if (bits == 0) continue;
-    claimed[i] = 0;
-    while (bits)
-    {
-      const uint32_t h = (uint32_t)i * 32u + (uint32_t)__builtin_ctz(bits);
-      bits &= bits - 1;
-      fk[h] = KEY_INF;
-      fk[(size_t)slots + h] = KEY_INF;
-    }
+    p.tile_fill[i] = 0;
+    p.tile_dirty[i] = 0;
+  }
+  for (int64_t i = tid; i < p.n_tiles * TILE_DIRECT; i += stride) p.tile_chunk[i] = 0;
+  uint32_t *big_vals = reinterpret_cast<uint32_t *>(p.big_keys + p.big_slots);
+  for (int64_t i = tid; i < p.big_slots; i += stride)
+  {
+    p.big_keys[i] = KEY_INF;
+    big_vals[i] = 0;
   }
 }
-__global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p) { scatter_prep(p, true); }
+
+// Chunks a scan whose records are bounded by `need` can use at most: every tile with records ends in one partly filled
+// chunk, so sum over tiles of ceil(r / 256) <= need / 256 + min(tiles, need).  est_shift != 0 (maps whose tile term alone
+// would cost gigabytes): an estimate instead -- the bound counts every sample as a candidate, about 2.3 x what a scan
+// makes -- and a scan that does exhaust the chunks is ABORTED (nothing of it reaches the maps) and repeated with more.
+__host__ __device__ inline unsigned long long chunks_needed(unsigned long long need, unsigned long long n_tiles, uint32_t est_shift)
+{
+  if (est_shift) return ((need >> CHUNK_BITS) >> (est_shift - 1)) + 4096ull;
+  return (need >> CHUNK_BITS) + (n_tiles < need ? n_tiles : need) + 64ull;
+}
 
 // Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
 // = (k1 - k0) + sum_j #{steps with delta_z >= ceil(j*res/2)}.  Exact when every sample is a candidate; additive over ranges.
@@ -205,13 +192,15 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
 {
   __shared__ unsigned long long ub_wave[4];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
-  // the free-space key hash still holds what the previous scan claimed: back to empty, long before this scan's free pass.
-  // (this thread's word of the claimed-slots bitmap is requested here and used at the END of the block: its round trip
-  // runs under the ray arithmetic)
-  const uint32_t fk_slots = a.fk_mask + 1u;
-  uint32_t *const fk_claimed = reinterpret_cast<uint32_t *>(a.fk_keys + 2 * (size_t)fk_slots);
-  const bool fk_mine = ix < fk_slots / 32u && (uint64_t)n_setup_blocks * 256u >= fk_slots / 32u;
-  const uint32_t fk_bits = fk_mine ? fk_claimed[ix] : 0u;
+  if (ix == 0)
+  {
+    // what the marches of this scan count up (the previous scan's integrate pass has read its tile list by now)
+    a.counters->chunk_cursor = 0;
+    a.counters->n_listed = 0;
+    a.counters->abort = 0;
+    a.counters->error = 0;
+    a.counters->last_free_keyed = 0;
+  }
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
@@ -265,9 +254,9 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
         const int64_t steps = div_trunc_i64(len_end - 1, half) + 1;
         const int64_t max_delta_z = (int64_t)DZ_PER_DISTANCE * len_end / MATRIX_RESOLUTION;
         const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
-        if (steps > 65536 || (max_delta_z * 2) / res + 1 > 256 || !small_iv)
+        if (steps > REC_MAX_STEPS || (max_delta_z * 2) / res + 1 > REC_MAX_FAN || !small_iv)
         {
-          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the order key
+          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the record's step / fan fields
         }
         else
         {
@@ -305,12 +294,16 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
             if (inside) r.pad |= RAY_SIMPLE;
           }
 
-          // Split of the ray.  A candidate is "free space" iff it is on-ray (positive weight) with value == +tau;
-          // ALL candidates of a ray are of that kind while len < min(len_neg, distance - tau - slack): before len_neg
-          // there is no fan, and a voxel centre further than tau from the hit point gives min(dist, tau) == tau.  The
-          // slack covers |centre - proj| (1.5 voxels per axis for the double-width cell of trunc division + the fan
-          // offset).  The bound argues with exact positions: rays whose `int` products wrap (not `fast`) and scans
-          // into a non-default new_map send every step through the order keys.
+          // Split of the ray.  A candidate is "free space" iff its value is +tau: the on-ray one is (tau, +64), the off-ray
+          // ones of its fan (tau, -64), whichever ray they come from -- so neither needs a record: the first is a byte per voxel
+          // (its order only matters on a voxel that also has records: earliest key, free-space hash), the second never takes
+          // part in the order at all (|value| == tau cannot block a positive candidate, and it only wins where nothing else
+          // landed: a second byte plane).  ALL candidates of a ray are of that kind while len < distance - tau - slack: a
+          // voxel centre further than tau from the hit point gives min(dist, tau) == tau.  The slack covers |centre - proj|
+          // (1.5 voxels per axis for the double-width cell of trunc division + the fan offset).  The bound argues with
+          // exact positions: rays whose `int` products wrap (not `fast`) and scans into a non-default new_map send every
+          // step through the order keys.  (Until round 3 the tail also began at the first step with a fan, 8.2 m at 50 mm:
+          // a quarter of the benchmark scan's records were free space with a fan.)
           int32_t kfirst = 0;
           if (fast && !a.all_keyed)
           {
@@ -319,7 +312,9 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
             if (kfirst > (int32_t)steps) kfirst = (int32_t)steps;
           }
           r.kfirst = kfirst;
-          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps);
+          // records this ray can make: the scatter targets of its tail + one per free-space step (a free-space candidate that
+          // lands on a voxel with records joins them)
+          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps) + (unsigned long long)kfirst;
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
@@ -372,24 +367,6 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
       __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  // the claimed slots of the free-space hash (see the top of the block)
-  if ((uint64_t)n_setup_blocks * 256u >= fk_slots / 32u)
-  {
-    uint32_t bits = fk_bits;
-    if (bits)
-    {
-      fk_claimed[ix] = 0;
-      while (bits)
-      {
-        const uint32_t h = ix * 32u + (uint32_t)__builtin_ctz(bits);
-        bits &= bits - 1;
-        a.fk_keys[h] = KEY_INF;
-        a.fk_keys[(size_t)fk_slots + h] = KEY_INF;
-      }
-    }
-  }
-  else
-    fk_clear_claimed(a.fk_keys, fk_slots, (int64_t)ix, (int64_t)n_setup_blocks * 256); // small scans: a strided loop
 }
 
 // Counting sort of the rays by direction bin, in the SAME launch as the set-up: blocks [0, S) are the set-up blocks above,
@@ -463,18 +440,197 @@ __global__ __launch_bounds__(256) void ray_setup_sort_kernel(ScatterArgs a, uint
 __global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a) { ray_sort_block<false>(a, 0); }
 
 // ---------------------------------------------------------------------------------------------------------
-// ray tails -> records, sorted by tile inside the workgroup
+// records of a tile: chunks, reservation, look-up
 // ---------------------------------------------------------------------------------------------------------
-constexpr int HT_BITS = 10, HT_SLOTS = 1 << HT_BITS;
+__device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr long long CHUNK_WAIT_TICKS = 2000000ll; // 20 ms on the 100 MHz wall clock: a chunk id that has not appeared by then never will
+
+__device__ __forceinline__ unsigned long long big_key(uint32_t tile, uint32_t j) { return ((unsigned long long)tile << 24) | j; } // j < 2^23
+__device__ __forceinline__ uint32_t big_slot(unsigned long long key, uint32_t mask) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask; }
+
+// a scan that runs out of chunks is aborted: its records are dropped from here on, the later kernels only put the scratch
+// back and the host repeats the scan with a larger buffer (launch_tsdf_scatter)
+__device__ __forceinline__ void raise_abort(const ScatterArgs &a)
+{
+  __hip_atomic_store(&a.counters->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// chunk number j of `tile` is chunk id1 - 1 (or CHUNK_LOST).  Never waits for anybody.
+__device__ __forceinline__ void chunk_publish(const ScatterArgs &a, uint32_t tile, uint32_t j, uint32_t id1)
+{
+  if (j < (uint32_t)TILE_DIRECT)
+  {
+    store_agent(&a.tile_chunk[(size_t)tile * TILE_DIRECT + j], id1);
+    return;
+  }
+  const unsigned long long key = big_key(tile, j);
+  uint32_t *vals = reinterpret_cast<uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
+  uint32_t h = big_slot(key, a.big_mask);
+  for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
+  {
+    const unsigned long long old = atomicCAS(&a.big_keys[h], KEY_INF, key);
+    if (old == KEY_INF || old == key)
+    {
+      // (a key stays in the table when its tile is released -- only the value goes back to "not published" -- so that the
+      // probe chains through it stay whole; the host empties the whole table before it fills up)
+      if (old == KEY_INF) atomicAdd(&a.counters->big_inserted, 1u);
+      store_agent(&vals[h], id1);
+      return;
+    }
+    h = (h + 1) & a.big_mask;
+  }
+  raise_error(a.counters, a.status, ERR_INTERNAL); // (the table has two slots per chunk)
+}
+
+// the chunk somebody else had to open (the one whose reservation covered the chunk's first record): poll until its id is
+// there.  The owner publishes right after its own reservation and never waits in between, so this ends.
+__device__ __forceinline__ uint32_t chunk_lookup(const ScatterArgs &a, uint32_t tile, uint32_t j)
+{
+  uint32_t spins = 0;
+  long long t0 = 0;
+  const unsigned long long key = big_key(tile, j);
+  const uint32_t *vals = reinterpret_cast<const uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
+  for (;;)
+  {
+    uint32_t v = CHUNK_NONE;
+    if (j < (uint32_t)TILE_DIRECT)
+      v = load_agent(&a.tile_chunk[(size_t)tile * TILE_DIRECT + j]);
+    else
+    {
+      uint32_t h = big_slot(key, a.big_mask);
+      for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
+      {
+        const unsigned long long cur = __hip_atomic_load(&a.big_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key)
+        {
+          v = load_agent(&vals[h]);
+          break;
+        }
+        if (cur == KEY_INF) break; // not inserted yet
+        h = (h + 1) & a.big_mask;
+      }
+    }
+    if (v != CHUNK_NONE) return v;
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255u) == 0)
+    {
+      const long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > CHUNK_WAIT_TICKS)
+      {
+        raise_error(a.counters, a.status, ERR_INTERNAL);
+        raise_abort(a);
+        return CHUNK_LOST;
+      }
+    }
+  }
+}
+
+// c records more for `tile`: the position of the first in the tile's record sequence, and the chunks that BEGIN inside the
+// range -- those are this caller's to open
+struct Reserve
+{
+  uint32_t p0;    // position of the first record
+  uint32_t j_new; // first chunk number to open
+  uint32_t n_new; // chunks to open
+  bool first;     // nobody has touched the tile in this scan: put it on the list
+};
+__device__ __forceinline__ Reserve tile_reserve(const ScatterArgs &a, uint32_t tile, uint32_t c)
+{
+  const uint32_t old = __hip_atomic_fetch_add(&a.tile_fill[tile], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  Reserve r;
+  r.first = old == 0;
+  r.p0 = old & ~FILL_DIRTY;
+  r.j_new = (r.p0 + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
+  const uint32_t j_last = (r.p0 + c - 1u) >> CHUNK_BITS;
+  r.n_new = j_last >= r.j_new ? j_last - r.j_new + 1u : 0u;
+  return r;
+}
+// chunks (low word) and list entries (high word) come from ONE counter: a workgroup asks once per flush
+__device__ __forceinline__ unsigned long long alloc_add(const ScatterArgs &a, unsigned long long chunks_and_listed)
+{
+  return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a.counters->chunk_cursor), chunks_and_listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static_assert(offsetof(TsdfCounters, chunk_cursor) == 0 && offsetof(TsdfCounters, n_listed) == 4, "chunk_cursor | n_listed << 32 is one 64-bit counter");
+__device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uint32_t tile)
+{
+  TileEntry e;
+  e.tile = tile;
+  e.tz = (int32_t)(tile % (uint32_t)a.ntz);
+  const uint32_t col = tile / (uint32_t)a.ntz;
+  e.ty = (int32_t)(col % (uint32_t)a.nty);
+  e.tx = (int32_t)(col / (uint32_t)a.nty);
+  a.tile_list[at] = e;
+}
+__device__ __forceinline__ uint32_t chunk_id1(const ScatterArgs &a, uint32_t cid)
+{
+  if (cid < a.chunk_cap) return cid + 1u;
+  raise_abort(a);
+  return CHUNK_LOST;
+}
+__device__ __forceinline__ void store_rec(const ScatterArgs &a, uint32_t id1, uint32_t q, unsigned long long rec)
+{
+  if (id1 != CHUNK_LOST) a.rec[(size_t)(id1 - 1u) * CHUNK_RECS + (q & (uint32_t)(CHUNK_RECS - 1))] = rec;
+}
+
+// one record, straight to its tile (a free-space candidate on a keyed voxel; the tail march when its staging area cannot
+// take a record).  All lanes publish what they have to open BEFORE any lane polls (two regions, in this order: a lane
+// may be waiting for a chunk a neighbouring lane of its own wave opens).
+__device__ __forceinline__ void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
+{
+  const Reserve r = tile_reserve(a, tile, 1u);
+  uint32_t id1 = CHUNK_NONE;
+  if (r.first || r.n_new)
+  {
+    const unsigned long long got = alloc_add(a, (unsigned long long)r.n_new | ((unsigned long long)(r.first ? 1u : 0u) << 32));
+    if (r.first) list_tile(a, (uint32_t)(got >> 32), tile);
+    if (r.n_new)
+    {
+      id1 = chunk_id1(a, (uint32_t)got);
+      chunk_publish(a, tile, r.j_new, id1);
+    }
+  }
+  asm volatile("" ::: "memory");
+  if (id1 == CHUNK_NONE) id1 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
+  store_rec(a, id1, r.p0, rec);
+}
+
+// a tile that holds no records but marks of the byte planes: on the list once (the byte in tile_dirty is only a filter in
+// front of this atomic; a stale zero there costs a second atomic, nothing else)
+__device__ __forceinline__ void list_dirty_tile_slow(const ScatterArgs &a, uint32_t tile)
+{
+  const uint32_t old = __hip_atomic_fetch_or(&a.tile_fill[tile], FILL_DIRTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == 0) list_tile(a, (uint32_t)(alloc_add(a, 1ull << 32) >> 32), tile);
+}
+__device__ __forceinline__ void list_dirty_tile(const ScatterArgs &a, uint32_t tile)
+{
+  if (a.tile_dirty[tile] != 0) return;
+  a.tile_dirty[tile] = 1;
+  list_dirty_tile_slow(a, tile);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ray tails -> records, staged in LDS and handed to their tiles
+// ---------------------------------------------------------------------------------------------------------
+constexpr int HT_BITS = 8, HT_SLOTS = 1 << HT_BITS; // tiles a workgroup can stage between two flushes (one slot per thread)
 #ifndef WS_TAIL_SPLIT
 #define WS_TAIL_SPLIT 2
 #endif
 #ifndef WS_TAIL_WGS
-#define WS_TAIL_WGS 6 // workgroups per CU the register budget is set for (80 VGPRs, no spills; 5 -> 6: 184 -> 181 us)
+#define WS_TAIL_WGS 4 // workgroups per CU the register budget is set for
+#endif
+#ifndef WS_TAIL_STAGE
+#define WS_TAIL_STAGE 2048 // records a workgroup stages before it flushes (8 + 2 bytes of LDS each)
 #endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
-constexpr uint32_t HT_EMPTY = 0xffffffffu, REC_DONE = 0xffffffffu;
+constexpr int TAIL_STAGE = WS_TAIL_STAGE;
+static_assert(TAIL_STAGE >= 64 * REC_MAX_FAN && TAIL_STAGE <= 65535, "one emit phase (64 samples with the widest fan) must fit the staging area");
+static_assert(HT_SLOTS == 256, "the flush gives every thread one slot of the tile table");
+constexpr uint32_t HT_EMPTY = 0xffffffffu;
+constexpr uint16_t SLOT_NONE = 0xffffu;
 
 __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
 {
@@ -492,703 +648,52 @@ __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
   }
   return -1;
 }
-__device__ __forceinline__ int ht_find(const uint32_t *keys, uint32_t tile)
+
+// n slots of the staging area, all or nothing (one lane calls; 0xffffffff: they do not fit before the next flush)
+__device__ __forceinline__ uint32_t stage_reserve(uint32_t *cursor, uint32_t n)
 {
-  uint32_t h = (tile * 0x9E3779B1u) >> (32 - HT_BITS);
-  for (int p = 0; p < HT_SLOTS; ++p)
+  uint32_t old = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (;;)
   {
-    const uint32_t cur = keys[h];
-    if (cur == tile) return (int)h;
-    if (cur == HT_EMPTY) return -1;
-    h = (h + 1) & (HT_SLOTS - 1);
+    if (old + n > (uint32_t)TAIL_STAGE) return 0xffffffffu;
+    const uint32_t seen = atomicCAS(cursor, old, old + n);
+    if (seen == old) return old;
+    old = seen;
   }
-  return -1;
 }
 
-// slot of the calling lane in a bump allocation shared by the lanes that reach this point together:
-// one LDS atomic per wave, not per lane
-__device__ __forceinline__ uint32_t lds_append(uint32_t *cursor)
+// inclusive prefix sum over the 64 lanes: four DPP shifts inside the rows of 16 (guarded: a lane whose source lies outside
+// its row keeps its value), then the totals of the rows in front through the scalar unit
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-  const unsigned long long mask = __ballot(1);
-  const int lane = (int)(threadIdx.x & 63);
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader); // (the leader is uniform: no trip through LDS for the broadcast, -3 us in the tail march)
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  const uint32_t rl = threadIdx.x & 15u, lane = threadIdx.x & 63u;
+  uint32_t t;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+  v += rl >= 1 ? t : 0u;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+  v += rl >= 2 ? t : 0u;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+  v += rl >= 4 ? t : 0u;
+  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+  v += rl >= 8 ? t : 0u;
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                 r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+  return v + (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(4))) u32x4_a4; // four consecutive voxels of a column: dword aligned only
 typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate bytes
 
-// A workgroup takes 64 rays of neighbouring directions (ray_order) and the four quarters of their tails (one
-// quarter per wave): its scatter targets fall into the same vertical slab of space, i.e. into few tiles.
-// does the scan in flight fit the record buffers?  (uniform: the set-up pass has finished, its total is final)
+// does the scan in flight fit the chunk buffer?  (uniform: the set-up pass has finished, its total is final)
 __device__ __forceinline__ bool scan_fits(const ScatterArgs &a)
 {
   // a plain (scalar) load: the total was finished by an earlier kernel.  (As a coherent load by every thread -- a million of
   // them on one address -- this line alone took the tail march from 190 to 500 us.)
   const unsigned long long need = a.counters->ub_total & ((1ull << 48) - 1ull);
-  return need <= (unsigned long long)a.rec_cap;
+  const unsigned long long n_tiles = (unsigned long long)a.ntx * (unsigned long long)a.nty * (unsigned long long)a.ntz;
+  return chunks_needed(need, n_tiles, a.est_shift) <= (unsigned long long)a.chunk_cap;
 }
-
-// one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails
-__device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
-{
-  __shared__ uint32_t s_cursor, s_base, s_ub, s_overflow, s_desc_base, s_round_total;
-  __shared__ uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_cur[HT_SLOTS];
-  __shared__ unsigned long long s_wave[4];
-  __shared__ u32x4 s_queue[4 * TAIL_QCAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n_sorted = a.az_off[AZ_BINS];
-  const uint32_t slot = (item / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
-  const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
-  const bool has_ray = slot < n_sorted;
-  uint32_t ix = 0;
-  RaySetup r;
-  r.steps = 0;
-  r.kfirst = 0;
-  r.ub = 0;
-  if (has_ray)
-  {
-    ix = a.ray_order[slot];
-    r = a.rays[ix];
-  }
-  // ---- phase 0: reserve a slice of the raw record buffer for the upper bound of this workgroup's records
-  if (threadIdx.x == 0)
-  {
-    s_cursor = 0;
-    s_overflow = 0;
-  }
-  for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
-  {
-    ht_key[i] = HT_EMPTY;
-    ht_cnt[i] = 0;
-  }
-  if (wave == 0)
-  {
-    unsigned long long ub = 0;
-    if (has_ray && r.steps > 0 && r.kfirst < r.steps)
-    {
-      const int32_t chp = (r.steps - r.kfirst + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
-      const int32_t ka = min(r.kfirst + part0 * chp, r.steps), kb = min(r.kfirst + (part0 + 4) * chp, r.steps);
-      ub = TAIL_SPLIT == 1 ? (unsigned long long)r.ub : tail_bound(ka, kb, (int64_t)r.distance + a.tau, a.fan_steps);
-    }
-    for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
-    if (lane == 0)
-    {
-      uint32_t base = 0xffffffffu;
-      if (ub == 0)
-        base = 0;
-      else if (ub <= a.rec_cap)
-      {
-        const uint32_t b = atomicAdd(&a.counters->raw_cursor, (uint32_t)ub);
-        if (b <= a.rec_cap - (uint32_t)ub) base = b;
-      }
-      if (base == 0xffffffffu) raise_error(a.counters, a.status, ERR_CAPACITY);
-      s_base = base;
-      s_ub = (uint32_t)ub;
-    }
-  }
-  __syncthreads();
-  const uint32_t base = s_base;
-  if (base == 0xffffffffu) return; // record buffer exhausted: this workgroup's candidates are lost, the error is sticky
-  const uint32_t ub_total = s_ub;
-
-#ifdef WS_TAIL_TIMING
-  const long long tt0 = wall_clock64(); // 100 MHz, the same clock on every CU: start / middle / end per workgroup -> ws_debug_block_stats
-#endif
-  // ---- phase 1: march, one record per scatter target
-  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
-  const bool mark = !a.all_keyed;
-  // one scatter target -> one record (vx, vy, vz: world voxel inside the window)
-  auto put_record = [&](uint32_t rix, int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-    const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
-                  sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-    // the free-space pass must know that this voxel takes part in the key order
-    if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
-    const uint32_t p = lds_append(&s_cursor);
-    if (p < ub_total)
-    {
-      u32x4 rec;
-      const uint64_t key = record_key(order_key(rix, k, step), value, positive);
-      rec.x = (uint32_t)key;
-      rec.y = (uint32_t)(key >> 32);
-      rec.z = tile_of(a.nty, a.ntz, sx, sy, sz);
-      // the workgroup's tile histogram is built on the fly (the slot travels in the record); a full table defers
-      // the record to the extra rounds of phase 2
-      const int slot = ht_insert(ht_key, rec.z);
-      // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together -- counting the lanes
-      // of a slot with ballots and adding once per (wave, tile) made the kernel 205 -> 345 us)
-      if (slot >= 0)
-        atomicAdd(&ht_cnt[slot], 1u);
-      else
-        s_overflow = 1;
-      rec.w = local_of(sx, sy, sz) | ((uint32_t)(slot >= 0 ? slot : HT_SLOTS) << 10);
-      *reinterpret_cast<u32x4 *>(&a.rec_raw[base + p]) = rec;
-    }
-    else
-    {
-      raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
-    }
-  };
-  int32_t k0 = 0, k1 = 0;
-  if (has_ray && r.steps > 0 && r.kfirst < r.steps)
-  {
-    const int32_t kbeg = r.kfirst, kend = r.steps;
-    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
-    k0 = min(kbeg + (part0 + wave) * ch, kend);
-    k1 = min(k0 + ch, kend);
-  }
-  const bool work = k0 < k1;
-  if (!__all(!work || (r.pad & RAY_SIMPLE)))
-  {
-    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
-    if (work)
-      march_steps<false>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-        put_record(ix, k, step, vx, vy, vz, value, positive);
-      });
-  }
-  else if (__any(work))
-  {
-    // compacting walk (ws_march.h): the sample phase queues (position, step, ray) of every sample that enters a new
-    // voxel column; the emit phase pops 64 of them and does update_tsdf.cu:81-125 with every lane busy
-    u32x4 *queue = s_queue + wave * TAIL_QCAP;
-    uint32_t qhead = 0, qtail = 0;
-    const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
-    const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
-    AxisRun ix0, iy0, iz0;
-    ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
-    ix0.gap = 0x3fffffff;
-    iy0 = ix0;
-    iz0 = ix0;
-    int32_t k = k0; // the next sample of this lane
-    if (work)
-    {
-      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-      run_init(ix0, f, r, r.dx, f.posx, kinit, true);
-      run_init(iy0, f, r, r.dy, f.posy, kinit, true);
-      run_init(iz0, f, r, r.dz, f.posz, kinit, false);
-    }
-    // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
-    AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
-    auto push = [&](bool cand, bool cx, bool cy) {
-      const unsigned long long mask = __ballot(cand);
-      if (mask == 0) return;
-      if (cand)
-      {
-        u32x4 e;
-        e.x = (uint32_t)fast_proj(wx, cx, res);
-        e.y = (uint32_t)fast_proj(wy, cy, res);
-        e.z = (uint32_t)fast_proj(wz, false, res);
-        e.w = (uint32_t)k | ((uint32_t)lane << 16);
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
-      }
-      qtail += (uint32_t)__popcll(mask);
-    };
-    {
-      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk starts: out
-      // of the loop, so that every iteration is "step, then test"
-      bool first = false;
-      if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
-      push(first, false, false);
-      if (work && k0 == 0) k = 1;
-    }
-    int32_t todo = work ? k1 - k : 0;
-    for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
-    const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
-    for (int32_t it = 0;; ++it)
-    {
-      const bool any_alive = it < n_iter;
-      if (any_alive)
-      {
-        // ---- sample phase
-        const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
-        fast_step_z(wz);
-        push((cx || cy) && k < k1, cx, cy);
-        k += 1;
-      }
-      // ---- emit phase: 64 queued samples, one per lane
-      const uint32_t cnt = qtail - qhead;
-      if (cnt >= 64 || (!any_alive && cnt > 0))
-      {
-        const uint32_t n = cnt < 64 ? cnt : 64;
-        u32x4 e = {0, 0, 0, 0};
-        const bool has = (uint32_t)lane < n;
-        if (has) e = queue[(qhead + (uint32_t)lane) & (TAIL_QCAP - 1)];
-        qhead += n;
-        // constants of the ray the sample belongs to (a lane of this wave)
-        const int src = (int)(e.w >> 16);
-        const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
-        const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
-        const int32_t s_dist = __shfl(r.distance, src, 64);
-        const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
-        if (has)
-        {
-          const int32_t ek = (int32_t)(e.w & 0xffffu);
-          const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
-          const int32_t len = 1 + ek * half;
-          // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
-          const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
-                        ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
-          int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
-          value = value < tau ? value : tau;
-          if (len > s_dist) value = -value;
-          if (!tsdf_weight_is_zero(value, tau, f.weight_epsilon))
-          {
-            // update_tsdf.cu:101-125
-            const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
-            int32_t iter_steps = 1, mid = 0;
-            if (delta_z * 2 >= res)
-            {
-              iter_steps = (int32_t)(__umulhi((uint32_t)(delta_z * 2), f.rM32) >> f.rS) + 1;
-              mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
-            }
-            const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
-                          lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
-            for (int32_t step = 0; step < iter_steps; ++step)
-            {
-              const int32_t sm = step * res;
-              const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
-                            vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
-              put_record(s_ix, ek, step, vx, vy, vz, value, step == mid);
-            }
-          }
-        }
-      }
-      if (!any_alive && qtail == qhead) break;
-    }
-  }
-  __syncthreads();
-#ifdef WS_TAIL_TIMING
-  const long long tt2 = wall_clock64();
-  if (threadIdx.x == 0)
-  {
-    a.tail_stats[16384 + item] = (uint32_t)tt0;
-    a.tail_stats[32768 + item] = (uint32_t)tt2;
-    a.tail_stats[49152 + item] = (uint32_t)tt2;
-  }
-#endif
-  const uint32_t total = min(s_cursor, ub_total);
-  if (threadIdx.x == 0) a.tail_stats[item] = total;
-  if (total == 0) return;
-
-  // ---- phase 2: sort the slice by tile (counting sort over an LDS hash of the tiles this workgroup touched) and
-  // publish one run per tile.  If more tiles are touched than the hash holds, the rest is binned in further rounds.
-  uint32_t round_base = 0;
-  for (int round = 0;; ++round)
-  {
-    if (round > 0)
-    {
-      // records the table of the previous round had no room for
-      for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
-      {
-        ht_key[i] = HT_EMPTY;
-        ht_cnt[i] = 0;
-      }
-      __syncthreads();
-      for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 1024)
-      {
-        uint32_t tile[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-          const uint32_t i = i0 + (uint32_t)u * 256u;
-          tile[u] = i < total ? a.rec_raw[base + i].tile : REC_DONE;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-        {
-          if (tile[u] == REC_DONE) continue;
-          const int s = ht_insert(ht_key, tile[u]);
-          if (s < 0)
-            s_overflow = 1;
-          else
-            atomicAdd(&ht_cnt[s], 1u);
-        }
-      }
-      __syncthreads();
-    }
-    // exclusive scan over the slots: records (low word) and runs (high word) together
-    uint32_t c[4];
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-    {
-      c[j] = ht_cnt[threadIdx.x * 4 + j];
-      mine += (unsigned long long)c[j] + (c[j] ? (1ull << 32) : 0ull);
-    }
-    unsigned long long incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      const unsigned long long y = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += y;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long excl = incl - mine;
-    for (int w = 0; w < wave; ++w) excl += s_wave[w];
-    if (threadIdx.x == 255)
-    {
-      const unsigned long long all = excl + mine;
-      const uint32_t runs = (uint32_t)(all >> 32);
-      s_round_total = (uint32_t)all;
-      uint32_t db = 0xffffffffu;
-      if (runs)
-      {
-        const uint32_t b = atomicAdd(&a.counters->desc_cursor, runs);
-        if (b <= a.desc_cap && runs <= a.desc_cap - b) db = b;
-        if (db == 0xffffffffu) raise_error(a.counters, a.status, ERR_CAPACITY);
-      }
-      s_desc_base = db;
-    }
-    __syncthreads();
-    const uint32_t desc_base = s_desc_base;
-    {
-      uint32_t off = (uint32_t)excl, rank = (uint32_t)(excl >> 32);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-      {
-        const int s = threadIdx.x * 4 + j;
-        ht_cur[s] = off;
-        if (c[j])
-        {
-          if (desc_base != 0xffffffffu)
-          {
-            RunDesc d;
-            d.tile = ht_key[s];
-            d.count = c[j];
-            d.start = base + round_base + off;
-            d.pad = 0;
-            a.desc[desc_base + rank] = d;
-            atomicAdd(&a.tile_nruns[d.tile], 1u);
-          }
-          rank += 1;
-          off += c[j];
-        }
-      }
-    }
-    __syncthreads();
-    const bool more = s_overflow != 0;
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 256u * SORT_U)
-    {
-      u32x4 rec[SORT_U];
-#pragma unroll
-      for (int u = 0; u < SORT_U; ++u)
-      {
-        // unconditional (clamped) loads, SORT_U in flight; a load under a branch would be waited for on the spot
-        const uint32_t i = i0 + (uint32_t)u * 256u;
-        rec[u] = *reinterpret_cast<const u32x4 *>(&a.rec_raw[base + (i < total ? i : total - 1)]);
-        if (i >= total) rec[u].z = REC_DONE;
-      }
-#pragma unroll
-      for (int u = 0; u < SORT_U; ++u)
-      {
-        if (rec[u].z == REC_DONE) continue;
-        // round 0: the slot was found when the record was written; later rounds look the tile up again
-        int s = (int)(rec[u].w >> 10);
-        if (round > 0)
-          s = ht_find(ht_key, rec[u].z);
-        else if (s >= HT_SLOTS)
-          s = -1;
-        if (s < 0) continue; // next round
-        const uint32_t p = atomicAdd(&ht_cur[s], 1u);
-        rec[u].w &= (uint32_t)(TILE_VOXELS - 1);
-        *reinterpret_cast<u32x4 *>(&a.rec_sorted[base + round_base + p]) = rec[u];
-        if (more) a.rec_raw[base + i0 + (uint32_t)u * 256u].tile = REC_DONE;
-      }
-    }
-    __syncthreads();
-    if (!more) break;
-    round_base += s_round_total;
-    __syncthreads();
-    if (threadIdx.x == 0) s_overflow = 0;
-  }
-#ifdef WS_TAIL_TIMING
-  if (threadIdx.x == 0) a.tail_stats[49152 + item] = (uint32_t)wall_clock64();
-#endif
-}
-
-// Persistent workgroups (as many as the chip holds at once) that take work items from a counter: a launch of one workgroup
-// per item spent a third of its time ramping up and draining (tools/tail_schedule.py: 4096 workgroups of 48 us each over 1536
-// slots finished after 190 us, the sum of their durations over the slots is 127 us) -- items differ by 10x in work.
-__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
-{
-#if WS_TAIL_PERSISTENT
-  __shared__ uint32_t s_item;
-#endif
-  // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
-  const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
-  // The whole update is enqueued before the host has seen the record bound of this scan (below: launch_tsdf_scatter).  If the
-  // scan does not fit the record buffers, NOTHING of it may happen: the tail march and the free pass leave at once (no byte
-  // of the map's state is touched, the later kernels find nothing to do), and the host grows the buffers and runs it again.
-  if (scan_fits(a) == false) return;
-#if WS_TAIL_PERSISTENT
-  for (;;)
-  {
-    if (threadIdx.x == 0) s_item = atomicAdd(&a.counters->tail_next, 1u);
-    __syncthreads();
-    const uint32_t item = s_item;
-    if (item >= n_items) break;
-    tail_item(a, item);
-    __syncthreads(); // everybody is done with the item's LDS state (and has read s_item)
-  }
-#else
-  if (blockIdx.x < n_items) tail_item(a, blockIdx.x);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// free space
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fk_hash(unsigned long long idx, int32_t shift) { return (uint32_t)((idx * 0x9E3779B97F4A7C15ull) >> shift); }
-
-// What a free-space candidate does to its voxel, in two halves: the byte of the voxel is REQUESTED when the candidate is
-// popped from the queue and USED one emit phase later.  The free pass is not bound by instruction issue alone: shortening
-// the sample phase from ~115 to ~60 instructions moved it from 137 to 126 us, taking this load's round trip off the wave's
-// path to 122 us; what remains is the scattered byte traffic itself (21 M byte loads, 9 M byte stores, one cache line each).
-struct FreePending
-{
-  int64_t idx;   // voxel (storage index)
-  uint32_t tile;
-  uint32_t ix;   // ray
-  int32_t k;     // ray step
-  uint32_t b;    // the voxel's byte (in flight until the next emit phase)
-  bool valid;
-};
-__device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFrame &f, FreePending &p, bool valid, uint32_t ix, int32_t k, int32_t vx, int32_t vy,
-                                             int32_t vz)
-{
-  const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
-                sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-  p.valid = valid;
-  p.idx = valid ? storage_index(a.map, sx, sy, sz) : 0; // unconditional (clamped) load: nothing waits for it here
-  p.tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-  p.ix = ix;
-  p.k = k;
-  p.b = a.vstate[p.idx];
-}
-__device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p)
-{
-  if (!p.valid) return;
-  const int64_t idx = p.idx;
-  const uint32_t b = p.b;
-  if (b & VOX_KEYED)
-  {
-    // the voxel also has ordered candidates (from the tails): this one takes part in the key order.  Only the
-    // earliest free-space candidate of a voxel can matter (a later one meets a state that is at least as final).
-    if (!(b & VOX_FREEHIT)) a.vstate[idx] = VOX_KEYED | VOX_FREEHIT;
-    const unsigned long long t = order_key(p.ix, p.k, 0);
-    uint32_t h = fk_hash((unsigned long long)idx, a.fk_shift);
-    bool done = false;
-    for (int q = 0; q < 128 && !done; ++q)
-    {
-      const unsigned long long cur = a.fk_keys[h];
-      unsigned long long old = cur;
-      if (cur == KEY_INF) old = atomicCAS(&a.fk_keys[h], KEY_INF, (unsigned long long)idx);
-      if (old == KEY_INF) // claimed: one bit per slot behind the hash tells the next scan's set-up where to clean
-        atomicOr(&reinterpret_cast<uint32_t *>(a.fk_keys + 2 * ((size_t)a.fk_mask + 1))[h >> 5], 1u << (h & 31u));
-      if (old == KEY_INF || old == (unsigned long long)idx)
-      {
-        atomicMin(&a.fk_keys[(size_t)a.fk_mask + 1 + h], t);
-        done = true;
-      }
-      h = (h + 1) & a.fk_mask;
-    }
-    if (!done) raise_error(a.counters, a.status, ERR_CAPACITY);
-  }
-  else if (b == 0)
-  {
-    // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
-    // whose loads both saw 0 both store: idempotent.)
-    a.vstate[idx] = VOX_TOUCHED;
-    // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured)
-    if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
-  }
-}
-// both halves at once (general walk)
-__device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz)
-{
-  FreePending p;
-  free_request(a, f, p, true, ix, k, vx, vy, vz);
-  free_finish(a, p);
-}
-
-constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
-#ifndef WS_FREE_LANES
-#define WS_FREE_LANES 4
-#endif
-constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space part of one ray
-
-// 64 rays per workgroup, 4 lanes per ray (round 2 walk: 32 lanes 163 us, 16: 146, 8: 141, 4: 147, 1: 280; round 3 walk: 8: 123, 4: 120, 2: 131): lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
-// so every lane has the same amount of work whatever the ray length.  Waves whose rays are all RAY_SIMPLE use the
-// compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
-__global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
-{
-  if (scan_fits(a) == false) return; // see march_tail_kernel
-  __shared__ u32x4 s_queue[4 * FREE_QCAP];
-  const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
-  const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
-  const int lane = threadIdx.x & 63;
-  RaySetup r;
-  r.steps = 0;
-  r.kfirst = 0;
-  r.pad = 0;
-  if (ix < a.n) r = a.rays[ix];
-  const int32_t kend = min(r.steps, r.kfirst);
-  const int32_t ch = (kend + FREE_LANES - 1) / FREE_LANES;
-  const int32_t k0 = c * ch;
-  const int32_t k1 = min(k0 + ch, kend);
-  const bool work = k0 < k1;
-  const int32_t tau = a.tau;
-  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
-  if (!__all(!work || (r.pad & RAY_SIMPLE)))
-  {
-    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
-    if (!work) return;
-    march_steps<true>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-      // every candidate of these steps is free space: on the ray, further than tau from the hit point
-      if (!(positive && value == tau))
-      {
-        raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
-        return;
-      }
-      free_emit(a, f, ix, k, vx, vy, vz);
-    });
-    return;
-  }
-  if (!__any(work)) return;
-
-  // wave-private ring buffer: LDS operations of one wave are performed in order, so no barrier between push and pop
-  u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
-  uint32_t qhead = 0, qtail = 0;
-  const int32_t res = f.res, half = f.half, dist = r.distance;
-  // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
-  // previous emit phase, then pop the next batch and request its bytes
-  FreePending pend;
-  pend.valid = false;
-  pend.idx = 0;
-  pend.tile = pend.ix = pend.b = 0;
-  pend.k = 0;
-  auto emit = [&]() {
-#if WS_FREE_PIPE
-    free_finish(a, pend);
-#endif
-    const uint32_t cnt = qtail - qhead;
-    const uint32_t n = cnt < 64 ? cnt : 64;
-    u32x4 e = {0, 0, 0, 0};
-    const bool has = (uint32_t)lane < n;
-    if (has) e = queue[(qhead + (uint32_t)lane) & (FREE_QCAP - 1)];
-    const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
-    free_request(a, f, pend, has, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
-#if !WS_FREE_PIPE
-    free_finish(a, pend);
-    pend.valid = false;
-#endif
-    qhead += n;
-  };
-  AxisRun ix0, iy0, iz0;
-  ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
-  ix0.gap = 0x3fffffff;
-  iy0 = ix0;
-  iz0 = ix0;
-  int32_t k = k0; // the next sample of this lane
-  if (work)
-  {
-    const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-    run_init(ix0, f, r, r.dx, f.posx, kinit, true);
-    run_init(iy0, f, r, r.dy, f.posy, kinit, true);
-    run_init(iz0, f, r, r.dz, f.posz, kinit, false);
-  }
-  AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
-  int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
-  // target of the single on-ray candidate of a free-space sample (update_tsdf.cu:103-112 with iter_steps == 1): the sample
-  // minus the fan base offset, which changes every 328 mm of ray
-  auto push = [&](bool cand, bool cx, bool cy, int32_t dzl) {
-    const unsigned long long mask = __ballot(cand);
-    if (mask == 0) return;
-    if (cand)
-    {
-      const int32_t px = fast_proj(wx, cx, res), py = fast_proj(wy, cy, res), pz = fast_proj(wz, false, res);
-      const int32_t delta_z = dzl >> 15; // (DZ_PER_DISTANCE * len) >> 15, len > 0; no fan in the free-space part: delta_z * 2 < res
-      if (delta_z != last_dz)
-      {
-        last_dz = delta_z;
-        c0x = trunc_shift15(delta_z * r.ivx);
-        c0y = trunc_shift15(delta_z * r.ivy);
-        c0z = trunc_shift15(delta_z * r.ivz);
-      }
-      u32x4 e;
-      e.x = (uint32_t)(px - c0x);
-      e.y = (uint32_t)(py - c0y);
-      e.z = (uint32_t)(pz - c0z);
-      e.w = (uint32_t)k | ((uint32_t)lane << 16);
-      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      queue[(qtail + rank) & (FREE_QCAP - 1)] = e;
-    }
-    qtail += (uint32_t)__popcll(mask);
-  };
-  // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk was initialised:
-  // taken out of the loop, so that every iteration below is "step, then test"
-  {
-    bool first = false;
-    if (work && k0 == 0)
-    {
-      const int32_t px = fast_proj(wx, false, res), py = fast_proj(wy, false, res);
-      first = div_trunc(px, f.rM, f.rK, res) != 0 || div_trunc(py, f.rM, f.rK, res) != 0;
-    }
-    push(first, false, false, DZ_PER_DISTANCE); // len == 1
-    if (work && k0 == 0) k = 1;
-  }
-  // iterations of the wave: the longest lane (uniform: the loop itself is scalar)
-  int32_t todo = work ? k1 - k : 0;
-  for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
-  const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
-  int32_t dzl = DZ_PER_DISTANCE * (1 + k * half); // DZ_PER_DISTANCE * len of the sample k, carried (no multiply per sample)
-  const int32_t dzl_step = DZ_PER_DISTANCE * half;
-  for (int32_t it = 0; it < n_iter; ++it)
-  {
-    // ---- sample phase: every lane steps (lanes that are through keep stepping; their samples are masked)
-    const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
-    fast_step_z(wz);
-    const bool cand = (cx || cy) && k < k1;
-    push(cand, cx, cy, dzl);
-    k += 1;
-    dzl += dzl_step;
-    // ---- emit phase
-    if (qtail - qhead >= 64) emit();
-  }
-  while (qtail != qhead) emit();
-  free_finish(a, pend);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// runs per tile -> descriptor ranges, list of touched tiles
-// ---------------------------------------------------------------------------------------------------------
-constexpr int SCAN_TILES_PER_THREAD = 16;
-constexpr int SCAN_TILES_PER_BLOCK = 256 * SCAN_TILES_PER_THREAD;
-uint32_t tile_scan_blocks(int64_t n_tiles) { return (uint32_t)((n_tiles + SCAN_TILES_PER_BLOCK - 1) / SCAN_TILES_PER_BLOCK); }
-
-struct TileScanArgs
-{
-  uint32_t *tile_nruns;
-  uint32_t *tile_begin;
-  uint8_t *tile_dirty;
-  TileEntry *tile_list;
-  uint32_t *block_sums; // [blocks][2] (runs, listed), then [blocks][2] their exclusive scan
-  uint32_t n_blocks;
-  int64_t n_tiles;
-  int32_t nty, ntz;
-  TsdfCounters *counters;
-  // run descriptors as the tail march wrote them -> grouped by tile (placement blocks of tile_scan_kernel / desc_place_kernel)
-  const RunDesc *desc;
-  uint32_t desc_cap;
-  uint32_t *sorted_desc;
-};
 
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
 {
@@ -1214,303 +719,609 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return excl;
 }
 
-__global__ __launch_bounds__(256) void tile_count_kernel(TileScanArgs a)
+struct TailShared
 {
-  __shared__ unsigned long long wave_sums[4];
-  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
-  unsigned long long mine = 0; // runs in the low word, listed tiles in the high word
-  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-  {
-    const int64_t t = t0 + j;
-    if (t >= a.n_tiles) break;
-    const uint32_t nr = a.tile_nruns[t];
-    mine += nr;
-    if (nr || a.tile_dirty[t]) mine += 1ull << 32;
-  }
-  unsigned long long total;
-  block_scan_u64(mine, wave_sums, total);
-  if (threadIdx.x == 0)
-  {
-    a.block_sums[2 * blockIdx.x + 0] = (uint32_t)total;
-    a.block_sums[2 * blockIdx.x + 1] = (uint32_t)(total >> 32);
-  }
-}
+  unsigned long long rec[TAIL_STAGE];
+  uint16_t slot[TAIL_STAGE]; // slot of the record's tile in the table below (SLOT_NONE: the record went straight to its tile)
+  uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c0[HT_SLOTS], ht_c1[HT_SLOTS];
+  unsigned long long wave_sums[4];
+  unsigned long long alloc;
+  uint32_t cursor, done, n_records, n_groups;
+};
 
-__global__ __launch_bounds__(1024) void tile_blockscan_kernel(TileScanArgs a)
+// The staged records go to their tiles: thread t owns slot t of the tile table.  One reservation per tile (its count is
+// known), ONE request to the shared chunk / list counter per workgroup, then every record is copied to
+// chunk(position >> 8)[position & 255].  total: staged records (uniform).
+__device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
 {
-  __shared__ unsigned long long wave_sums[16];
-  uint32_t *out = a.block_sums + 2 * (size_t)a.n_blocks;
-  unsigned long long carry = 0;
-  for (uint32_t b0 = 0; b0 < a.n_blocks; b0 += 1024)
+  const int t = threadIdx.x;
+  const uint32_t c = sh.ht_cnt[t], tile = sh.ht_key[t];
+  Reserve r;
+  r.p0 = r.j_new = r.n_new = 0;
+  r.first = false;
+  if (c) r = tile_reserve(a, tile, c);
+  unsigned long long all = 0;
+  const unsigned long long mine = (unsigned long long)r.n_new | ((unsigned long long)(r.first ? 1u : 0u) << 32);
+  const unsigned long long excl = block_scan_u64(mine, sh.wave_sums, all);
+  if (t == 0)
   {
-    const uint32_t b = b0 + threadIdx.x;
-    unsigned long long mine = 0;
-    if (b < a.n_blocks) mine = (unsigned long long)a.block_sums[2 * b] | ((unsigned long long)a.block_sums[2 * b + 1] << 32);
-    unsigned long long total;
-    const unsigned long long excl = block_scan_u64(mine, wave_sums, total) + carry;
-    if (b < a.n_blocks)
+    sh.alloc = all ? alloc_add(a, all) : 0ull;
+    sh.n_records += total;
+  }
+  __syncthreads();
+  const unsigned long long got = sh.alloc + excl;
+  const uint32_t cid = (uint32_t)got;
+  if (c)
+  {
+    if (r.first) list_tile(a, (uint32_t)(got >> 32), tile);
+    for (uint32_t q = 0; q < r.n_new; ++q) chunk_publish(a, tile, r.j_new + q, chunk_id1(a, cid + q));
+  }
+  asm volatile("" ::: "memory"); // everything this wave opens is published before any of its lanes polls
+  if (c)
+  {
+    const bool aligned = (r.p0 & (uint32_t)(CHUNK_RECS - 1)) == 0;
+    uint32_t c0, c1 = CHUNK_NONE;
+    if (aligned)
     {
-      out[2 * b + 0] = (uint32_t)excl;
-      out[2 * b + 1] = (uint32_t)(excl >> 32);
+      c0 = chunk_id1(a, cid);
+      if (r.n_new >= 2) c1 = chunk_id1(a, cid + 1u);
     }
-    carry += total;
+    else
+    {
+      c0 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
+      if (r.n_new >= 1) c1 = chunk_id1(a, cid);
+    }
+    sh.ht_base[t] = r.p0;
+    sh.ht_c0[t] = c0;
+    sh.ht_c1[t] = c1;
+    sh.ht_cnt[t] = 0; // now the slot's copy cursor
+    atomicAdd(&sh.n_groups, 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = (uint32_t)t; i < total; i += 256u)
+  {
+    const uint32_t slot = sh.slot[i];
+    if (slot == SLOT_NONE) continue;
+    const unsigned long long rec = sh.rec[i];
+    const uint32_t base = sh.ht_base[slot];
+    const uint32_t q = base + atomicAdd(&sh.ht_cnt[slot], 1u);
+    const uint32_t jrel = (q >> CHUNK_BITS) - (base >> CHUNK_BITS);
+    // (a group of more than two chunks -- one tile took most of the staging area -- finds the others through the tile's table;
+    // this workgroup published them above)
+    const uint32_t id1 = jrel == 0 ? sh.ht_c0[slot] : (jrel == 1 ? sh.ht_c1[slot] : chunk_lookup(a, sh.ht_key[slot], q >> CHUNK_BITS));
+    store_rec(a, id1, q, rec);
+  }
+  __syncthreads();
+  sh.ht_key[t] = HT_EMPTY;
+  sh.ht_cnt[t] = 0;
+  if (t == 0) sh.cursor = 0;
+  __syncthreads();
+}
+
+// one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
+// targets fall into the same vertical slab of space, i.e. into few tiles
+__device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
+{
+  __shared__ TailShared sh;
+  __shared__ u32x4 s_queue[4 * TAIL_QCAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n_sorted = a.az_off[AZ_BINS];
+  const uint32_t slot = (item / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
+  const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
+  const bool has_ray = slot < n_sorted;
+  uint32_t ix = 0;
+  RaySetup r;
+  r.steps = 0;
+  r.kfirst = 0;
+  r.ub = 0;
+  r.pad = 0;
+  if (has_ray)
+  {
+    ix = a.ray_order[slot];
+    r = a.rays[ix];
   }
   if (threadIdx.x == 0)
   {
-    a.counters->n_desc_sorted = (uint32_t)carry;
-    a.counters->n_listed = (uint32_t)(carry >> 32);
+    sh.cursor = 0;
+    sh.done = 0;
+    sh.n_records = 0;
+    sh.n_groups = 0;
   }
-}
+  sh.ht_key[threadIdx.x] = HT_EMPTY;
+  sh.ht_cnt[threadIdx.x] = 0;
+  __syncthreads();
 
-__global__ __launch_bounds__(256) void tile_list_kernel(TileScanArgs a)
-{
-  __shared__ unsigned long long wave_sums[4];
-  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
-  uint32_t nr[SCAN_TILES_PER_THREAD];
-  uint32_t listed = 0; // bit mask
-  unsigned long long mine = 0;
-#pragma unroll
-  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-  {
-    const int64_t t = t0 + j;
-    nr[j] = 0;
-    if (t < a.n_tiles)
+  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
+  const bool mark = !a.all_keyed;
+  uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
+  // a record into staging slot `pos` (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
+  auto stage_record = [&](uint32_t pos, uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
+    // the free-space pass must know that this voxel takes part in the key order
+    if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+    const unsigned long long rec = make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz));
+    // the workgroup's tile table is built on the fly; a full table sends the record straight to its tile
+    const int s = pos < (uint32_t)TAIL_STAGE ? ht_insert(sh.ht_key, tile) : -1;
+    if (s >= 0)
     {
-      nr[j] = a.tile_nruns[t];
-      const bool dirty = a.tile_dirty[t] != 0;
-      if (dirty) a.tile_dirty[t] = 0;
-      mine += nr[j];
-      if (nr[j] || dirty)
+      // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
+      atomicAdd(&sh.ht_cnt[s], 1u);
+      sh.rec[pos] = rec;
+      sh.slot[pos] = (uint16_t)s;
+    }
+    else
+    {
+      if (pos < (uint32_t)TAIL_STAGE) sh.slot[pos] = SLOT_NONE;
+      append_record(a, tile, rec);
+    }
+    return tile;
+  };
+  // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
+  auto mark_negative = [&](int32_t sx, int32_t sy, int32_t sz, uint32_t listed_tile) {
+    vneg[storage_index(a.map, sx, sy, sz)] = 1;
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+    if (tile != listed_tile) list_dirty_tile(a, tile);
+  };
+
+  int32_t k0 = 0, k1 = 0;
+  if (has_ray && r.steps > 0 && r.kfirst < r.steps)
+  {
+    const int32_t kbeg = r.kfirst, kend = r.steps;
+    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
+    k0 = min(kbeg + (part0 + wave) * ch, kend);
+    k1 = min(k0 + ch, kend);
+  }
+  const bool work = k0 < k1;
+  const bool general = !__all(!work || (r.pad & RAY_SIMPLE));
+
+  // ---- state of the compacting walk (ws_march.h): the sample phase queues (position, step, ray) of every sample that
+  // enters a new voxel column; the emit phase takes 64 of them and does update_tsdf.cu:81-125 with every lane busy
+  u32x4 *queue = s_queue + wave * TAIL_QCAP;
+  uint32_t qhead = 0, qtail = 0;
+  const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
+  const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
+  AxisRun ix0, iy0, iz0;
+  ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
+  ix0.gap = 0x3fffffff;
+  iy0 = ix0;
+  iz0 = ix0;
+  int32_t k = k0; // the next sample of this lane
+  if (work && !general)
+  {
+    const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+    run_init(ix0, f, r, r.dx, f.posx, kinit, true);
+    run_init(iy0, f, r, r.dy, f.posy, kinit, true);
+    run_init(iz0, f, r, r.dz, f.posz, kinit, false);
+  }
+  // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
+  AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
+  auto push = [&](bool cand, bool cx, bool cy) {
+    const unsigned long long mask = __ballot(cand);
+    if (mask == 0) return;
+    if (cand)
+    {
+      u32x4 e;
+      e.x = (uint32_t)fast_proj(wx, cx, res);
+      e.y = (uint32_t)fast_proj(wy, cy, res);
+      e.z = (uint32_t)fast_proj(wz, false, res);
+      e.w = (uint32_t)k | ((uint32_t)lane << 16);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
+    }
+    qtail += (uint32_t)__popcll(mask);
+  };
+  int32_t n_iter = 0, it = 0;
+  if (!general && __any(work))
+  {
+    // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk starts: out
+    // of the loop, so that every iteration is "step, then test"
+    bool first = false;
+    if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
+    push(first, false, false);
+    if (work && k0 == 0) k = 1;
+    int32_t todo = work ? k1 - k : 0;
+    for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
+    n_iter = __builtin_amdgcn_readfirstlane(todo);
+  }
+
+  // emit phase: up to 64 queued samples, one per lane.  false: the staging area cannot take their records before the next
+  // flush (nothing has been consumed: the same call is repeated afterwards)
+  auto emit_batch = [&]() -> bool {
+    const uint32_t cnt = qtail - qhead;
+    const uint32_t n = cnt < 64 ? cnt : 64;
+    u32x4 e = {0, 0, 0, 0};
+    const bool has = (uint32_t)lane < n;
+    if (has) e = queue[(qhead + (uint32_t)lane) & (TAIL_QCAP - 1)];
+    // constants of the ray the sample belongs to (a lane of this wave)
+    const int src = (int)(e.w >> 16);
+    const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
+    const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
+    const int32_t s_dist = __shfl(r.distance, src, 64);
+    const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
+    const int32_t ek = (int32_t)(e.w & 0xffffu);
+    const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
+    const int32_t len = 1 + ek * half;
+    // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
+    const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
+                  ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
+    int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
+    value = value < tau ? value : tau;
+    if (len > s_dist) value = -value;
+    // update_tsdf.cu:101-105
+    const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
+    int32_t iter_steps = 0, mid = 0;
+    if (has && !tsdf_weight_is_zero(value, tau, f.weight_epsilon))
+    {
+      iter_steps = 1;
+      if (delta_z * 2 >= res)
       {
-        mine += 1ull << 32;
-        listed |= 1u << j;
+        iter_steps = (int32_t)(__umulhi((uint32_t)(delta_z * 2), f.rM32) >> f.rS) + 1;
+        mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
       }
     }
-  }
-  unsigned long long total;
-  unsigned long long excl = block_scan_u64(mine, wave_sums, total);
-  const uint32_t *boff = a.block_sums + 2 * (size_t)a.n_blocks;
-  uint32_t run_off = (uint32_t)excl + boff[2 * blockIdx.x + 0];
-  uint32_t list_off = (uint32_t)(excl >> 32) + boff[2 * blockIdx.x + 1];
-#pragma unroll
-  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-  {
-    if (!(listed & (1u << j))) continue;
-    const int64_t t = t0 + j;
-    if (nr[j]) a.tile_begin[t] = run_off;
-    TileEntry e;
-    e.tile = (uint32_t)t;
-    e.desc_begin = run_off;
-    e.nruns = nr[j];
-    e.tz = (int32_t)((uint32_t)t % (uint32_t)a.ntz);
-    e.ty = (int32_t)(((uint32_t)t / (uint32_t)a.ntz) % (uint32_t)a.nty);
-    e.tx = (int32_t)((uint32_t)t / ((uint32_t)a.ntz * (uint32_t)a.nty));
-    e.pad[0] = e.pad[1] = 0;
-    a.tile_list[list_off] = e;
-    run_off += nr[j];
-    list_off += 1;
-  }
-}
-
-// The three kernels above as ONE launch for maps whose scan fits the chip (every workgroup resident: no workgroup waits for
-// one that has not started): each workgroup publishes the (runs, listed) total of its 4096 tiles in a single 64-bit word
-// — status in the top two bits, so value and flag cannot be seen apart — and looks back over its predecessors' words
-// (aggregate or inclusive prefix) for its own exclusive prefix.  `look` is zero at the start of a scan (prep).
-constexpr unsigned long long LOOK_AGG = 1ull << 62, LOOK_INCL = 2ull << 62, LOOK_MASK = 3ull << 62;
-constexpr uint32_t LOOKBACK_MAX_BLOCKS = 2048;
-__device__ __forceinline__ unsigned long long look_pack(unsigned long long v) { return (v & 0x7fffffffull) | ((v >> 32) << 31); } // runs(31) | listed(31)
-__device__ __forceinline__ unsigned long long look_unpack(unsigned long long w) { return (w & 0x7fffffffull) | (((w >> 31) & 0x7fffffffull) << 32); }
-
-// run descriptors grouped by tile: the tile's counter of runs doubles as its placement cursor (and ends at zero).
-// COHERENT: called by the placement blocks of tile_scan_kernel, which read what scan blocks of the same launch wrote.
-template <bool COHERENT>
-__device__ __forceinline__ void place_descriptors(const TileScanArgs &a, uint32_t first_block, uint32_t n_blocks)
-{
-  // n_desc_sorted = sum of tile_nruns = descriptors actually written: they are the first n of the array (a reservation
-  // that did not fit wrote nothing and counted nothing, and every later one failed too)
-  uint32_t n = COHERENT ? __hip_atomic_load(&a.counters->n_desc_sorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.counters->n_desc_sorted;
-  if (n > a.desc_cap) n = a.desc_cap;
-  // four descriptors per thread and pass, every step issued for all four before the next step uses any of them (loads,
-  // then the returning atomics and the coherent loads, then the stores): three round trips per pass instead of per descriptor
-  constexpr int PU = 4;
-  const uint32_t stride = n_blocks * 256u;
-  for (uint32_t i0 = (blockIdx.x - first_block) * 256u + threadIdx.x; i0 < n; i0 += stride * PU)
-  {
-    RunDesc d[PU];
-    uint32_t old[PU], begin[PU];
-#pragma unroll
-    for (int u = 0; u < PU; ++u)
+    // the off-ray targets of a sample of value +tau are marks, not records
+    const bool blind = mark && value == tau;
+    const uint32_t nrec = iter_steps == 0 ? 0u : (blind ? 1u : (uint32_t)iter_steps);
+    const uint32_t incl = wave_incl_scan(nrec);
+    const uint32_t batch = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t base = 0;
+    if (batch)
     {
-      const uint32_t i = i0 + (uint32_t)u * stride;
-      d[u] = a.desc[i < n ? i : n - 1u];
+      if (lane == 0) base = stage_reserve(&sh.cursor, batch);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (base == 0xffffffffu) return false;
     }
-#pragma unroll
-    for (int u = 0; u < PU; ++u)
+    qhead += n;
+    if (batch == 0) return true;
+    uint32_t pos = base + incl - nrec;
+    const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
+                  lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
+    auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
+      const int32_t sm = step * res;
+      const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
+                    vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
+      sx = ring_fast(vx, f.ringK[0], a.map.size[0]);
+      sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
+      sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+    };
+    // the on-ray target (fan step `mid`) first: always a record, and its tile is on the list through it
+    uint32_t mid_tile = 0xffffffffu;
+    if (iter_steps > 0)
     {
-      const uint32_t i = i0 + (uint32_t)u * stride;
-      old[u] = i < n ? atomicSub(&a.tile_nruns[d[u].tile], 1u) : 0u;
-      begin[u] = COHERENT ? __hip_atomic_load(&a.tile_begin[d[u].tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.tile_begin[d[u].tile];
+      int32_t sx, sy, sz;
+      target(mid, sx, sy, sz);
+      mid_tile = stage_record(pos, s_ix, ek, 0, value, sx, sy, sz);
+      pos += 1;
     }
-#pragma unroll
-    for (int u = 0; u < PU; ++u)
+    // the off-ray targets (update_tsdf.cu:107-125)
+    int32_t widest = iter_steps;
+    for (int d = 32; d > 0; d >>= 1) widest = max(widest, __shfl_xor(widest, d, 64));
+    widest = __builtin_amdgcn_readfirstlane(widest);
+    for (int32_t step = 0; step < widest; ++step)
     {
-      const uint32_t i = i0 + (uint32_t)u * stride;
-      if (i >= n) continue;
-      const uint32_t pos = begin[u] + old[u] - 1u;
-      *reinterpret_cast<uint2 *>(&a.sorted_desc[2 * (size_t)pos]) = make_uint2(d[u].start, d[u].count);
+      if (step < iter_steps && step != mid)
+      {
+        int32_t sx, sy, sz;
+        target(step, sx, sy, sz);
+        if (blind)
+          mark_negative(sx, sy, sz, mid_tile);
+        else
+        {
+          stage_record(pos, s_ix, ek, step - mid, value, sx, sy, sz);
+          pos += 1;
+        }
+      }
     }
-  }
-}
+    return true;
+  };
 
-// Blocks [0, n_scan_blocks): the scan.  Blocks behind them: the placement of the run descriptors, which needs every tile's
-// range -- they wait for the scan blocks' arrival count (in-order dispatch: a placement block is only on the chip when every
-// scan block is there or done), instead of a launch of their own.
-__global__ __launch_bounds__(256) void tile_scan_kernel(TileScanArgs a, unsigned long long *look, uint32_t n_scan_blocks)
-{
-  __shared__ unsigned long long wave_sums[4];
-  __shared__ unsigned long long s_prefix;
-  if (blockIdx.x >= n_scan_blocks)
+  // The waves of the workgroup walk on their own and meet whenever one of them cannot stage its next records (and at the
+  // end): all four flush together, then go on.  A wave that has finished keeps joining the flushes of the others.
+  bool finished = false;
+  for (;;)
   {
-    if (threadIdx.x == 0)
-      while (__hip_atomic_load(&a.counters->scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_scan_blocks) __builtin_amdgcn_s_sleep(8);
+    if (!finished)
+    {
+      if (general)
+      {
+        // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record
+        // (when the staging area is full its records go straight to their tiles)
+        if (work)
+          march_steps<false>(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+            const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
+                          sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+            if (mark && !positive && value == tau)
+            {
+              mark_negative(sx, sy, sz, 0xffffffffu);
+              return;
+            }
+            // fan step - mid: update_tsdf.cu:103-104 (`positive` == the on-ray step)
+            const int32_t delta_z = wmul(DZ_PER_DISTANCE, 1 + kk * half) / MATRIX_RESOLUTION;
+            const int32_t fm = step - delta_z / res;
+            const unsigned long long active = __ballot(1);
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)active) - 1;
+            if (lane == leader) base = stage_reserve(&sh.cursor, (uint32_t)__popcll(active));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            const uint32_t pos = base == 0xffffffffu ? 0xffffffffu : base + (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
+            stage_record(pos, ix, kk, fm, value, sx, sy, sz);
+          });
+        finished = true;
+      }
+      else
+      {
+        for (;;)
+        {
+          const uint32_t cnt = qtail - qhead;
+          const bool alive = it < n_iter;
+          if (cnt >= 64 || (!alive && cnt > 0))
+          {
+            if (!emit_batch()) break; // flush first
+            continue;
+          }
+          if (!alive)
+          {
+            finished = true;
+            break;
+          }
+          // ---- sample phase
+          const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
+          fast_step_z(wz);
+          push((cx || cy) && k < k1, cx, cy);
+          k += 1;
+          it += 1;
+        }
+      }
+      if (finished && lane == 0) atomicAdd(&sh.done, 1u);
+    }
     __syncthreads();
-    place_descriptors<true>(a, n_scan_blocks, gridDim.x - n_scan_blocks);
-    return;
+    const uint32_t total = sh.cursor;
+    const bool all_done = sh.done == 4u;
+    if (total)
+      tail_flush(a, sh, total);
+    else
+      __syncthreads(); // (tail_flush ends with a barrier behind its last reads of the shared state; keep the waves together here too)
+    if (all_done) break;
   }
-  const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILES_PER_BLOCK + (int64_t)threadIdx.x * SCAN_TILES_PER_THREAD;
-  uint32_t nr[SCAN_TILES_PER_THREAD];
-  uint32_t listed = 0; // bit mask
-  unsigned long long mine = 0;
-  static_assert(SCAN_TILES_PER_THREAD == 16, "a thread's tiles are four 128-bit loads of counters and one of dirty bytes");
-  uint32_t dirty_bits = 0;
-  if (t0 + SCAN_TILES_PER_THREAD <= a.n_tiles)
+  if (threadIdx.x == 0)
   {
-    // five 128-bit loads issued together, then one store: tile by tile (load, load, conditional store, ...) the in-order
-    // memory counter made sixteen dependent round trips out of this
-    u32x4 c[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c[q] = *reinterpret_cast<const u32x4 *>(&a.tile_nruns[t0 + 4 * q]);
-    const u32x4 d = *reinterpret_cast<const u32x4 *>(&a.tile_dirty[t0]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-    {
-      nr[4 * q + 0] = c[q].x;
-      nr[4 * q + 1] = c[q].y;
-      nr[4 * q + 2] = c[q].z;
-      nr[4 * q + 3] = c[q].w;
-    }
-    const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dirty_bits |= ((dw[j >> 2] >> (8 * (j & 3))) & 0xffu) ? (1u << j) : 0u;
-    if (dirty_bits)
-    {
-      const u32x4 z = {0, 0, 0, 0};
-      *reinterpret_cast<u32x4 *>(&a.tile_dirty[t0]) = z;
-    }
+    a.tail_stats[item] = sh.n_records;
+    a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
   }
-  else
-  {
-#pragma unroll
-    for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-    {
-      const int64_t t = t0 + j;
-      nr[j] = 0;
-      if (t < a.n_tiles)
-      {
-        nr[j] = a.tile_nruns[t];
-        if (a.tile_dirty[t] != 0)
-        {
-          a.tile_dirty[t] = 0;
-          dirty_bits |= 1u << j;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-  {
-    mine += nr[j];
-    if (nr[j] || (dirty_bits & (1u << j)))
-    {
-      mine += 1ull << 32;
-      listed |= 1u << j;
-    }
-  }
-  unsigned long long total;
-  const unsigned long long excl = block_scan_u64(mine, wave_sums, total);
-  if (threadIdx.x < 64)
-  {
-    // The look-back, by the whole first wave: lane i reads the word of block b - 1 - i, so 64 predecessors cost ONE round
-    // trip (one thread walking back word by word paid a coherent load -- 1 to 2 us -- per predecessor: the last of the 33
-    // blocks of the 513^3 map waited ~30 us).  Everything up to the nearest inclusive prefix must be published (status
-    // != 0); aggregates in between are added, the inclusive prefix ends the walk.
-    const uint32_t b = blockIdx.x;
-    const int lane = threadIdx.x;
-    unsigned long long prefix = 0;
-    if (b > 0)
-    {
-      if (lane == 0) __hip_atomic_store(&look[b], LOOK_AGG | look_pack(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t j0 = (int64_t)b - 1;
-      for (;;)
-      {
-        const int64_t j = j0 - lane;
-        unsigned long long w = LOOK_INCL; // before block 0: an inclusive prefix of zero
-        if (j >= 0) w = __hip_atomic_load(&look[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long incl = __ballot((w & LOOK_MASK) == LOOK_INCL), ready = __ballot((w & LOOK_MASK) != 0);
-        const int first = incl ? __ffsll((long long)incl) - 1 : 64;                            // nearest inclusive prefix among these 64
-        const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);          // lanes 0 .. first
-        if ((ready & need) != need)
-        {
-          __builtin_amdgcn_s_sleep(2);
-          continue; // somebody in front has not published yet: read again
-        }
-        unsigned long long v = lane <= first ? look_unpack(w & ~LOOK_MASK) : 0ull;
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-        prefix += v;
-        if (first < 64) break;
-        j0 -= 64;
-      }
-    }
-    if (lane == 0)
-    {
-      __hip_atomic_store(&look[b], LOOK_INCL | look_pack(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_prefix = prefix;
-      if (b == n_scan_blocks - 1)
-      {
-        __hip_atomic_store(&a.counters->n_desc_sorted, (uint32_t)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.counters->n_listed = (uint32_t)((prefix + total) >> 32);
-      }
-    }
-  }
-  __syncthreads();
-  uint32_t run_off = (uint32_t)excl + (uint32_t)s_prefix;
-  uint32_t list_off = (uint32_t)(excl >> 32) + (uint32_t)(s_prefix >> 32);
-#pragma unroll
-  for (int j = 0; j < SCAN_TILES_PER_THREAD; ++j)
-  {
-    if (!(listed & (1u << j))) continue;
-    const int64_t t = t0 + j;
-    if (nr[j]) __hip_atomic_store(&a.tile_begin[t], run_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // read by the placement blocks
-    TileEntry e;
-    e.tile = (uint32_t)t;
-    e.desc_begin = run_off;
-    e.nruns = nr[j];
-    e.tz = (int32_t)((uint32_t)t % (uint32_t)a.ntz);
-    e.ty = (int32_t)(((uint32_t)t / (uint32_t)a.ntz) % (uint32_t)a.nty);
-    e.tx = (int32_t)((uint32_t)t / ((uint32_t)a.ntz * (uint32_t)a.nty));
-    e.pad[0] = e.pad[1] = 0;
-    a.tile_list[list_off] = e;
-    run_off += nr[j];
-    list_off += 1;
-  }
-  // this block's ranges (and, from the last block, the totals) have been written through: count it
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.counters->scan_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the placement as a launch of its own, behind the three-kernel scan of maps with more than LOOKBACK_MAX_BLOCKS scan blocks
-__global__ __launch_bounds__(256) void desc_place_kernel(TileScanArgs a) { place_descriptors<false>(a, 0, gridDim.x); }
+__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
+{
+  // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
+  const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
+  // The whole update is enqueued before the host has seen the record bound of this scan (below: launch_tsdf_scatter).  If the
+  // scan does not fit the chunk buffer, NOTHING of it may happen: the tail march and the free pass leave at once (no byte
+  // of the map's state is touched, the later kernels find nothing to do), and the host grows the buffer and runs it again.
+  if (scan_fits(a) == false) return;
+  if (blockIdx.x < n_items) tail_item(a, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// free space
+// ---------------------------------------------------------------------------------------------------------
+// What a free-space candidate does to its voxel, in two halves: the byte of the voxel is REQUESTED when the candidate is
+// popped from the queue and USED one emit phase later.  The free pass is not bound by instruction issue alone: shortening
+// the sample phase from ~115 to ~60 instructions moved it from 137 to 126 us, taking this load's round trip off the wave's
+// path to 122 us; what remains is the scattered byte traffic itself (21 M byte loads, 9 M byte stores, one cache line each).
+struct FreePending
+{
+  int64_t idx;   // voxel (storage index)
+  uint32_t tile;
+  uint32_t local; // voxel inside the tile
+  uint32_t ix;   // ray
+  int32_t k;     // ray step
+  uint32_t b;    // the voxel's byte (in flight until the next emit phase)
+  bool valid;
+};
+__device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFrame &f, FreePending &p, bool valid, uint32_t ix, int32_t k, int32_t vx, int32_t vy,
+                                             int32_t vz)
+{
+  const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
+                sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+  p.valid = valid;
+  p.idx = valid ? storage_index(a.map, sx, sy, sz) : 0; // unconditional (clamped) load: nothing waits for it here
+  p.tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+  p.local = local_of(sx, sy, sz);
+  p.ix = ix;
+  p.k = k;
+  p.b = a.vstate[p.idx];
+}
+__device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed)
+{
+  if (!p.valid) return;
+  const uint32_t b = p.b;
+  if (b & VOX_KEYED)
+  {
+    // the voxel also has ordered candidates (from the tails): this one, (tau, +64) at its place in the order, joins the
+    // records of the tile (25 000 of the benchmark scan's 21 million free-space candidates)
+    append_record(a, p.tile, make_rec(p.ix, p.k, 0, a.tau, p.local));
+    n_keyed += 1;
+  }
+  else if (b == 0)
+  {
+    // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
+    // whose loads both saw 0 both store: idempotent.)
+    a.vstate[p.idx] = VOX_TOUCHED;
+    // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured)
+    list_dirty_tile(a, p.tile);
+  }
+}
+// both halves at once (general walk)
+__device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz, uint32_t &n_keyed)
+{
+  FreePending p;
+  free_request(a, f, p, true, ix, k, vx, vy, vz);
+  free_finish(a, p, n_keyed);
+}
+
+constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
+#ifndef WS_FREE_LANES
+#define WS_FREE_LANES 4
+#endif
+constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space part of one ray
+
+// 64 rays per workgroup, 4 lanes per ray (round 2 walk: 32 lanes 163 us, 16: 146, 8: 141, 4: 147, 1: 280; round 3 walk: 8: 123, 4: 120, 2: 131): lane c walks the steps [c*CH, (c+1)*CH) of the free-space part of its ray,
+// so every lane has the same amount of work whatever the ray length.  Waves whose rays are all RAY_SIMPLE use the
+// compacting walk (ws_march.h): samples for all lanes, candidates through a per-wave LDS queue, 64 at a time.
+// (Round 4 measured the free part extended over the steps that carry a fan -- 8.2 m to the tail at 50 mm, their off-ray
+// targets as marks in the second byte plane: 10.8 M records instead of 14.4 M and a tail march of 146 instead of 187 us, but
+// a free pass of 195-230 instead of 123 us whatever the lane layout: out there neighbouring rays are more than a voxel
+// apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
+__global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
+{
+  if (scan_fits(a) == false || a.counters->abort != 0) return; // see march_tail_kernel
+  __shared__ u32x4 s_queue[4 * FREE_QCAP];
+  __shared__ uint32_t s_keyed[4];
+  const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
+  const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
+  const int lane = threadIdx.x & 63;
+  uint32_t n_keyed = 0;
+  RaySetup r;
+  r.steps = 0;
+  r.kfirst = 0;
+  r.pad = 0;
+  if (ix < a.n) r = a.rays[ix];
+  const int32_t kend = min(r.steps, r.kfirst);
+  const int32_t ch = (kend + FREE_LANES - 1) / FREE_LANES;
+  const int32_t k0 = c * ch;
+  const int32_t k1 = min(k0 + ch, kend);
+  const bool work = k0 < k1;
+  const int32_t tau = a.tau;
+  const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
+  // wave-private ring buffer: LDS operations of one wave are performed in order, so no barrier between push and pop
+  u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
+  uint32_t qhead = 0, qtail = 0;
+  const int32_t res = f.res, half = f.half, dist = r.distance;
+  if (!__all(!work || (r.pad & RAY_SIMPLE)))
+  {
+    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
+    if (work)
+      march_steps<true>(f, r, k0, k1, [&](int32_t k, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+        // every candidate of these steps is free space: on the ray, further than tau from the hit point
+        if (!(positive && value == tau))
+        {
+          raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
+          return;
+        }
+        free_emit(a, f, ix, k, vx, vy, vz, n_keyed);
+      });
+  }
+  else if (__any(work))
+  {
+    // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
+    // previous emit phase, then pop the next batch and request its bytes
+    FreePending pend;
+    pend.valid = false;
+    pend.idx = 0;
+    pend.tile = pend.local = pend.ix = pend.b = 0;
+    pend.k = 0;
+    auto emit = [&]() {
+#if WS_FREE_PIPE
+      free_finish(a, pend, n_keyed);
+#endif
+      const uint32_t cnt = qtail - qhead;
+      const uint32_t n = cnt < 64 ? cnt : 64;
+      u32x4 e = {0, 0, 0, 0};
+      const bool has = (uint32_t)lane < n;
+      if (has) e = queue[(qhead + (uint32_t)lane) & (FREE_QCAP - 1)];
+      const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
+      free_request(a, f, pend, has, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
+#if !WS_FREE_PIPE
+      free_finish(a, pend, n_keyed);
+      pend.valid = false;
+#endif
+      qhead += n;
+    };
+    AxisRun ix0, iy0, iz0;
+    ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
+    ix0.gap = 0x3fffffff;
+    iy0 = ix0;
+    iz0 = ix0;
+    int32_t k = k0; // the next sample of this lane
+    if (work)
+    {
+      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+      run_init(ix0, f, r, r.dx, f.posx, kinit, true);
+      run_init(iy0, f, r, r.dy, f.posy, kinit, true);
+      run_init(iz0, f, r, r.dz, f.posz, kinit, false);
+    }
+    AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
+    int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
+    // target of the single on-ray candidate of a free-space sample (update_tsdf.cu:103-112 with iter_steps == 1): the sample
+    // minus the fan base offset, which changes every 328 mm of ray
+    auto push = [&](bool cand, bool cx, bool cy, int32_t dzl) {
+      const unsigned long long mask = __ballot(cand);
+      if (mask == 0) return;
+      if (cand)
+      {
+        const int32_t px = fast_proj(wx, cx, res), py = fast_proj(wy, cy, res), pz = fast_proj(wz, false, res);
+        const int32_t delta_z = dzl >> 15; // (DZ_PER_DISTANCE * len) >> 15, len > 0; no fan in the free-space part: delta_z * 2 < res
+        if (delta_z != last_dz)
+        {
+          last_dz = delta_z;
+          c0x = trunc_shift15(delta_z * r.ivx);
+          c0y = trunc_shift15(delta_z * r.ivy);
+          c0z = trunc_shift15(delta_z * r.ivz);
+        }
+        u32x4 e;
+        e.x = (uint32_t)(px - c0x);
+        e.y = (uint32_t)(py - c0y);
+        e.z = (uint32_t)(pz - c0z);
+        e.w = (uint32_t)k | ((uint32_t)lane << 16);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[(qtail + rank) & (FREE_QCAP - 1)] = e;
+      }
+      qtail += (uint32_t)__popcll(mask);
+    };
+    // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk was initialised:
+    // taken out of the loop, so that every iteration below is "step, then test"
+    {
+      bool first = false;
+      if (work && k0 == 0)
+      {
+        const int32_t px = fast_proj(wx, false, res), py = fast_proj(wy, false, res);
+        first = div_trunc(px, f.rM, f.rK, res) != 0 || div_trunc(py, f.rM, f.rK, res) != 0;
+      }
+      push(first, false, false, DZ_PER_DISTANCE); // len == 1
+      if (work && k0 == 0) k = 1;
+    }
+    // iterations of the wave: the longest lane (uniform: the loop itself is scalar)
+    int32_t todo = work ? k1 - k : 0;
+    for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
+    const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
+    int32_t dzl = DZ_PER_DISTANCE * (1 + k * half); // DZ_PER_DISTANCE * len of the sample k, carried (no multiply per sample)
+    const int32_t dzl_step = DZ_PER_DISTANCE * half;
+    for (int32_t it = 0; it < n_iter; ++it)
+    {
+      // ---- sample phase: every lane steps (lanes that are through keep stepping; their samples are masked)
+      const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
+      fast_step_z(wz);
+      const bool cand = (cx || cy) && k < k1;
+      push(cand, cx, cy, dzl);
+      k += 1;
+      dzl += dzl_step;
+      // ---- emit phase
+      if (qtail - qhead >= 64) emit();
+    }
+    while (qtail != qhead) emit();
+    free_finish(a, pend, n_keyed);
+  }
+  // statistics: free-space candidates that became records
+  for (int d = 32; d > 0; d >>= 1) n_keyed += __shfl_down(n_keyed, d, 64);
+  if (lane == 0) s_keyed[threadIdx.x >> 6] = n_keyed;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const uint32_t all = s_keyed[0] + s_keyed[1] + s_keyed[2] + s_keyed[3];
+    if (all) atomicAdd(&a.counters->last_free_keyed, all);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // exact resolve of one tile in LDS
@@ -1518,54 +1329,73 @@ __global__ __launch_bounds__(256) void desc_place_kernel(TileScanArgs a) { place
 struct ResolveArgs
 {
   const TileEntry *tile_list;
-  const uint32_t *sorted_desc;
-  const CandRecord *recs;
+  uint32_t *tile_fill;
+  uint32_t *tile_chunk;
+  uint8_t *tile_dirty;
+  const unsigned long long *recs;
+  unsigned long long *big_keys;
+  uint32_t big_mask;
+  uint32_t scan_seq;
   uint32_t *new_data;
   uint32_t *avg_data;
   uint8_t *vstate;
-  const unsigned long long *fk_keys;
-  const unsigned long long *fk_vals;
-  int32_t fk_shift;
-  uint32_t fk_mask;
   MapParams map;
   int32_t nty, ntz;
   int32_t tau, max_weight;
   uint32_t wM32;     // division by tau - tau/10 of the weight ramp (update_tsdf.cu:92) as one v_mul_hi_u32 + shift
   int32_t wS;
-  uint32_t desc_cap; // entries of sorted_desc
-  uint32_t *resolve_stats; // [grid][2]: contested voxels, free-space hits on keyed voxels
+  uint32_t *resolve_stats; // [grid]: contested voxels
   TsdfCounters *counters;
   uint32_t *status;
-  unsigned long long *look; // look-back words of the tile scan: consumed, zeroed here for the next scan
-  uint32_t n_look;
 };
 static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
 
-constexpr int PLACE_BLOCKS = 256; // workgroups that group the run descriptors by tile
 constexpr int RESOLVE_GRID = 4096; // 1024 / 2048 / 8192 workgroups: the same 170 us, 3072: 182 (block_stats holds two words per workgroup)
 constexpr uint32_t M_IDLE = 0xffffffffu, M_NONE = 0x10000u; // mstate: voxel not in the ordered rounds / no earlier negative seen
+constexpr unsigned long long REC_NONE = ~0ull;
 
 // kneg: smallest |value| wins, the LATEST candidate among equal |value| (a later equal one replaces the entry)
-__device__ __forceinline__ uint64_t neg_key(uint64_t key, int32_t av, int32_t value)
+__device__ __forceinline__ uint64_t neg_key(uint64_t rec, int32_t av, int32_t value)
 {
-  const uint64_t t = key >> 17;
-  return ((uint64_t)av << 45) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
+  const uint64_t t = rec >> REC_T_SHIFT;
+  return ((uint64_t)av << 39) | ((T_MASK - t) << 1) | (value < 0 ? 1u : 0u);
+}
+__device__ __forceinline__ int32_t neg_key_abs(uint64_t N) { return (int32_t)(N >> 39); }
+
+// chunk number j of a tile at resolve time: every id has been published (the marches are over)
+__device__ __forceinline__ uint32_t resolve_chunk(const ResolveArgs &a, uint32_t tile, uint32_t j)
+{
+  if (j < (uint32_t)TILE_DIRECT) return a.tile_chunk[(size_t)tile * TILE_DIRECT + j];
+  const unsigned long long key = big_key(tile, j);
+  const uint32_t *vals = reinterpret_cast<const uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
+  uint32_t h = big_slot(key, a.big_mask);
+  for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
+  {
+    const unsigned long long cur = a.big_keys[h];
+    if (cur == key) return vals[h];
+    if (cur == KEY_INF) break;
+    h = (h + 1) & a.big_mask;
+  }
+  return CHUNK_LOST;
 }
 
+// every record of a tile, chunk by chunk from memory (wave w the chunks w, w + 4, ...): tiles of more than 2048 records, and
+// the ordered rounds
 template <class F>
-__device__ __forceinline__ void for_each_record(uint32_t desc_begin, uint32_t nruns, const uint32_t *sorted_desc, const CandRecord *recs, F &&f)
+__device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t fill, F &&f)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t r = (uint32_t)wave; r < nruns; r += 4)
+  const uint32_t n_chunks = (fill + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
+  for (uint32_t j = (uint32_t)wave; j < n_chunks; j += 4)
   {
-    const uint32_t start = sorted_desc[2 * (size_t)(desc_begin + r)];
-    const uint32_t count = sorted_desc[2 * (size_t)(desc_begin + r) + 1];
+    const uint32_t id1 = resolve_chunk(a, tile, j);
+    if (id1 == CHUNK_NONE || id1 == CHUNK_LOST) continue;
+    const uint32_t count = min((uint32_t)CHUNK_RECS, fill - (j << CHUNK_BITS));
     for (uint32_t i = (uint32_t)lane; i < count; i += 64)
     {
-      const u32x4 rec = *reinterpret_cast<const u32x4 *>(&recs[start + i]);
-      const uint64_t key = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
-      const int32_t value = (int32_t)(int16_t)(rec.x & 0xffffu);
-      f(key, value, value < 0 ? -value : value, (int)(rec.w & (TILE_VOXELS - 1)));
+      const unsigned long long rec = a.recs[(size_t)(id1 - 1u) * CHUNK_RECS + i];
+      const int32_t value = rec_value(rec);
+      f((uint64_t)rec, value, value < 0 ? -value : value, (int)rec_local(rec));
     }
   }
 }
@@ -1577,20 +1407,17 @@ __device__ __forceinline__ void for_each_record(uint32_t desc_begin, uint32_t nr
 #define WS_RESOLVE_WGS 4
 #endif
 constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
+static_assert(RES_MAXR <= TILE_DIRECT, "the register route reads the chunks of the tile's direct table");
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
 struct TilePre
 {
   int64_t idx0;
   int nz;
-  uint32_t my_start, my_count; // run descriptor `lane` of the tile (nruns <= 64)
-  uint32_t vs;                 // four vstate bytes
-  uint32_t s0[4];              // new_map entries (HAS_S0)
-};
-// what stays of a list entry once its voxel bytes and descriptors have been requested
-struct TileRef
-{
-  uint32_t nruns, desc_begin;
+  uint32_t fill; // records of the tile (uniform)
+  uint32_t cid;  // lane k < TILE_DIRECT of every wave: id + 1 of the tile's chunk k
+  uint32_t vs;   // four vstate bytes (both planes)
+  uint32_t s0[4]; // new_map entries (HAS_S0)
 };
 // the result of a tile, written back one tile later (behind the next tile's wait for its records)
 struct TilePost
@@ -1619,8 +1446,11 @@ struct TilePost
 // Memory pipeline.  gfx950 retires vector memory operations in order behind ONE counter (loads and stores), and the
 // counts here are data dependent, so every wait is a wait for everything outstanding.  The loop therefore has a single
 // such point per tile — the arrival of the tile's records — and everything else is arranged around it: entry, voxel
-// bytes and descriptors of later tiles and the records of the next tile are all requested together at the END of an
+// bytes and chunk table of later tiles and the records of the next tile are all requested together at the END of an
 // iteration, and the stores of a tile are issued right AFTER the next wait, so they drain under the LDS phases.
+//
+// A scan that ran out of chunks (counters->abort) leaves no trace: the tiles' scratch is put back as always, nothing is
+// written to the maps, and the host runs the scan again with a larger buffer.
 template <bool HAS_S0, bool FUSED>
 __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(ResolveArgs a)
 {
@@ -1631,26 +1461,16 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
   __shared__ uint32_t s_unres[2];
   const uint32_t n_list = a.counters->n_listed;
+  const bool aborted = a.counters->abort != 0;
   const int32_t weight_epsilon = a.tau / 10;
   const uint32_t reset = pack_entry(a.tau, 0);
   const int lane = threadIdx.x & 63;
+  uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
   // thread t owns the voxels 4t .. 4t+3 of the tile: column t >> (ZB - 2), four consecutive z
   const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
   const int l0 = threadIdx.x * 4;
   const uint32_t G = gridDim.x;
-  uint32_t n_contested = 0, n_freehit = 0;
-#ifdef WS_RESOLVE_TIMING
-  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = clock64();
-  int t_tiles = 0, t_rounds = 0;
-#define WS_TP(i)                      \
-  {                                   \
-    const long long now = clock64();  \
-    tp[i] += now - tl;                \
-    tl = now;                         \
-  }
-#else
-#define WS_TP(i)
-#endif
+  uint32_t n_contested = 0;
 
   // all loads unconditional (clamped addresses, results masked)
   auto request = [&](const TileEntry &te, TilePre &p) {
@@ -1659,17 +1479,13 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     int nz = a.map.size[2] - sz;
     p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
     p.idx0 = p.nz ? storage_index(a.map, sx, sy, sz) : 0;
-    const uint32_t which = (uint32_t)lane;
-    const bool mine = which < te.nruns && te.nruns <= 64;
-    uint32_t di = te.desc_begin + (mine ? which : 0u);
-    di = di < a.desc_cap ? di : a.desc_cap - 1;
-    const uint2 d = *reinterpret_cast<const uint2 *>(&a.sorted_desc[2 * (size_t)di]);
-    p.my_start = mine ? d.x : 0u;
-    p.my_count = mine ? d.y : 0u;
+    p.fill = a.tile_fill[te.tile] & ~FILL_DIRTY;
+    p.cid = a.tile_chunk[(size_t)te.tile * TILE_DIRECT + (uint32_t)(lane & (TILE_DIRECT - 1))];
     // four voxels of a column in one access each (the arrays carry 16 bytes of slack behind the last voxel)
     const uint32_t keep = p.nz >= 4 ? 0xffffffffu : ((1u << (8 * p.nz)) - 1u);
     p.vs = 0;
-    if (!HAS_S0) p.vs = *reinterpret_cast<const u32_a1 *>(a.vstate + p.idx0) & keep;
+    // both byte planes of the four voxels in one register: the second plane's mark becomes bit VOX_NEGFREE of the byte
+    if (!HAS_S0) p.vs = (*reinterpret_cast<const u32_a1 *>(a.vstate + p.idx0) | ((*reinterpret_cast<const u32_a1 *>(vneg + p.idx0) & 0x01010101u) << 3)) & keep;
     const u32x4 z4 = {reset, reset, reset, reset};
     u32x4 s4 = z4;
     if (HAS_S0) s4 = *reinterpret_cast<const u32x4_a4 *>(a.new_data + p.idx0);
@@ -1690,62 +1506,35 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       mstate[l0 + j] = M_NONE;
     }
   };
-  // The records of a tile, in registers: every lane of every wave holds descriptor `lane` of the tile (nruns <= 64), the
-  // records are dealt out to the 256 threads round robin, up to RES_MAXR per thread, all loads in flight together.
-  // Returns false (uniform over the workgroup) when the tile has more than 64 runs or more than 256 * RES_MAXR records:
-  // the waves then stream the runs from memory in every pass (wave w the runs w, w + 4, ...).
-  // The loads are UNCONDITIONAL (clamped address) and all issued before the first result is touched: a load under a branch,
-  // or a use right behind it, makes the compiler wait for each of them in turn (eight serial round trips instead of one).
-  // (Keeping the raw 16-byte records in registers across the decide phase, to defer that one wait as well, spills.)
-  unsigned long long rkey[RES_MAXR];
-  uint32_t rloc[RES_MAXR]; // voxel in the tile, 0xffffffff: no record
+  // The records of a tile, in registers: a tile's chunks back to back are its record sequence, thread t takes the records
+  // t, t + 256, ... -- record t of chunk k, one coalesced 2 KB read per chunk, all RES_MAXR of them in flight together.
+  // Returns false (uniform over the workgroup) when the tile has more than 256 * RES_MAXR records: the waves then stream
+  // the chunks from memory in every pass.  The loads are UNCONDITIONAL (clamped address) and all issued before the first
+  // result is touched: a load under a branch, or a use right behind it, makes the compiler wait for each of them in turn.
+  unsigned long long rrec[RES_MAXR]; // REC_NONE: no record
   u32x4 ex_next = {0, 0, 0, 0}; // FUSED: the avg_map entries of the tile whose records are in flight
-  auto fetch_records = [&](const TileRef &te, const TilePre &p) -> bool {
+  auto fetch_records = [&](const TilePre &p) -> bool {
     if (FUSED) ex_next = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
-#pragma unroll
-    for (int k = 0; k < RES_MAXR; ++k) rloc[k] = 0xffffffffu;
-    if (te.nruns == 0 || te.nruns > 64) return false;
-    const int nruns = (int)te.nruns;
-    // the tile's runs back to back: thread t takes the records t, t + 256, ... of that sequence.  Every wave walks ALL
-    // descriptors (scalar reads from its lanes), so all of them see the same total and take the same route.
-    uint32_t addr[RES_MAXR];
-#pragma unroll
-    for (int k = 0; k < RES_MAXR; ++k) addr[k] = 0xffffffffu;
-    uint32_t pref = 0; // uniform
-    for (int r = 0; r < nruns; ++r)
-    {
-      const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)p.my_start, r);
-      const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)p.my_count, r);
-      // (A run covers one or two of the eight slots; skipping the others with uniform compares and branches removes 40 % of
-      // this kernel's vector instructions and makes it SLOWER, 166 -> 184 us: with four waves per SIMD the resolve is bound
-      // by the length of each wave's own instruction stream, and a taken scalar branch costs more than three selects.)
-#pragma unroll
-      for (int k = 0; k < RES_MAXR; ++k)
-      {
-        const uint32_t rel = (uint32_t)(256 * k) + threadIdx.x - pref; // wraps for positions before this run
-        if (rel < count) addr[k] = start + rel;
-      }
-      pref += count;
-    }
-    if (pref > (uint32_t)(256 * RES_MAXR)) return false;
-    u32x4 raw[RES_MAXR];
-#pragma unroll
-    for (int k = 0; k < RES_MAXR; ++k) raw[k] = *reinterpret_cast<const u32x4 *>(&a.recs[addr[k] != 0xffffffffu ? addr[k] : 0u]);
+    const uint32_t fill = p.fill;
+    const bool in_regs = fill != 0 && fill <= (uint32_t)(CHUNK_RECS * RES_MAXR);
 #pragma unroll
     for (int k = 0; k < RES_MAXR; ++k)
     {
-      rkey[k] = (unsigned long long)raw[k].x | ((unsigned long long)raw[k].y << 32);
-      rloc[k] = addr[k] != 0xffffffffu ? (raw[k].w & (TILE_VOXELS - 1)) : 0xffffffffu;
+      const uint32_t id1 = (uint32_t)__builtin_amdgcn_readlane((int)p.cid, k);
+      const bool ok = in_regs && (uint32_t)(k * CHUNK_RECS) + threadIdx.x < fill && id1 != CHUNK_NONE && id1 != CHUNK_LOST;
+      const unsigned long long v = a.recs[ok ? (size_t)(id1 - 1u) * CHUNK_RECS + threadIdx.x : (size_t)threadIdx.x];
+      rrec[k] = ok ? v : REC_NONE;
     }
-    return true;
+    return in_regs;
   };
   auto write_back = [&](const TilePost &w) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
       if (j >= w.nz) continue;
-      if (!HAS_S0 && ((w.vs >> (8 * j)) & 0xffu)) a.vstate[w.idx0 + j] = 0;
-      if (!(w.touched & (1u << j))) continue;
+      if (!HAS_S0 && ((w.vs >> (8 * j)) & (0xffu & ~(uint32_t)VOX_NEGFREE))) a.vstate[w.idx0 + j] = 0;
+      if (!HAS_S0 && ((w.vs >> (8 * j)) & VOX_NEGFREE)) vneg[w.idx0 + j] = 0;
+      if (!(w.touched & (1u << j)) || aborted) continue;
       if (FUSED)
       {
         const uint32_t updated = integrate_entry(w.existing[j], w.value[j], a.max_weight);
@@ -1757,49 +1546,75 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       }
     }
   };
+  // the tile's scratch goes back to zero for the next scan (no clean-up launch): record count, list flag, chunk table
+  // (and the entries of the chunks beyond it)
+  auto release_tile = [&](uint32_t tile, uint32_t fill) {
+    if (threadIdx.x < (uint32_t)TILE_DIRECT) a.tile_chunk[(size_t)tile * TILE_DIRECT + threadIdx.x] = 0;
+    if (threadIdx.x == 8) a.tile_fill[tile] = 0;
+    if (threadIdx.x == 9) a.tile_dirty[tile] = 0;
+    const uint32_t n_chunks = (fill + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
+    if (n_chunks > (uint32_t)TILE_DIRECT)
+    {
+      uint32_t *vals = reinterpret_cast<uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
+      for (uint32_t j = (uint32_t)TILE_DIRECT + threadIdx.x; j < n_chunks; j += 256u)
+      {
+        const unsigned long long key = big_key(tile, j);
+        uint32_t h = big_slot(key, a.big_mask);
+        for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
+        {
+          const unsigned long long cur = a.big_keys[h];
+          if (cur == key)
+          {
+            // (the slot keeps its key: emptying it would cut the probe chains that run through it; a key of an earlier
+            // scan with value 0 is "not published" to the marches and is overwritten by the tile's next chunk j)
+            vals[h] = 0;
+            break;
+          }
+          if (cur == KEY_INF) break;
+          h = (h + 1) & a.big_mask;
+        }
+      }
+    }
+  };
 
   // The per-scan scratch this scan has consumed goes back to zero here, for the next scan (no clean-up launch behind the
-  // update): the look-back words of the tile scan, and the cursors of the tail march after a copy for ws_tsdf_stats.
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n_look; i += gridDim.x * 256u) a.look[i] = 0;
+  // update); the host learns that the marches are over and whether the scan has to be repeated.
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     TsdfCounters *c = a.counters;
-    c->last_slots = c->raw_cursor;
-    c->last_runs = c->desc_cursor;
+    c->last_chunks = c->chunk_cursor;
     c->last_listed = n_list;
-    c->raw_cursor = 0;
-    c->desc_cursor = 0;
-    c->scan_done = 0;
-    c->tail_next = 0;
+    c->last_need = c->ub_total & ((1ull << 48) - 1ull);
     c->ub_total = 0;
+    __hip_atomic_store(a.status + 10, c->big_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.status + 9, aborted ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint32_t e0 = blockIdx.x;
   if (e0 >= n_list)
   {
-    if (threadIdx.x == 0) a.resolve_stats[2 * blockIdx.x + 0] = a.resolve_stats[2 * blockIdx.x + 1] = 0;
+    if (threadIdx.x == 0) a.resolve_stats[blockIdx.x] = 0;
     return;
   }
   const uint32_t last = n_list - 1;
-  // pipeline: tile i is processed while the voxel bytes / descriptors of tiles i+1 and i+2, the list entries up to i+3
+  // pipeline: tile i is processed while the voxel bytes / chunk table of tiles i+1 and i+2, the list entries up to i+3
   // and (from the middle of the iteration on) the records of tile i+1 are in flight
   TileEntry te_n2 = a.tile_list[min(e0 + 2 * G, last)], te_n3 = te_n2;
-  TileRef te_cur, te_n1;
+  uint32_t tile_cur, tile_n1;
   TilePre p_cur, p_n1, p_n2;
   {
     const TileEntry t0 = a.tile_list[e0], t1 = a.tile_list[min(e0 + G, last)];
     request(t0, p_cur);
     request(t1, p_n1);
-    te_cur.nruns = t0.nruns;
-    te_cur.desc_begin = t0.desc_begin;
-    te_n1.nruns = t1.nruns;
-    te_n1.desc_begin = t1.desc_begin;
+    tile_cur = t0.tile;
+    tile_n1 = t1.tile;
   }
-  bool cached = fetch_records(te_cur, p_cur), cached_next = false;
+  bool cached = fetch_records(p_cur), cached_next = false;
   u32x4 ex_cur = ex_next;
   auto issue_next = [&](uint32_t e) {
     te_n3 = a.tile_list[min(e + 3 * G, last)];
     request(te_n2, p_n2);
-    cached_next = fetch_records(te_n1, p_n1);
+    cached_next = fetch_records(p_n1);
   };
   TilePost post;
   post.nz = 0;
@@ -1811,8 +1626,8 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
   for (uint32_t e = e0; e < n_list; e += G)
   {
-    const TileRef te = te_cur;
     const TilePre p = p_cur;
+    const uint32_t tile = tile_cur, fill = p.fill;
     const int nz = p.nz;
     const int64_t idx0 = p.idx0;
 
@@ -1821,23 +1636,23 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     uint8_t vs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) vs[j] = (uint8_t)(p.vs >> (8 * j)); // <- the wait of this iteration (with the records)
-    WS_TP(0)
     write_back(post); // the previous tile's stores drain under this tile's LDS phases
 
-    if (te.nruns == 0)
+    if (fill == 0)
     {
       issue_next(e);
-      // free space only
+      // free space only: (tau, +64) where an on-ray candidate landed, else (tau, -64) where only off-ray ones did
       if (!HAS_S0)
       {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (vs[j] & VOX_TOUCHED)
+          if (vs[j] & (VOX_TOUCHED | VOX_NEGFREE))
           {
-            entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
+            entry[j] = pack_entry(a.tau, (vs[j] & VOX_TOUCHED) ? WEIGHT_RESOLUTION : -WEIGHT_RESOLUTION);
             touched |= 1u << j;
           }
       }
+      __syncthreads(); // (keeps the workgroup's iterations together: release_tile below relies on it)
     }
     else
     {
@@ -1851,93 +1666,62 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         }
         __syncthreads();
       }
-      WS_TP(1)
       bool from_regs = cached; // pass 1 and scan A; the rounds stream (the registers then hold the next tile's records)
       auto scan_records = [&](auto &&f) {
         if (from_regs)
         {
 #pragma unroll
           for (int k = 0; k < RES_MAXR; ++k)
-            if (rloc[k] != 0xffffffffu)
+            if (rrec[k] != REC_NONE)
             {
-              const int32_t value = (int32_t)(int16_t)(rkey[k] & 0xffffu);
+              const int32_t value = rec_value(rrec[k]);
               const int32_t av = value < 0 ? -value : value;
-              if (HAS_S0 && av >= (int32_t)bound0[rloc[k]]) continue; // rejected by the stored entry, now and for ever
-              f((uint64_t)rkey[k], value, av, (int)rloc[k]);
+              const int l = (int)rec_local(rrec[k]);
+              if (HAS_S0 && av >= (int32_t)bound0[l]) continue; // rejected by the stored entry, now and for ever
+              f((uint64_t)rrec[k], value, av, l);
             }
         }
         else
         {
-          for_each_record(te.desc_begin, te.nruns, a.sorted_desc, a.recs, [&](uint64_t key, int32_t value, int32_t av, int l) {
+          for_each_record(a, tile, fill, [&](uint64_t rec, int32_t value, int32_t av, int l) {
             if (HAS_S0 && av >= (int32_t)bound0[l]) return;
-            f(key, value, av, l);
+            f(rec, value, av, l);
           });
         }
       };
       // scan A: the negatives that come before the current positive candidate and can block it
       auto scan_a = [&]() {
-        scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
-          if (!(key & KEY_NEG_BIT)) return;
+        scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
+          if (!rec_negative(rec)) return;
           const uint32_t m = mstate[l];
           if (m == M_IDLE || (uint32_t)av >= m) return;
           const unsigned long long P = kpos[l];
-          if (P == KEY_INF || key > P) return;
-          const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+          if (P == KEY_INF || rec > P) return;
+          const int32_t vp = rec_value(P);
           if (av < (vp < 0 ? -vp : vp)) atomicMin(&mstate[l], (uint32_t)av);
         });
       };
       auto negative_entry = [&](unsigned long long N) {
         // no positive candidate is accepted: the negatives fold to the smallest |value|, latest on ties
-        const int32_t an = (int32_t)(N >> 45);
+        const int32_t an = neg_key_abs(N);
         const int32_t v = (N & 1ull) ? -an : an;
         return pack_entry(v, -weight_of(v));
       };
 
       // ---- pass 1: earliest positive, smallest negative per voxel
-      scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
-        if (key & KEY_NEG_BIT)
-          atomicMin(&kneg[l], (unsigned long long)neg_key(key, av, value));
+      scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
+        if (rec_negative(rec))
+          atomicMin(&kneg[l], (unsigned long long)neg_key(rec, av, value));
         else
-          atomicMin(&kpos[l], (unsigned long long)key);
+          atomicMin(&kpos[l], (unsigned long long)rec);
       });
-      if (!HAS_S0)
-      {
-        // free-space candidates that hit a keyed voxel: (tau, +weight) at their earliest order key
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (vs[j] & VOX_FREEHIT)
-          {
-            n_freehit += 1;
-            const unsigned long long want = (unsigned long long)(idx0 + j);
-            uint32_t h = fk_hash(want, a.fk_shift);
-            unsigned long long t = KEY_INF;
-            for (int q = 0; q < 128; ++q)
-            {
-              const unsigned long long cur = a.fk_keys[h];
-              if (cur == want)
-              {
-                t = a.fk_vals[h];
-                break;
-              }
-              if (cur == KEY_INF) break;
-              h = (h + 1) & a.fk_mask;
-            }
-            if (t != KEY_INF)
-              atomicMin(&kpos[l0 + j], (unsigned long long)record_key(t, a.tau, true));
-            else
-              raise_error(a.counters, a.status, ERR_INTERNAL);
-          }
-      }
       __syncthreads();
-      WS_TP(2)
       scan_a();
       __syncthreads();
-      WS_TP(3)
       // this tile's records are not needed again (unless it needs ordered rounds, which stream): everything the next
       // iterations need is requested NOW and arrives under the decide phase, the barrier and the write-back
       from_regs = false;
       issue_next(e);
-      WS_TP(6)
 
       // ---- decide
       uint32_t unres = 0; // bit j: voxel j is still open
@@ -1956,9 +1740,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           }
           else
           {
-            const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+            const int32_t vp = rec_value(P);
             const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
-            if (N != KEY_INF && ap > (uint32_t)(N >> 45)) n_contested += 1; // a negative candidate COULD have blocked it
+            if (N != KEY_INF && ap > (uint32_t)neg_key_abs(N)) n_contested += 1; // a negative candidate COULD have blocked it
             if (ap <= m)
             {
               entry[j] = pack_entry(vp, weight_of(vp));
@@ -1973,9 +1757,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
             }
           }
         }
-        else if (j < nz && !HAS_S0 && (vs[j] & VOX_TOUCHED))
+        else if (j < nz && !HAS_S0 && (vs[j] & (VOX_TOUCHED | VOX_NEGFREE)))
         {
-          entry[j] = pack_entry(a.tau, WEIGHT_RESOLUTION);
+          entry[j] = pack_entry(a.tau, (vs[j] & VOX_TOUCHED) ? WEIGHT_RESOLUTION : -WEIGHT_RESOLUTION);
           touched |= 1u << j;
         }
         if (!open)
@@ -1988,7 +1772,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       }
       if (unres) atomicAdd(&s_unres[0], 1u);
       __syncthreads();
-      WS_TP(4)
 
       if (s_unres[0] != 0)
       {
@@ -2002,11 +1785,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         for (;;)
         {
           // B: the next positive candidate that can still be accepted
-          scan_records([&](uint64_t key, int32_t value, int32_t av, int l) {
-            if (key & KEY_NEG_BIT) return;
+          scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
+            if (rec_negative(rec)) return;
             const uint32_t m = mstate[l];
             if (m == M_IDLE || (uint32_t)av > m) return;
-            if (key > klast[l]) atomicMin(&kpos[l], (unsigned long long)key);
+            if (rec > klast[l]) atomicMin(&kpos[l], (unsigned long long)rec);
           });
           __syncthreads();
 #pragma unroll
@@ -2028,9 +1811,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           __syncthreads();
           if (threadIdx.x == 0) s_unres[phase] = 0;
           phase ^= 1;
-#ifdef WS_RESOLVE_TIMING
-          t_rounds += 1;
-#endif
           if (s_unres[phase] == 0) break;
           scan_a();
           __syncthreads();
@@ -2039,7 +1819,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           {
             if (!(unres & (1u << j))) continue;
             const unsigned long long P = kpos[l0 + j];
-            const int32_t vp = (int32_t)(int16_t)(P & 0xffffu);
+            const int32_t vp = rec_value(P);
             const uint32_t ap = (uint32_t)(vp < 0 ? -vp : vp);
             if (ap <= mstate[l0 + j])
             {
@@ -2064,11 +1844,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         init_lds();
         __syncthreads();
       }
-      WS_TP(5)
-#ifdef WS_RESOLVE_TIMING
-      t_tiles += 1;
-#endif
     }
+
+    // Nobody reads the tile's tables again: every thread's prefetch of them was consumed before the last barrier of the
+    // PREVIOUS iteration, the passes that stream the chunks from memory ended before the last barrier of this one.
+    release_tile(tile, fill);
 
     // ---- this tile's result waits in registers until the next iteration's loads have arrived
     post.idx0 = idx0;
@@ -2081,40 +1861,21 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       post.value[j] = entry[j];
     }
     post.existing[0] = ex_cur.x; post.existing[1] = ex_cur.y; post.existing[2] = ex_cur.z; post.existing[3] = ex_cur.w;
-    te_cur = te_n1;
+    tile_cur = tile_n1;
     p_cur = p_n1;
     cached = cached_next;
     ex_cur = ex_next;
-    te_n1.nruns = te_n2.nruns;
-    te_n1.desc_begin = te_n2.desc_begin;
+    tile_n1 = te_n2.tile;
     p_n1 = p_n2;
     te_n2 = te_n3;
   }
   write_back(post);
-#ifdef WS_RESOLVE_TIMING
-  if (threadIdx.x == 0 && (blockIdx.x & 511) == 7)
-    printf("resolve wg %u: %d keyed tiles, %d rounds | wait %lld staged %lld pass1 %lld scanA %lld decide %lld rounds %lld issue %lld cycles per keyed tile\n",
-           blockIdx.x, t_tiles, t_rounds, tp[0] / max(t_tiles, 1), tp[1] / max(t_tiles, 1), tp[2] / max(t_tiles, 1), tp[3] / max(t_tiles, 1),
-           tp[4] / max(t_tiles, 1), tp[5] / max(t_tiles, 1), tp[6] / max(t_tiles, 1));
-#endif
   // statistics: one slot per workgroup, no shared counter
-  for (int d = 32; d > 0; d >>= 1)
-  {
-    n_contested += __shfl_down(n_contested, d, 64);
-    n_freehit += __shfl_down(n_freehit, d, 64);
-  }
-  __shared__ uint32_t s_stat[8];
-  if ((threadIdx.x & 63) == 0)
-  {
-    s_stat[(threadIdx.x >> 6) * 2 + 0] = n_contested;
-    s_stat[(threadIdx.x >> 6) * 2 + 1] = n_freehit;
-  }
+  for (int d = 32; d > 0; d >>= 1) n_contested += __shfl_down(n_contested, d, 64);
+  __shared__ uint32_t s_stat[4];
+  if ((threadIdx.x & 63) == 0) s_stat[threadIdx.x >> 6] = n_contested;
   __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    a.resolve_stats[2 * blockIdx.x + 0] = s_stat[0] + s_stat[2] + s_stat[4] + s_stat[6];
-    a.resolve_stats[2 * blockIdx.x + 1] = s_stat[1] + s_stat[3] + s_stat[5] + s_stat[7];
-  }
+  if (threadIdx.x == 0) a.resolve_stats[blockIdx.x] = s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2180,37 +1941,37 @@ __global__ __launch_bounds__(256) void tsdf_stats_kernel(TsdfCounters *c, const 
                                                          uint32_t n_resolve)
 {
   __shared__ uint32_t part[12];
-  uint32_t rec = 0, con = 0, fh = 0;
-  for (uint32_t i = threadIdx.x; i < n_tail; i += 256) rec += tail_stats[i];
-  for (uint32_t i = threadIdx.x; i < n_resolve; i += 256)
+  uint32_t rec = 0, con = 0, grp = 0;
+  for (uint32_t i = threadIdx.x; i < n_tail; i += 256)
   {
-    con += resolve_stats[2 * i + 0];
-    fh += resolve_stats[2 * i + 1];
+    rec += tail_stats[i];
+    grp += tail_stats[WS_TAIL_STATS + i];
   }
+  for (uint32_t i = threadIdx.x; i < n_resolve; i += 256) con += resolve_stats[i];
   for (int d = 32; d > 0; d >>= 1)
   {
     rec += __shfl_down(rec, d, 64);
     con += __shfl_down(con, d, 64);
-    fh += __shfl_down(fh, d, 64);
+    grp += __shfl_down(grp, d, 64);
   }
   if ((threadIdx.x & 63) == 0)
   {
     part[(threadIdx.x >> 6) * 3 + 0] = rec;
     part[(threadIdx.x >> 6) * 3 + 1] = con;
-    part[(threadIdx.x >> 6) * 3 + 2] = fh;
+    part[(threadIdx.x >> 6) * 3 + 2] = grp;
   }
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    c->last_records = part[0] + part[3] + part[6] + part[9];
+    c->last_records = part[0] + part[3] + part[6] + part[9] + c->last_free_keyed; // tail records + free-space candidates that joined them
     c->last_contested = part[1] + part[4] + part[7] + part[10];
-    c->last_free_keyed = part[2] + part[5] + part[8] + part[11];
+    c->last_runs = part[2] + part[5] + part[8] + part[11];
   }
 }
 int launch_tsdf_stats(ws_map *m)
 {
   hipLaunchKernelGGL(tsdf_stats_kernel, dim3(1), dim3(256), 0, m->ctx->stream, m->counters, (const uint32_t *)m->block_stats, m->tail_blocks,
-                     (const uint32_t *)(m->block_stats + WS_TAIL_STATS), m->resolve_blocks);
+                     (const uint32_t *)(m->block_stats + 2 * WS_TAIL_STATS), m->resolve_blocks);
   WS_HIP(hipGetLastError());
   return WS_OK;
 }
@@ -2351,18 +2112,19 @@ static PrepArgs make_prep_args(ws_map *m)
   p.counters = m->counters;
   p.az_hist = m->az_hist;
   p.n_hist = (uint32_t)(AZ_BINS + 1);
-  p.tile_nruns = m->tile_nruns;
+  p.tile_fill = m->tile_fill;
+  p.tile_chunk = m->tile_chunk;
+  p.tile_dirty = m->tile_dirty;
   p.n_tiles = m->n_tiles;
-  p.fk = m->fk_keys;
-  p.n_fk = (int64_t)2 * m->fk_slots;
-  p.look = reinterpret_cast<unsigned long long *>(m->block_sums);
-  p.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
+  p.big_keys = m->big_keys;
+  p.big_slots = m->big_slots;
   return p;
 }
 int launch_scatter_prep(ws_map *m)
 {
   hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), dim3(256), 0, m->ctx->stream, make_prep_args(m));
   WS_HIP(hipGetLastError());
+  m->status_host[10] = 0;
   m->prepped = true;
   return WS_OK;
 }
@@ -2377,21 +2139,20 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res)
     const int64_t cj = (j * res + 1) / 2;                                                   // delta_z that gives 2*delta_z/res >= j
     const int64_t Lj = (cj * MATRIX_RESOLUTION + DZ_PER_DISTANCE - 1) / DZ_PER_DISTANCE;   // first length with that delta_z
     const int64_t kj = (Lj - 1 + half - 1) / half;                                          // first step with len_k >= Lj
-    fan_steps[j] = (int32_t)(kj > (1ll << 30) ? (1ll << 30) : kj);                          // beyond the 65 536 steps the order key admits anyway
+    fan_steps[j] = (int32_t)(kj > (1ll << 30) ? (1ll << 30) : kj);                          // beyond the steps the record admits anyway
   }
 }
 
-// workgroups of march_tail_kernel the device holds at once (queried once)
-static unsigned tail_resident_blocks(int device)
+// Chunk buffers up to this size are sized by the hard bound of chunks_needed() (a scan can never run out); maps whose
+// tile term alone is larger (2049^3: 8.7 M tiles x 2 KB) take the estimate and repeat a scan that does run out.
+constexpr uint64_t CHUNK_BUDGET_BYTES = 6ull << 30;
+static uint32_t est_shift_of(const ws_map *m)
 {
-  static unsigned cached = 0;
-  if (cached) return cached;
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, march_tail_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = WS_TAIL_WGS;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-  cached = (unsigned)per_cu * (unsigned)cus;
-  return cached;
+  const uint64_t budget = m->chunk_budget_bytes ? m->chunk_budget_bytes : CHUNK_BUDGET_BYTES;
+  if ((uint64_t)m->n_tiles * CHUNK_RECS * sizeof(unsigned long long) <= budget) return 0;
+  return m->est_shift ? m->est_shift : 1u;
 }
+uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records) { return chunks_needed(need_records, (uint64_t)m->n_tiles, est_shift_of(m)); }
 
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
@@ -2402,11 +2163,14 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   if (n == 0)
   {
     m->resolve_blocks = 0;
-    WS_HIP(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
-    return WS_OK; // (nothing listed: a following integrate pass has nothing to do)
+    // nothing listed: a following integrate pass has nothing to do
+    WS_HIP(hipMemsetAsync(&m->counters->n_listed, 0, sizeof(uint32_t), s));
+    return WS_OK;
   }
 
   const bool s0 = !m->new_is_default;
+  // the (tile, chunk) hash keeps the keys of released tiles: empty it before it fills up
+  if (m->status_host[10] > m->big_slots / 4) m->prepped = false;
   ScatterArgs sa;
   sa.xyz = xyz_dev;
   sa.n = (uint32_t)n;
@@ -2438,20 +2202,15 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.fan_steps = m->fan_steps;
   sa.vstate = m->vstate;
   sa.tile_dirty = m->tile_dirty;
-  sa.tile_nruns = m->tile_nruns;
-  sa.rec_raw = m->rec_raw;
-  sa.rec_sorted = m->rec_sorted;
-  sa.rec_cap = m->rec_cap;
+  sa.tile_fill = m->tile_fill;
+  sa.tile_chunk = m->tile_chunk;
+  sa.tile_list = m->tile_list;
+  sa.rec = m->rec;
+  sa.chunk_cap = m->chunk_cap;
   sa.scan_seq = ++m->scan_seq;
-  sa.desc = m->desc;
-  sa.desc_cap = m->desc_cap;
-  sa.fk_keys = m->fk_keys;
-  {
-    int l = 0;
-    while ((1u << l) < m->fk_slots) ++l;
-    sa.fk_shift = 64 - l;
-    sa.fk_mask = m->fk_slots - 1;
-  }
+  sa.big_keys = m->big_keys;
+  sa.big_mask = m->big_slots - 1;
+  sa.est_shift = est_shift_of(m);
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;
   sa.status = m->status_dev;
@@ -2467,7 +2226,11 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   {
   prof_begin(ctx, WS_K_SETUP);
   // normally the kernels of the previous update have left their scratch zero / empty on their way (m->prepped)
-  if (!m->prepped) hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), block, 0, s, make_prep_args(m));
+  if (!m->prepped)
+  {
+    hipLaunchKernelGGL(scatter_prep_kernel, dim3(PREP_GRID), block, 0, s, make_prep_args(m));
+    m->status_host[10] = 0;
+  }
   m->prepped = false;
 #if WS_FUSE_SETUP
   // set-up blocks + direction-sort blocks in one launch
@@ -2478,11 +2241,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 #endif
   prof_end(ctx, WS_K_SETUP);
   prof_begin(ctx, WS_K_MARCH_TAILS);
-#if WS_TAIL_PERSISTENT
-  hipLaunchKernelGGL(march_tail_kernel, dim3(min(grid_tail.x, tail_resident_blocks(ctx->device))), block, 0, s, sa);
-#else
   hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);
-#endif
   prof_end(ctx, WS_K_MARCH_TAILS);
   if (!s0)
   {
@@ -2491,52 +2250,18 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     prof_end(ctx, WS_K_MARCH_FREE);
   }
 
-  prof_begin(ctx, WS_K_TILE_BIN);
-  TileScanArgs ta;
-  ta.tile_nruns = m->tile_nruns;
-  ta.tile_begin = m->tile_begin;
-  ta.tile_dirty = m->tile_dirty;
-  ta.tile_list = m->tile_list;
-  ta.block_sums = m->block_sums;
-  ta.n_blocks = m->scan_blocks;
-  ta.n_tiles = m->n_tiles;
-  ta.nty = m->nty;
-  ta.ntz = m->ntz;
-  ta.counters = m->counters;
-  ta.desc = m->desc;
-  ta.desc_cap = m->desc_cap;
-  ta.sorted_desc = m->sorted_desc;
-  if (m->scan_blocks <= LOOKBACK_MAX_BLOCKS)
-  {
-#if WS_FUSE_PLACE
-    // scan blocks + descriptor-placement blocks in one launch
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks + PLACE_BLOCKS), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums),
-                       m->scan_blocks);
-#else
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(m->scan_blocks), block, 0, s, ta, reinterpret_cast<unsigned long long *>(m->block_sums), m->scan_blocks);
-    hipLaunchKernelGGL(desc_place_kernel, dim3(PLACE_BLOCKS), block, 0, s, ta);
-#endif
-  }
-  else
-  {
-    hipLaunchKernelGGL(tile_count_kernel, dim3(m->scan_blocks), block, 0, s, ta);
-    hipLaunchKernelGGL(tile_blockscan_kernel, dim3(1), dim3(1024), 0, s, ta);
-    hipLaunchKernelGGL(tile_list_kernel, dim3(m->scan_blocks), block, 0, s, ta);
-    hipLaunchKernelGGL(desc_place_kernel, dim3(PLACE_BLOCKS), block, 0, s, ta);
-  }
-  prof_end(ctx, WS_K_TILE_BIN);
-
   ResolveArgs ra;
   ra.tile_list = m->tile_list;
-  ra.sorted_desc = m->sorted_desc;
-  ra.recs = m->rec_sorted;
+  ra.tile_fill = m->tile_fill;
+  ra.tile_chunk = m->tile_chunk;
+  ra.tile_dirty = m->tile_dirty;
+  ra.recs = m->rec;
+  ra.big_keys = m->big_keys;
+  ra.big_mask = m->big_slots - 1;
+  ra.scan_seq = sa.scan_seq;
   ra.new_data = m->data[WS_MAP_NEW];
   ra.avg_data = m->data[WS_MAP_AVG];
   ra.vstate = m->vstate;
-  ra.fk_keys = m->fk_keys;
-  ra.fk_vals = m->fk_vals;
-  ra.fk_shift = sa.fk_shift;
-  ra.fk_mask = sa.fk_mask;
   ra.map = m->par[WS_MAP_NEW];
   ra.nty = m->nty;
   ra.ntz = m->ntz;
@@ -2547,12 +2272,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     ra.wM32 = (uint32_t)wd.M;
     ra.wS = wd.k - 32;
   }
-  ra.desc_cap = m->desc_cap;
-  ra.resolve_stats = m->block_stats + WS_TAIL_STATS;
+  ra.resolve_stats = m->block_stats + 2 * WS_TAIL_STATS;
   ra.counters = m->counters;
   ra.status = m->status_dev;
-  ra.look = reinterpret_cast<unsigned long long *>(m->block_sums);
-  ra.n_look = m->scan_blocks <= LOOKBACK_MAX_BLOCKS ? m->scan_blocks : 0;
   m->resolve_blocks = RESOLVE_GRID;
   prof_begin(ctx, WS_K_TILE_RESOLVE);
   if (s0)
@@ -2562,55 +2284,79 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   else
     hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   prof_end(ctx, WS_K_TILE_RESOLVE);
-  // The set-up pass has counted the record slots this scan can need; its last workgroup writes the total and this scan's
+  // The set-up pass has counted the records this scan can make; its last workgroup writes the total and this scan's
   // sequence number into host-mapped memory.  Everything above was enqueued WITHOUT waiting for that word (the march kernels
   // check the bound themselves and do nothing if the scan does not fit), so the device runs the update back to back; the
   // host looks at the word now -- it arrived while the later launches were being enqueued -- and, should the scan not have
-  // fitted, grows the buffers and runs the update again.  (Waiting for the word BEFORE the tail march was enqueued left the
+  // fitted, grows the buffer and runs the update again.  (Waiting for the word BEFORE the tail march was enqueued left the
   // device idle for ~10 us per scan once the set-up pass got faster than the host's flag -> launch -> doorbell path.)  A hint
   // from the previous scan is not enough: a door that opens multiplies the need.
   {
     volatile uint32_t *st = m->status_host;
-    const auto t0 = std::chrono::steady_clock::now();
-    uint32_t spins = 0;
-    while (st[6] != sa.scan_seq)
-    {
-      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+    auto wait_word = [&](int word, const char *what) -> int {
+      const auto t0 = std::chrono::steady_clock::now();
+      uint32_t spins = 0;
+      while (st[word] != sa.scan_seq)
       {
-        WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
-        if (st[6] != sa.scan_seq)
+        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
         {
-          set_error("TSDF update: the set-up pass did not report its record bound");
-          return WS_ERR_INTERNAL;
+          WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
+          if (st[word] != sa.scan_seq)
+          {
+            set_error(what);
+            return WS_ERR_INTERNAL;
+          }
         }
       }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return WS_OK;
+    };
+    int rc = wait_word(6, "TSDF update: the set-up pass did not report its record bound");
+    if (rc != WS_OK) return rc;
     const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
-    if (need <= m->rec_cap) break; // the normal case
-    if (attempt > 0)
+    const uint64_t want = chunks_for_scan(m, need);
+    bool again = false;
+    uint64_t grow_to = 0;
+    if (want > m->chunk_cap)
     {
-      set_error("TSDF update: the scan did not fit the record buffers it had just been given");
+      // the marches have skipped this scan (scan_fits): a larger buffer, and once more
+      again = true;
+      grow_to = want + want / 8;
+    }
+    else if (sa.est_shift)
+    {
+      // sized by estimate: did the marches get through?  (they are over when the resolve starts: ~0.4 ms into the update)
+      rc = wait_word(8, "TSDF update: the resolve did not report the end of the marches");
+      if (rc != WS_OK) return rc;
+      if (st[9] != 0)
+      {
+        again = true;
+        grow_to = (uint64_t)m->chunk_cap * 2;
+      }
+    }
+    if (!again) break; // the normal case
+    if (attempt >= 8)
+    {
+      set_error("TSDF update: the scan did not fit the chunk buffer it had just been given");
       return WS_ERR_INTERNAL;
     }
-    if (need > 0xfffffff0ull)
+    if (grow_to > 0xfffffff0ull)
     {
-      set_error("TSDF update: the scan needs more than 2^32 candidate records");
+      set_error("TSDF update: the scan needs more than 2^32 record chunks");
       return WS_ERR_CAPACITY;
     }
-    const int rc = resize_records(m, need + need / 8); // (waits for the stream: the skipped update has drained)
+    rc = resize_records(m, grow_to); // (waits for the stream: the skipped / aborted update has drained and put its scratch back)
     if (rc != WS_OK) return rc;
-    sa.rec_raw = m->rec_raw;
-    sa.rec_sorted = m->rec_sorted;
-    sa.rec_cap = m->rec_cap;
-    sa.desc = m->desc;
-    sa.desc_cap = m->desc_cap;
+    sa.rec = m->rec;
+    sa.chunk_cap = m->chunk_cap;
+    sa.big_keys = m->big_keys;
+    sa.big_mask = m->big_slots - 1;
     sa.scan_seq = ++m->scan_seq;
-    m->prepped = true; // the skipped update put its scratch back like any other
+    // (resize_records leaves prepped == false: the new hash is filled by the preparation pass; the tile tables are zero already)
   }
   } // attempts
   m->fused_done = fuse;
-  m->prepped = true; // every kernel above has put back what it consumed (the free-space hash: the next scan's set-up blocks)
+  m->prepped = true; // every kernel above has put back what it consumed
   WS_HIP(hipGetLastError());
   return WS_OK;
 }

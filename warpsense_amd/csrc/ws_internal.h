@@ -32,8 +32,11 @@ constexpr int TILE_XB = WS_TILE_XB, TILE_YB = WS_TILE_YB, TILE_ZB = WS_TILE_ZB;
 static_assert(TILE_XB + TILE_YB + TILE_ZB == 10 && TILE_ZB >= 2, "a tile is 1024 voxels: 256 threads x 4 consecutive z");
 constexpr int TILE_VOXELS = 1 << (TILE_XB + TILE_YB + TILE_ZB); // 1024
 constexpr uint64_t KEY_INF = ~0ull;
-constexpr uint32_t WS_TAIL_STATS = 65536; // per-workgroup slots of the tail march (1 000 000 points / 64 rays x up to 4 workgroups), then 2 per resolve workgroup
-constexpr uint32_t WS_BLOCK_STATS = WS_TAIL_STATS + 2 * 4096;
+// the voxel bytes are two planes in one allocation: [0] keyed / touched / free-space hit (VOX_*), [1] "an off-ray free-space
+// candidate (tau, -weight) landed here" (blind, idempotent byte stores of the free pass)
+__host__ __device__ inline size_t vstate_plane_bytes(int64_t n_vox) { return ((size_t)n_vox + 16 + 255) & ~(size_t)255; }
+constexpr uint32_t WS_TAIL_STATS = 65536; // per-workgroup slots of the tail march: records, flush groups (1 000 000 points / 64 rays x up to 2 workgroups), then 2 per resolve workgroup
+constexpr uint32_t WS_BLOCK_STATS = 2 * WS_TAIL_STATS + 2 * 4096;
 
 // ring-buffer parameters passed BY VALUE to kernels (the reference chases three device pointers per
 // access, device_map.h:93-101)
@@ -44,55 +47,58 @@ struct MapParams
   int32_t offset[3];
 };
 
-// ---- order key layout -------------------------------------------------------------------
-// t    = point(20) | ray step(16) | fan step(8)                       -> 44 bits, unique per candidate
-// key  = t << 17 | (weight < 0) << 16 | value(u16)                     (ascending key == canonical serial order)
-constexpr int T_BITS = 44;
+// ---- candidate records ---------------------------------------------------------------------
+// One scatter target of a ray tail (a write_tsdf_min call, update_tsdf.cu:107-125) is ONE 64-bit word:
+//   point(20) | ray step(13) | fan(5) | value(16) | voxel in tile(10)
+// `fan` = fan step - mid + 15 (mid: the on-ray fan step, update_tsdf.cu:104): ascending like the fan step itself, and the
+// weight is negated iff fan != 15 (update_tsdf.cu:118-121) -- no separate sign-of-weight bit.  The top 38 bits
+// t = point | step | fan are unique per candidate, so ascending records == canonical serial order (the low bits never decide).
+constexpr int REC_VOX_BITS = 10, REC_VALUE_SHIFT = 10, REC_T_SHIFT = 26, REC_FAN_MID = 15;
+constexpr int T_BITS = 38;
 constexpr uint64_t T_MASK = (1ull << T_BITS) - 1;
-constexpr uint64_t KEY_NEG_BIT = 1ull << 16;
-
-// one scatter target of the ray tails (write_tsdf_min call, update_tsdf.cu:107-125)
-struct CandRecord // 16 bytes
+constexpr int32_t REC_MAX_STEPS = 8192, REC_MAX_FAN = 31; // what the fields hold: more is WS_ERR_RANGE
+__host__ __device__ inline uint64_t make_rec(uint32_t point, int32_t step, int32_t fan_minus_mid, int32_t value, uint32_t local)
 {
-  uint64_t key;
-  uint32_t tile;  // tile id in the window's tile grid
-  uint32_t local; // voxel inside the tile: lx << 7 | ly << 4 | lz
-};
-// a run of records of ONE tile, contiguous in the sorted record buffer (written by one workgroup of the tail march)
-struct RunDesc // 16 bytes
+  return ((uint64_t)point << 44) | ((uint64_t)(uint32_t)step << 31) | ((uint64_t)(uint32_t)(fan_minus_mid + REC_FAN_MID) << REC_T_SHIFT) |
+         ((uint64_t)((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT) | (uint64_t)local;
+}
+__host__ __device__ inline int32_t rec_value(uint64_t rec) { return (int32_t)(int16_t)(uint16_t)(rec >> REC_VALUE_SHIFT); }
+__host__ __device__ inline uint32_t rec_local(uint64_t rec) { return (uint32_t)rec & ((1u << REC_VOX_BITS) - 1u); }
+__host__ __device__ inline bool rec_negative(uint64_t rec) { return (((uint32_t)(rec >> REC_T_SHIFT)) & 31u) != (uint32_t)REC_FAN_MID; }
+
+// Records live in CHUNKS of 256 (2 KB) that belong to one tile each: a workgroup of the tail march stages its records in
+// LDS, reserves a range of the tile's record sequence with one atomic per (flush, tile) and copies them there, so HBM sees
+// every record once and the resolve reads a tile's records as whole chunks.  tile_fill[tile] counts the records (bit 31:
+// the free pass has put the tile on the list); tile_chunk[tile][j] = id + 1 of the chunk holding records 256 j ..; chunks
+// beyond TILE_DIRECT are found through a small hash (tile, j) -> id (tiles of more than 2048 records: only a scan into a
+// non-default new_map, where every candidate is a record, has them).
+constexpr int CHUNK_BITS = 8, CHUNK_RECS = 1 << CHUNK_BITS, TILE_DIRECT = 8;
+constexpr uint32_t FILL_DIRTY = 0x80000000u;
+constexpr uint32_t CHUNK_NONE = 0u, CHUNK_LOST = 0xffffffffu; // not published yet / the chunk buffer was exhausted (scan aborted)
+
+struct TileEntry // 16 bytes: one touched tile of the scan in flight
 {
   uint32_t tile;
-  uint32_t count;
-  uint32_t start;
-  uint32_t pad;
-};
-struct TileEntry // 32 bytes: one touched tile of the scan in flight
-{
-  uint32_t tile;
-  uint32_t desc_begin; // its runs: sorted_desc[desc_begin .. desc_begin + nruns)
-  uint32_t nruns;
-  int32_t tx, ty, tz;  // tile coordinates (so that 256 threads per tile do not divide the tile id again)
-  uint32_t pad[2];
+  int32_t tx, ty, tz; // tile coordinates (so that 256 threads per tile do not divide the tile id again)
 };
 
-struct TsdfCounters // device-resident, zeroed at the start of every scatter
+struct TsdfCounters // device-resident
 {
-  uint32_t raw_cursor;    // record slots handed to the workgroups of the tail march (upper bounds)
-  uint32_t desc_cursor;   // run descriptors written
+  uint32_t chunk_cursor;  // chunks handed out (reset by the set-up pass of the next scan)
   uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
-  uint32_t n_desc_sorted; // == desc_cursor once the tile scan has run
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
-  uint32_t pad_setup;     // (the arrival count of the set-up blocks lives in the top 16 bits of ub_total)
-  uint32_t scan_done;     // scan blocks of tile_scan_kernel that have written their tiles' ranges
-  uint32_t tail_next;     // next work item of the tail march (persistent workgroups)
+  uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
-  // statistics of the last update, filled by finish_update_kernel
+  uint32_t big_inserted;  // keys ever put into the (tile, chunk) hash since it was last emptied (the host empties it when it fills up)
+  uint32_t pad0;
+  // statistics of the last update (ws_tsdf_stats)
   uint32_t last_records;
   uint32_t last_contested;
   uint32_t last_listed;
   uint32_t last_runs;
   uint32_t last_free_keyed;
-  uint32_t last_slots; // record slots the last scan reserved
+  uint32_t last_chunks;
+  unsigned long long last_need; // record bound of the last scan
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -142,7 +148,7 @@ struct ws_map
   ws::MapParams par[2]; // [WS_MAP_AVG], [WS_MAP_NEW]
   int64_t n_vox = 0;
   uint32_t *data[2] = {nullptr, nullptr};
-  uint8_t *vstate = nullptr; // one byte per voxel: keyed / touched by free space / free-space hit on a keyed voxel
+  uint8_t *vstate = nullptr; // two planes of one byte per voxel (vstate_plane_bytes): keyed / touched by free space / free-space hit on a keyed voxel; off-ray free-space hit
   void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
   uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
   void *ray_bin = nullptr;   // [1 000 000] uint2: (direction bin, rank inside the bin) per ray
@@ -156,31 +162,27 @@ struct ws_map
   // tile grid (4 x 4 x 64 voxels of storage space)
   int32_t ntx = 0, nty = 0, ntz = 0;
   int64_t n_tiles = 0;
-  uint32_t *tile_nruns = nullptr;   // [n_tiles] runs per tile of the scan in flight (consumed by the placement pass)
-  uint32_t *tile_begin = nullptr;   // [n_tiles] first sorted descriptor of the tile
-  uint8_t *tile_dirty = nullptr;    // [n_tiles] touched by the free-space pass
+  uint32_t *tile_fill = nullptr;    // [n_tiles] records of the tile in the scan in flight | FILL_DIRTY (zero between scans)
+  uint32_t *tile_chunk = nullptr;   // [n_tiles][TILE_DIRECT] chunk id + 1 (zero between scans)
+  uint8_t *tile_dirty = nullptr;    // [n_tiles] touched by the free-space pass (a cheap filter in front of the atomic that lists the tile)
   ws::TileEntry *tile_list = nullptr; // [n_tiles] touched tiles of the scan in flight
-  uint32_t *block_sums = nullptr;   // [2 * 2 * scan blocks] tile scan scratch
-  uint32_t scan_blocks = 0;
-  // candidate records of the ray tails
-  ws::CandRecord *rec_raw = nullptr, *rec_sorted = nullptr;
-  uint32_t rec_cap = 0;
-  ws::RunDesc *desc = nullptr;
-  uint32_t *sorted_desc = nullptr; // [desc_cap][2]: start, count
-  uint32_t desc_cap = 0;
-  uint32_t desc_scale = 1;   // run descriptors per 8 records (doubled after a scan that ran out of them)
-  // free-space candidates that hit a keyed voxel: voxel index -> earliest order key (open addressing)
-  unsigned long long *fk_keys = nullptr, *fk_vals = nullptr;
-  uint32_t fk_slots = 0;
+  // candidate records of the ray tails: chunks of 256 x 8 bytes
+  unsigned long long *rec = nullptr;
+  uint32_t chunk_cap = 0;
+  unsigned long long *big_keys = nullptr; // (tile, chunk number) -> chunk id for chunks beyond TILE_DIRECT: keys, then uint32 values
+  uint32_t big_slots = 0;
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
   uint32_t tail_blocks = 0;        // workgroups of the last tail march
   uint32_t resolve_blocks = 0;     // workgroups of the last tile resolve
   bool fused_done = false;         // the last scatter already integrated into avg_map
   uint32_t scan_seq = 0;           // scatters launched on this map (ray_setup reports its record bound under this number)
-  bool grow_aux = false;           // a scan overflowed the run descriptors / the free-space hash: double them before the next
+  uint64_t chunk_budget_bytes = 0; // chunk buffers above this size are sized by estimate + abort / re-run instead of by the hard bound (0: default)
+  uint32_t est_shift = 0;          // the estimate is the record bound / 256 >> (est_shift - 1) (0: default 1; tests shrink it to force the abort route)
   ws::TsdfCounters *counters = nullptr;
   ws::TsdfCounters *counters_host = nullptr; // pinned
-  uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [4..5] record bound of the scan in flight (u64), [6] its sequence number
+  uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [4..5] record bound of the scan in flight (u64), [6] its sequence number,
+                                             // [8] sequence number of the last scan whose marches have finished, [9] != 0: that scan was aborted (chunks exhausted),
+                                             // [10] keys in the (tile, chunk) hash
   uint32_t *status_dev = nullptr;            // device view of status_host
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
@@ -233,6 +235,7 @@ struct ws_reg
   void *peer_block_dev = nullptr;    // PeerBlock
   int peer_rank = 0, peer_world = 0; // 0: not connected
   int peer_blocks = 0;               // grid of the peer loop on this rank
+  bool peer_dirty = false;           // an exchange failed or was given up: the mailboxes hold partial additions until ws_reg_peer_reset / reconnect
 };
 
 // scan pre-processing buffers (App::preprocess on the device, scan_preprocess.hip)
@@ -277,8 +280,8 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
-int resize_records(ws_map *m, uint64_t records); // api.hip: (re)allocate the candidate-record buffers
-uint32_t tile_scan_blocks(int64_t n_tiles);
+int resize_records(ws_map *m, uint64_t chunks); // api.hip: (re)allocate the chunk buffer (waits for the stream)
+uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records); // chunks the map's buffer must hold for a scan of that record bound (hard bound, or the estimate for huge maps)
 int launch_tsdf_integrate(ws_map *m);
 int launch_tsdf_stats(ws_map *m); // fills the last_* statistics of TsdfCounters from the per-workgroup slots
 int launch_box_copy(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);

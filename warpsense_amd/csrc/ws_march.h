@@ -211,7 +211,7 @@ __device__ __forceinline__ int32_t axis_index_offset(const AxisWalk &w, int32_t 
 }
 
 // FREE_SPACE: the caller guarantees that every step of [k0, k1) lies more than tau (+ the centre/fan slack) in front
-// of the hit point, so value == tau and the weight is positive without computing them (no squares, no sqrt).
+// of the hit point, so value == tau (weight 64, negated off the ray) without computing it (no squares, no sqrt).
 // the same for |e| < res (one wrap at most)
 __device__ __forceinline__ int32_t axis_index_offset_small(const AxisWalk &w, int32_t e, int32_t res)
 {
@@ -282,15 +282,6 @@ __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RayS
       c0x = trunc_shift15(delta_z * r.ivx);
       c0y = trunc_shift15(delta_z * r.ivy);
       c0z = trunc_shift15(delta_z * r.ivz);
-    }
-    if (FREE_SPACE)
-    {
-      // no fan before len_neg (delta_z * 2 < res): one on-ray candidate, offset by less than half a voxel
-      const int32_t vx = axis_index_offset_small(wx, -c0x, res);
-      const int32_t vy = axis_index_offset_small(wy, -c0y, res);
-      const int32_t vz = axis_index_offset_small(wz, -c0z, res);
-      if (in_bounds(f.map, vx, vy, vz)) emit(k, 0, vx, vy, vz, value, true);
-      continue;
     }
     int32_t iter_steps = 1, mid = 0;
     if (delta_z * 2 >= res)
@@ -470,17 +461,6 @@ __device__ __forceinline__ int32_t fast_proj(AxisFast &w, bool crossed, int32_t 
   const int32_t a = w.spos + w.q;
   if (crossed && (uint32_t)(a + res - 1) < (uint32_t)(res - 1)) w.gap += res - 1; // entered the cell around zero from below
   return (a ^ w.sm) - w.sm;
-}
-
-// order key of a candidate: point(20) | ray step(16) | fan step(8)
-__device__ __forceinline__ uint64_t order_key(uint32_t ix, int32_t k, int32_t step)
-{
-  return ((uint64_t)ix << 24) | ((uint64_t)(uint32_t)k << 8) | (uint64_t)(uint32_t)step;
-}
-// record key: ascending == canonical serial order (t is unique per candidate)
-__device__ __forceinline__ uint64_t record_key(uint64_t t, int32_t value, bool positive)
-{
-  return (t << 17) | (positive ? 0ull : KEY_NEG_BIT) | ((uint32_t)value & 0xffffu);
 }
 
 } // namespace ws

@@ -279,7 +279,13 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
     first, count = shard_range(n_points, rank, world)
     if getattr(backend, "peers", None) is not None and backend.peers[1] == world:
         # the resident loop on every rank, sums exchanged device to device: one launch per registration
-        res = backend.register_peers(first, count, T_in, max_iterations, it_weight_gradient, epsilon)
+        # (an error other than the time-out -- e.g. a sticky map error surfacing here -- must not leave the other ranks
+        # blocked in the agreement below: vote "not ok", take part in the collective, raise afterwards)
+        failure = None
+        try:
+            res = backend.register_peers(first, count, T_in, max_iterations, it_weight_gradient, epsilon)
+        except Exception as exc:  # noqa: BLE001 - re-raised below, after the collective
+            res, failure = None, exc
         ok = res is not None
         if world > 1:  # a time-out is seen by every rank, but agree before anyone takes the other route
             import torch
@@ -290,6 +296,7 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
             ok = bool(int(flag.item()))
         if ok:
             backend.peer_timeouts = 0
+            backend.last_route = "device_mailboxes"
             return res
         import sys
         # every rank saw the same verdict above, so every rank counts alike and they leave the route together
@@ -297,12 +304,16 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
         give_up = backend.peer_timeouts >= PEER_TIMEOUTS_BEFORE_GIVING_UP
         print("[warpsense_amd.dist] the device-side exchange timed out; this registration runs through the all-reduce route"
               + (" and so do all later ones (time-out %d in a row)" % backend.peer_timeouts if give_up else ""), file=sys.stderr)
+        backend.peer_timeouts_total = getattr(backend, "peer_timeouts_total", 0) + 1
         if give_up:
             backend.drop_peers()
         else:
             backend.reset_peers()
         if world > 1:
             dist.barrier(group=group)
+        if failure is not None:
+            raise failure
+    backend.last_route = "all_reduce"
     runner = None
     if graphs is not None:
         key = (first, count, batch) + (backend.binding() if hasattr(backend, "binding") else ())
