@@ -340,11 +340,11 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   // per-tile bookkeeping of the scatter: record count, chunk table, a byte, one 16-byte list entry per 1024 voxels
   TRY(hipMalloc((void **)&m->tile_fill, (size_t)m->n_tiles * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->tile_chunk, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->tile_dirty, (size_t)m->n_tiles));
+  TRY(hipMalloc((void **)&m->tile_dirty, 2 * tile_flag_plane_bytes(m->n_tiles)));
   TRY(hipMalloc((void **)&m->tile_list, (size_t)m->n_tiles * sizeof(TileEntry)));
   TRY(hipMemsetAsync(m->tile_fill, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->tile_chunk, 0, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t), s));
-  TRY(hipMemsetAsync(m->tile_dirty, 0, (size_t)m->n_tiles, s));
+  TRY(hipMemsetAsync(m->tile_dirty, 0, 2 * tile_flag_plane_bytes(m->n_tiles), s));
   TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));
   TRY(hipHostMalloc((void **)&m->counters_host, sizeof(TsdfCounters), hipHostMallocDefault));
@@ -748,7 +748,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   const TsdfCounters *c = m->counters_host;
   out->contested_voxels = c->last_contested;
   out->records = c->last_records;
-  out->tiles = c->last_listed;
+  out->tiles = (int64_t)c->last_listed + c->last_unlisted;
   out->runs = c->last_runs;
   out->free_space_hits = c->last_free_keyed;
   out->record_slots = (int64_t)c->last_need;

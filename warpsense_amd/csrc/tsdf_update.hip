@@ -59,7 +59,7 @@ struct ScatterArgs
   const int32_t *fan_steps; // [256], see tail_bound
   uint8_t *vstate;     // two planes of one byte per voxel: VOX_* / off-ray free-space mark
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
-  uint32_t *tile_fill;  // [tiles] records of the tile | FILL_DIRTY
+  uint32_t *tile_fill;  // [tiles] records of the tile
   uint32_t *tile_chunk; // [tiles][TILE_DIRECT] chunk id + 1
   TileEntry *tile_list;
   unsigned long long *rec; // chunks of CHUNK_RECS records
@@ -145,11 +145,8 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
   for (int64_t i = tid; i < p.n_hist; i += stride) p.az_hist[i] = 0;
-  for (int64_t i = tid; i < p.n_tiles; i += stride)
-  {
-    p.tile_fill[i] = 0;
-    p.tile_dirty[i] = 0;
-  }
+  for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_fill[i] = 0;
+  for (int64_t i = tid; i < (int64_t)(2 * tile_flag_plane_bytes(p.n_tiles)); i += stride) p.tile_dirty[i] = 0;
   for (int64_t i = tid; i < p.n_tiles * TILE_DIRECT; i += stride) p.tile_chunk[i] = 0;
   uint32_t *big_vals = reinterpret_cast<uint32_t *>(p.big_keys + p.big_slots);
   for (int64_t i = tid; i < p.big_slots; i += stride)
@@ -200,6 +197,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
     a.counters->abort = 0;
     a.counters->error = 0;
     a.counters->last_free_keyed = 0;
+    a.counters->last_unlisted = 0;
   }
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
@@ -542,7 +540,7 @@ __device__ __forceinline__ Reserve tile_reserve(const ScatterArgs &a, uint32_t t
   const uint32_t old = __hip_atomic_fetch_add(&a.tile_fill[tile], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   Reserve r;
   r.first = old == 0;
-  r.p0 = old & ~FILL_DIRTY;
+  r.p0 = old;
   r.j_new = (r.p0 + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
   const uint32_t j_last = (r.p0 + c - 1u) >> CHUNK_BITS;
   r.n_new = j_last >= r.j_new ? j_last - r.j_new + 1u : 0u;
@@ -563,6 +561,7 @@ __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uin
   e.ty = (int32_t)(col % (uint32_t)a.nty);
   e.tx = (int32_t)(col / (uint32_t)a.nty);
   a.tile_list[at] = e;
+  a.tile_dirty[tile_flag_plane_bytes((int64_t)a.ntx * a.nty * a.ntz) + tile] = 1; // the resolve's scan for unlisted tiles skips it
 }
 __device__ __forceinline__ uint32_t chunk_id1(const ScatterArgs &a, uint32_t cid)
 {
@@ -595,20 +594,6 @@ __device__ __forceinline__ void append_record(const ScatterArgs &a, uint32_t til
   asm volatile("" ::: "memory");
   if (id1 == CHUNK_NONE) id1 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
   store_rec(a, id1, r.p0, rec);
-}
-
-// a tile that holds no records but marks of the byte planes: on the list once (the byte in tile_dirty is only a filter in
-// front of this atomic; a stale zero there costs a second atomic, nothing else)
-__device__ __forceinline__ void list_dirty_tile_slow(const ScatterArgs &a, uint32_t tile)
-{
-  const uint32_t old = __hip_atomic_fetch_or(&a.tile_fill[tile], FILL_DIRTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old == 0) list_tile(a, (uint32_t)(alloc_add(a, 1ull << 32) >> 32), tile);
-}
-__device__ __forceinline__ void list_dirty_tile(const ScatterArgs &a, uint32_t tile)
-{
-  if (a.tile_dirty[tile] != 0) return;
-  a.tile_dirty[tile] = 1;
-  list_dirty_tile_slow(a, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -727,6 +712,9 @@ struct TailShared
   unsigned long long wave_sums[4];
   unsigned long long alloc;
   uint32_t cursor, done, n_records, n_groups;
+#ifdef WS_TAIL_TIMING
+  uint32_t t_flush[5];
+#endif
 };
 
 // The staged records go to their tiles: thread t owns slot t of the tile table.  One reservation per tile (its count is
@@ -735,6 +723,10 @@ struct TailShared
 __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
 {
   const int t = threadIdx.x;
+#ifdef WS_TAIL_TIMING
+  long long tf[6];
+  tf[0] = wall_clock64();
+#endif
   const uint32_t c = sh.ht_cnt[t], tile = sh.ht_key[t];
   Reserve r;
   r.p0 = r.j_new = r.n_new = 0;
@@ -743,12 +735,18 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
   unsigned long long all = 0;
   const unsigned long long mine = (unsigned long long)r.n_new | ((unsigned long long)(r.first ? 1u : 0u) << 32);
   const unsigned long long excl = block_scan_u64(mine, sh.wave_sums, all);
+#ifdef WS_TAIL_TIMING
+  tf[1] = wall_clock64();
+#endif
   if (t == 0)
   {
     sh.alloc = all ? alloc_add(a, all) : 0ull;
     sh.n_records += total;
   }
   __syncthreads();
+#ifdef WS_TAIL_TIMING
+  tf[2] = wall_clock64();
+#endif
   const unsigned long long got = sh.alloc + excl;
   const uint32_t cid = (uint32_t)got;
   if (c)
@@ -778,6 +776,9 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
     atomicAdd(&sh.n_groups, 1u);
   }
   __syncthreads();
+#ifdef WS_TAIL_TIMING
+  tf[3] = wall_clock64();
+#endif
   for (uint32_t i = (uint32_t)t; i < total; i += 256u)
   {
     const uint32_t slot = sh.slot[i];
@@ -792,6 +793,17 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
     store_rec(a, id1, q, rec);
   }
   __syncthreads();
+#ifdef WS_TAIL_TIMING
+  tf[4] = wall_clock64();
+  if (t == 0)
+  {
+    sh.t_flush[0] += (uint32_t)(tf[1] - tf[0]);
+    sh.t_flush[1] += (uint32_t)(tf[2] - tf[1]);
+    sh.t_flush[2] += (uint32_t)(tf[3] - tf[2]);
+    sh.t_flush[3] += (uint32_t)(tf[4] - tf[3]);
+    sh.t_flush[4] += 1;
+  }
+#endif
   sh.ht_key[t] = HT_EMPTY;
   sh.ht_cnt[t] = 0;
   if (t == 0) sh.cursor = 0;
@@ -820,12 +832,18 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     ix = a.ray_order[slot];
     r = a.rays[ix];
   }
+#ifdef WS_TAIL_TIMING
+  const long long t_item0 = wall_clock64();
+#endif
   if (threadIdx.x == 0)
   {
     sh.cursor = 0;
     sh.done = 0;
     sh.n_records = 0;
     sh.n_groups = 0;
+#ifdef WS_TAIL_TIMING
+    for (int q = 0; q < 5; ++q) sh.t_flush[q] = 0;
+#endif
   }
   sh.ht_key[threadIdx.x] = HT_EMPTY;
   sh.ht_cnt[threadIdx.x] = 0;
@@ -859,8 +877,10 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
   auto mark_negative = [&](int32_t sx, int32_t sy, int32_t sz, uint32_t listed_tile) {
     vneg[storage_index(a.map, sx, sy, sz)] = 1;
+    // (the tile of the sample's on-ray record is on the list through that record -- nearly always this tile too; any other gets
+    // the byte the resolve scans for.  A blind store: a load here would be a wait for everything the wave has in flight.)
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    if (tile != listed_tile) list_dirty_tile(a, tile);
+    if (tile != listed_tile) a.tile_dirty[tile] = 1;
   };
 
   int32_t k0 = 0, k1 = 0;
@@ -1087,6 +1107,11 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   {
     a.tail_stats[item] = sh.n_records;
     a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
+#ifdef WS_TAIL_TIMING
+    if ((item & 255u) == 7u)
+      printf("tail item %u: %u records %u groups %u flushes | total %lld ticks, flush: reserve+scan %u, alloc %u, publish+lookup %u, copy %u (10 ns ticks)\n", item, sh.n_records,
+             sh.n_groups, sh.t_flush[4], wall_clock64() - t_item0, sh.t_flush[0], sh.t_flush[1], sh.t_flush[2], sh.t_flush[3]);
+#endif
   }
 }
 
@@ -1148,8 +1173,10 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
     // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
     // whose loads both saw 0 both store: idempotent.)
     a.vstate[p.idx] = VOX_TOUCHED;
-    // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured)
-    list_dirty_tile(a, p.tile);
+    // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured; an atomic
+    // that puts the tile on the scan's list at its first mark: 123 -> 355 us -- the load sees stale zeros from the L1 of its
+    // compute unit all through the kernel, harmless for a byte store, a blocking round trip for a returning atomic)
+    if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
   }
 }
 // both halves at once (general walk)
@@ -1347,6 +1374,8 @@ struct ResolveArgs
   uint32_t *resolve_stats; // [grid]: contested voxels
   TsdfCounters *counters;
   uint32_t *status;
+  TileEntry *tile_list_out; // == tile_list: the tiles found by the scan of the flag planes are appended for a separate integrate pass
+  int64_t n_tiles;
 };
 static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
 
@@ -1479,7 +1508,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     int nz = a.map.size[2] - sz;
     p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
     p.idx0 = p.nz ? storage_index(a.map, sx, sy, sz) : 0;
-    p.fill = a.tile_fill[te.tile] & ~FILL_DIRTY;
+    p.fill = a.tile_fill[te.tile];
     p.cid = a.tile_chunk[(size_t)te.tile * TILE_DIRECT + (uint32_t)(lane & (TILE_DIRECT - 1))];
     // four voxels of a column in one access each (the arrays carry 16 bytes of slack behind the last voxel)
     const uint32_t keep = p.nz >= 4 ? 0xffffffffu : ((1u << (8 * p.nz)) - 1u);
@@ -1551,7 +1580,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   auto release_tile = [&](uint32_t tile, uint32_t fill) {
     if (threadIdx.x < (uint32_t)TILE_DIRECT) a.tile_chunk[(size_t)tile * TILE_DIRECT + threadIdx.x] = 0;
     if (threadIdx.x == 8) a.tile_fill[tile] = 0;
-    if (threadIdx.x == 9) a.tile_dirty[tile] = 0;
     const uint32_t n_chunks = (fill + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
     if (n_chunks > (uint32_t)TILE_DIRECT)
     {
@@ -1591,11 +1619,8 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint32_t e0 = blockIdx.x;
-  if (e0 >= n_list)
+  if (e0 < n_list)
   {
-    if (threadIdx.x == 0) a.resolve_stats[blockIdx.x] = 0;
-    return;
-  }
   const uint32_t last = n_list - 1;
   // pipeline: tile i is processed while the voxel bytes / chunk table of tiles i+1 and i+2, the list entries up to i+3
   // and (from the middle of the iteration on) the records of tile i+1 are in flight
@@ -1870,6 +1895,84 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     te_n2 = te_n3;
   }
   write_back(post);
+  } // listed tiles
+
+  // ---- Tiles that are NOT on the list: no records, only marks of the free pass or of off-ray +tau candidates in the byte
+  // planes -- (tau, +64) / (tau, -64) where a mark is, nothing to fold.  They are found by scanning the per-tile flag planes
+  // (a byte per tile; the marches only ever STORE there: no atomic, no waiting in their loops), 16 tiles per thread and step,
+  // granule g of workgroup b = b + G k so that a cluster of such tiles spreads over the grid.  The scan owns both planes
+  // (it clears what it finds); the listed tiles above never look at them.
+  if (!HAS_S0)
+  {
+    uint32_t *found = reinterpret_cast<uint32_t *>(kpos); // 2048 tile ids (the fold above is over)
+    const int64_t n_gran = (a.n_tiles + 15) >> 4;
+    uint8_t *const flag_mark = a.tile_dirty, *const flag_listed = a.tile_dirty + tile_flag_plane_bytes(a.n_tiles);
+    __syncthreads();
+    if (threadIdx.x == 0) s_unres[0] = 0;
+    __syncthreads();
+    for (int64_t k0 = 0; (int64_t)blockIdx.x + (int64_t)G * k0 < n_gran; k0 += 128)
+    {
+      const int64_t g = (int64_t)blockIdx.x + (int64_t)G * (k0 + threadIdx.x);
+      if (threadIdx.x < 128 && g < n_gran)
+      {
+        const u32x4 d = *reinterpret_cast<const u32x4 *>(flag_mark + 16 * g), h = *reinterpret_cast<const u32x4 *>(flag_listed + 16 * g);
+        const uint32_t dw[4] = {d.x, d.y, d.z, d.w}, hw[4] = {h.x, h.y, h.z, h.w};
+        const u32x4 zero = {0, 0, 0, 0};
+        if (d.x | d.y | d.z | d.w) *reinterpret_cast<u32x4 *>(flag_mark + 16 * g) = zero;
+        if (h.x | h.y | h.z | h.w) *reinterpret_cast<u32x4 *>(flag_listed + 16 * g) = zero;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+          const uint32_t dj = (dw[j >> 2] >> (8 * (j & 3))) & 0xffu, hj = (hw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+          if (dj != 0 && hj == 0 && 16 * g + j < a.n_tiles) found[atomicAdd(&s_unres[0], 1u)] = (uint32_t)(16 * g + j);
+        }
+      }
+      __syncthreads();
+      const uint32_t n_found = s_unres[0];
+      if (n_found && threadIdx.x == 0) atomicAdd(&a.counters->last_unlisted, n_found);
+      for (uint32_t i = 0; i < n_found; ++i)
+      {
+        const uint32_t tile = found[i];
+        const int32_t tz = (int32_t)(tile % (uint32_t)a.ntz);
+        const uint32_t colt = tile / (uint32_t)a.ntz;
+        const int32_t ty = (int32_t)(colt % (uint32_t)a.nty), tx = (int32_t)(colt / (uint32_t)a.nty);
+        const int32_t sx = (tx << TILE_XB) + lx, sy = (ty << TILE_YB) + ly, sz = (tz << TILE_ZB) + z0;
+        const bool col_ok = sx < a.map.size[0] && sy < a.map.size[1];
+        int nz = a.map.size[2] - sz;
+        nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
+        const int64_t idx0 = nz ? storage_index(a.map, sx, sy, sz) : 0;
+        const uint32_t keep = nz >= 4 ? 0xffffffffu : ((1u << (8 * nz)) - 1u);
+        const uint32_t vs4 = (*reinterpret_cast<const u32_a1 *>(a.vstate + idx0) | ((*reinterpret_cast<const u32_a1 *>(vneg + idx0) & 0x01010101u) << 3)) & keep;
+        u32x4 ex = {0, 0, 0, 0};
+        if (FUSED) ex = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + idx0);
+        TilePost w;
+        w.idx0 = idx0;
+        w.nz = nz;
+        w.vs = vs4;
+        w.touched = 0;
+        w.existing[0] = ex.x; w.existing[1] = ex.y; w.existing[2] = ex.z; w.existing[3] = ex.w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          const uint32_t b = (vs4 >> (8 * j)) & 0xffu;
+          w.value[j] = pack_entry(a.tau, (b & VOX_TOUCHED) ? WEIGHT_RESOLUTION : -WEIGHT_RESOLUTION);
+          if (b & (VOX_TOUCHED | VOX_NEGFREE)) w.touched |= 1u << j;
+        }
+        write_back(w);
+        if (!FUSED && !aborted && threadIdx.x == 0)
+        {
+          TileEntry e;
+          e.tile = tile;
+          e.tx = tx; e.ty = ty; e.tz = tz;
+          a.tile_list_out[atomicAdd(&a.counters->n_listed, 1u)] = e;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_unres[0] = 0;
+      __syncthreads();
+    }
+  }
+
   // statistics: one slot per workgroup, no shared counter
   for (int d = 32; d > 0; d >>= 1) n_contested += __shfl_down(n_contested, d, 64);
   __shared__ uint32_t s_stat[4];
@@ -2275,6 +2378,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.resolve_stats = m->block_stats + 2 * WS_TAIL_STATS;
   ra.counters = m->counters;
   ra.status = m->status_dev;
+  ra.tile_list_out = m->tile_list;
+  ra.n_tiles = m->n_tiles;
   m->resolve_blocks = RESOLVE_GRID;
   prof_begin(ctx, WS_K_TILE_RESOLVE);
   if (s0)

@@ -68,12 +68,15 @@ __host__ __device__ inline bool rec_negative(uint64_t rec) { return (((uint32_t)
 
 // Records live in CHUNKS of 256 (2 KB) that belong to one tile each: a workgroup of the tail march stages its records in
 // LDS, reserves a range of the tile's record sequence with one atomic per (flush, tile) and copies them there, so HBM sees
-// every record once and the resolve reads a tile's records as whole chunks.  tile_fill[tile] counts the records (bit 31:
-// the free pass has put the tile on the list); tile_chunk[tile][j] = id + 1 of the chunk holding records 256 j ..; chunks
+// every record once and the resolve reads a tile's records as whole chunks.  tile_fill[tile] counts the records;
+// tile_chunk[tile][j] = id + 1 of the chunk holding records 256 j ..; chunks
 // beyond TILE_DIRECT are found through a small hash (tile, j) -> id (tiles of more than 2048 records: only a scan into a
 // non-default new_map, where every candidate is a record, has them).
 constexpr int CHUNK_BITS = 8, CHUNK_RECS = 1 << CHUNK_BITS, TILE_DIRECT = 8;
-constexpr uint32_t FILL_DIRTY = 0x80000000u;
+// per-tile bytes, two planes in one allocation (tile_flag_plane_bytes apart): [0] "the free pass / an off-ray mark touched the
+// tile" (plain idempotent byte stores), [1] "the tile is on the scan's list" (it has records).  The resolve visits the listed
+// tiles through the list and finds the others by scanning these planes.
+__host__ __device__ inline size_t tile_flag_plane_bytes(int64_t n_tiles) { return ((size_t)n_tiles + 16 + 255) & ~(size_t)255; }
 constexpr uint32_t CHUNK_NONE = 0u, CHUNK_LOST = 0xffffffffu; // not published yet / the chunk buffer was exhausted (scan aborted)
 
 struct TileEntry // 16 bytes: one touched tile of the scan in flight
@@ -99,6 +102,8 @@ struct TsdfCounters // device-resident
   uint32_t last_free_keyed;
   uint32_t last_chunks;
   unsigned long long last_need; // record bound of the last scan
+  uint32_t last_unlisted; // tiles without records (marks of the byte planes only) the resolve found by its scan
+  uint32_t pad1;
 };
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
@@ -162,9 +167,9 @@ struct ws_map
   // tile grid (4 x 4 x 64 voxels of storage space)
   int32_t ntx = 0, nty = 0, ntz = 0;
   int64_t n_tiles = 0;
-  uint32_t *tile_fill = nullptr;    // [n_tiles] records of the tile in the scan in flight | FILL_DIRTY (zero between scans)
+  uint32_t *tile_fill = nullptr;    // [n_tiles] records of the tile in the scan in flight (zero between scans)
   uint32_t *tile_chunk = nullptr;   // [n_tiles][TILE_DIRECT] chunk id + 1 (zero between scans)
-  uint8_t *tile_dirty = nullptr;    // [n_tiles] touched by the free-space pass (a cheap filter in front of the atomic that lists the tile)
+  uint8_t *tile_dirty = nullptr;    // two planes of [n_tiles] bytes (tile_flag_plane_bytes): touched by the free-space pass / an off-ray mark; on the list
   ws::TileEntry *tile_list = nullptr; // [n_tiles] touched tiles of the scan in flight
   // candidate records of the ray tails: chunks of 256 x 8 bytes
   unsigned long long *rec = nullptr;
