@@ -353,7 +353,7 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
   // chunks of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
   // every scan checks the buffer against its own bound and grows it first if it must, ws_tsdf_set_capacity() reserves up front
-  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20));
+  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20, 131072));
   if (rc != WS_OK)
   {
     map_free(m);

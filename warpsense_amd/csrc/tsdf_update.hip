@@ -61,7 +61,7 @@ struct ScatterArgs
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
   uint32_t *tile_fill;  // [tiles] records of the tile
   uint32_t *tile_chunk; // [tiles][TILE_DIRECT] chunk id + 1
-  TileEntry *tile_list;
+  TileEntry *tile_list; // the tiles with records (the first reservation of a tile appends it; the resolve deals them out evenly)
   unsigned long long *rec; // chunks of CHUNK_RECS records
   uint32_t chunk_cap;
   uint32_t scan_seq;  // sequence number of this scatter
@@ -160,10 +160,15 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
 // chunk, so sum over tiles of ceil(r / 256) <= need / 256 + min(tiles, need).  est_shift != 0 (maps whose tile term alone
 // would cost gigabytes): an estimate instead -- the bound counts every sample as a candidate, about 2.3 x what a scan
 // makes -- and a scan that does exhaust the chunks is ABORTED (nothing of it reaches the maps) and repeated with more.
-__host__ __device__ inline unsigned long long chunks_needed(unsigned long long need, unsigned long long n_tiles, uint32_t est_shift)
+// On top of either: the workgroups of the tail march take chunk ids in blocks of CHUNK_BLOCK (one request to the shared
+// counter per block instead of one per flush) and leave the rest of their last block unused.
+constexpr uint32_t CHUNK_BLOCK = 32;
+__host__ __device__ inline unsigned long long chunks_needed(unsigned long long need, unsigned long long n_tiles, uint32_t est_shift, unsigned long long n_points)
 {
-  if (est_shift) return ((need >> CHUNK_BITS) >> (est_shift - 1)) + 4096ull;
-  return (need >> CHUNK_BITS) + (n_tiles < need ? n_tiles : need) + 64ull;
+  const unsigned long long blocks = ((n_points + 63) / 64 * 2 + 1) * CHUNK_BLOCK; // (TAIL_SPLIT == 2 workgroups per 64 rays)
+  if (est_shift) return ((need >> CHUNK_BITS) >> (est_shift - 1)) + 4096ull + blocks;
+  const unsigned long long used = (need >> CHUNK_BITS) + (n_tiles < need ? n_tiles : need);
+  return used + used / 4 + blocks + 64ull; // (a refill leaves up to a quarter of a block behind)
 }
 
 // Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
@@ -533,25 +538,29 @@ struct Reserve
   uint32_t p0;    // position of the first record
   uint32_t j_new; // first chunk number to open
   uint32_t n_new; // chunks to open
-  bool first;     // nobody has touched the tile in this scan: put it on the list
 };
-__device__ __forceinline__ Reserve tile_reserve(const ScatterArgs &a, uint32_t tile, uint32_t c)
+__device__ __forceinline__ Reserve reserve_from(uint32_t old_fill, uint32_t c)
 {
-  const uint32_t old = __hip_atomic_fetch_add(&a.tile_fill[tile], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   Reserve r;
-  r.first = old == 0;
-  r.p0 = old;
+  r.p0 = old_fill;
   r.j_new = (r.p0 + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
   const uint32_t j_last = (r.p0 + c - 1u) >> CHUNK_BITS;
   r.n_new = j_last >= r.j_new ? j_last - r.j_new + 1u : 0u;
   return r;
 }
-// chunks (low word) and list entries (high word) come from ONE counter: a workgroup asks once per flush
-__device__ __forceinline__ unsigned long long alloc_add(const ScatterArgs &a, unsigned long long chunks_and_listed)
+__device__ __forceinline__ uint32_t chunk_id1(const ScatterArgs &a, uint32_t cid)
 {
-  return __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&a.counters->chunk_cursor), chunks_and_listed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cid < a.chunk_cap) return cid + 1u;
+  raise_abort(a);
+  return CHUNK_LOST;
 }
-static_assert(offsetof(TsdfCounters, chunk_cursor) == 0 && offsetof(TsdfCounters, n_listed) == 4, "chunk_cursor | n_listed << 32 is one 64-bit counter");
+// chunk number j of `tile` is chunk `cid`: into the tile's table
+__device__ __forceinline__ void open_chunk(const ScatterArgs &a, uint32_t tile, uint32_t j, uint32_t cid)
+{
+  chunk_publish(a, tile, j, chunk_id1(a, cid));
+}
+// the tile got its first records: entry `at` of the scan's tile list, and the flag byte that keeps the resolve's scan for
+// tiles WITHOUT records away from it
 __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uint32_t tile)
 {
   TileEntry e;
@@ -561,13 +570,7 @@ __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uin
   e.ty = (int32_t)(col % (uint32_t)a.nty);
   e.tx = (int32_t)(col / (uint32_t)a.nty);
   a.tile_list[at] = e;
-  a.tile_dirty[tile_flag_plane_bytes((int64_t)a.ntx * a.nty * a.ntz) + tile] = 1; // the resolve's scan for unlisted tiles skips it
-}
-__device__ __forceinline__ uint32_t chunk_id1(const ScatterArgs &a, uint32_t cid)
-{
-  if (cid < a.chunk_cap) return cid + 1u;
-  raise_abort(a);
-  return CHUNK_LOST;
+  a.tile_dirty[tile_flag_plane_bytes((int64_t)a.ntx * a.nty * a.ntz) + tile] = 1;
 }
 __device__ __forceinline__ void store_rec(const ScatterArgs &a, uint32_t id1, uint32_t q, unsigned long long rec)
 {
@@ -577,19 +580,24 @@ __device__ __forceinline__ void store_rec(const ScatterArgs &a, uint32_t id1, ui
 // one record, straight to its tile (a free-space candidate on a keyed voxel; the tail march when its staging area cannot
 // take a record).  All lanes publish what they have to open BEFORE any lane polls (two regions, in this order: a lane
 // may be waiting for a chunk a neighbouring lane of its own wave opens).
-__device__ __forceinline__ void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
+#ifndef WS_APPEND_INLINE
+#define WS_APPEND_INLINE 1
+#endif
+#if WS_APPEND_INLINE
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
 {
-  const Reserve r = tile_reserve(a, tile, 1u);
+  const Reserve r = reserve_from(__hip_atomic_fetch_add(&a.tile_fill[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
   uint32_t id1 = CHUNK_NONE;
-  if (r.first || r.n_new)
+  if (r.n_new)
   {
-    const unsigned long long got = alloc_add(a, (unsigned long long)r.n_new | ((unsigned long long)(r.first ? 1u : 0u) << 32));
-    if (r.first) list_tile(a, (uint32_t)(got >> 32), tile);
-    if (r.n_new)
-    {
-      id1 = chunk_id1(a, (uint32_t)got);
-      chunk_publish(a, tile, r.j_new, id1);
-    }
+    const uint32_t cid = __hip_atomic_fetch_add(&a.counters->chunk_cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    id1 = chunk_id1(a, cid);
+    open_chunk(a, tile, r.j_new, cid);
+    if (r.p0 == 0) list_tile(a, __hip_atomic_fetch_add(&a.counters->n_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tile);
   }
   asm volatile("" ::: "memory");
   if (id1 == CHUNK_NONE) id1 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
@@ -612,7 +620,7 @@ constexpr int HT_BITS = 8, HT_SLOTS = 1 << HT_BITS; // tiles a workgroup can sta
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
 constexpr int TAIL_STAGE = WS_TAIL_STAGE;
-static_assert(TAIL_STAGE >= 64 * REC_MAX_FAN && TAIL_STAGE <= 65535, "one emit phase (64 samples with the widest fan) must fit the staging area");
+static_assert(TAIL_STAGE >= 256 && TAIL_STAGE <= 65535, "staging slots are 16-bit; an emit phase whose records exceed the whole area (fans wider than TAIL_STAGE / 64) goes straight to the tiles");
 static_assert(HT_SLOTS == 256, "the flush gives every thread one slot of the tile table");
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 constexpr uint16_t SLOT_NONE = 0xffffu;
@@ -677,7 +685,7 @@ __device__ __forceinline__ bool scan_fits(const ScatterArgs &a)
   // them on one address -- this line alone took the tail march from 190 to 500 us.)
   const unsigned long long need = a.counters->ub_total & ((1ull << 48) - 1ull);
   const unsigned long long n_tiles = (unsigned long long)a.ntx * (unsigned long long)a.nty * (unsigned long long)a.ntz;
-  return chunks_needed(need, n_tiles, a.est_shift) <= (unsigned long long)a.chunk_cap;
+  return chunks_needed(need, n_tiles, a.est_shift, a.n) <= (unsigned long long)a.chunk_cap;
 }
 
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
@@ -709,18 +717,28 @@ struct TailShared
   unsigned long long rec[TAIL_STAGE];
   uint16_t slot[TAIL_STAGE]; // slot of the record's tile in the table below (SLOT_NONE: the record went straight to its tile)
   uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c0[HT_SLOTS], ht_c1[HT_SLOTS];
-  unsigned long long wave_sums[4];
-  unsigned long long alloc;
+  uint32_t block_base, block_next; // this workgroup's block of chunk ids and how many of them are taken
+  uint32_t n_first, list_base;     // tiles this flush is the first to reserve in, and where they go in the scan's tile list
   uint32_t cursor, done, n_records, n_groups;
 #ifdef WS_TAIL_TIMING
   uint32_t t_flush[5];
 #endif
 };
 
-// The staged records go to their tiles: thread t owns slot t of the tile table.  One reservation per tile (its count is
-// known), ONE request to the shared chunk / list counter per workgroup, then every record is copied to
-// chunk(position >> 8)[position & 255].  total: staged records (uniform).
-__device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
+// The staged records go to their tiles: thread t owns slot t of the tile table.  ONE memory round trip in front of the copy:
+// the reservation in the tile's record sequence (its count is known) travels together with a read of the tile's chunk
+// table, the chunks the range opens come out of the workgroup's own block of ids (an LDS counter), and the chunk the range
+// starts in -- opened by whoever reserved its first record -- is in the table that was read along, unless that happened
+// in these very microseconds (then: poll).  total: staged records (uniform).
+#ifndef WS_FLUSH_INLINE
+#define WS_FLUSH_INLINE 1
+#endif
+#if WS_FLUSH_INLINE
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
 {
   const int t = threadIdx.x;
 #ifdef WS_TAIL_TIMING
@@ -728,32 +746,33 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
   tf[0] = wall_clock64();
 #endif
   const uint32_t c = sh.ht_cnt[t], tile = sh.ht_key[t];
-  Reserve r;
-  r.p0 = r.j_new = r.n_new = 0;
-  r.first = false;
-  if (c) r = tile_reserve(a, tile, c);
-  unsigned long long all = 0;
-  const unsigned long long mine = (unsigned long long)r.n_new | ((unsigned long long)(r.first ? 1u : 0u) << 32);
-  const unsigned long long excl = block_scan_u64(mine, sh.wave_sums, all);
+  uint32_t old_fill = 0;
+  unsigned long long tab[TILE_DIRECT / 2] = {0, 0, 0, 0};
+  if (c)
+  {
+    old_fill = __hip_atomic_fetch_add(&a.tile_fill[tile], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long *tp = reinterpret_cast<const unsigned long long *>(a.tile_chunk + (size_t)tile * TILE_DIRECT);
+#pragma unroll
+    for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[q] = __hip_atomic_load(tp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const Reserve r = reserve_from(old_fill, c ? c : 1u);
+  // the first reservation of a tile in this scan puts it on the tile list: one request to the list's counter per workgroup,
+  // sent now, needed behind the copy (its round trip runs under it)
+  const bool first = c != 0 && old_fill == 0;
+  const uint32_t first_rank = first ? atomicAdd(&sh.n_first, 1u) : 0u;
+  uint32_t cid = 0;
+  if (c && r.n_new)
+  {
+    const uint32_t k = atomicAdd(&sh.block_next, r.n_new);
+    if (k + r.n_new <= CHUNK_BLOCK)
+      cid = sh.block_base + k;
+    else // (the block is used up: this group asks the shared counter itself; the block is renewed at the end of the flush)
+      cid = __hip_atomic_fetch_add(&a.counters->chunk_cursor, r.n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t q = 0; q < r.n_new; ++q) open_chunk(a, tile, r.j_new + q, cid + q);
+  }
 #ifdef WS_TAIL_TIMING
   tf[1] = wall_clock64();
 #endif
-  if (t == 0)
-  {
-    sh.alloc = all ? alloc_add(a, all) : 0ull;
-    sh.n_records += total;
-  }
-  __syncthreads();
-#ifdef WS_TAIL_TIMING
-  tf[2] = wall_clock64();
-#endif
-  const unsigned long long got = sh.alloc + excl;
-  const uint32_t cid = (uint32_t)got;
-  if (c)
-  {
-    if (r.first) list_tile(a, (uint32_t)(got >> 32), tile);
-    for (uint32_t q = 0; q < r.n_new; ++q) chunk_publish(a, tile, r.j_new + q, chunk_id1(a, cid + q));
-  }
   asm volatile("" ::: "memory"); // everything this wave opens is published before any of its lanes polls
   if (c)
   {
@@ -766,7 +785,10 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
     }
     else
     {
-      c0 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
+      const uint32_t j0 = r.p0 >> CHUNK_BITS;
+      const unsigned long long w = j0 < 2 ? tab[0] : (j0 < 4 ? tab[1] : (j0 < 6 ? tab[2] : tab[3]));
+      c0 = j0 < (uint32_t)TILE_DIRECT ? (uint32_t)((j0 & 1u) ? (w >> 32) : w) : CHUNK_NONE;
+      if (c0 == CHUNK_NONE) c0 = chunk_lookup(a, tile, j0);
       if (r.n_new >= 1) c1 = chunk_id1(a, cid);
     }
     sh.ht_base[t] = r.p0;
@@ -776,37 +798,73 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
     atomicAdd(&sh.n_groups, 1u);
   }
   __syncthreads();
+  uint32_t list_base = 0;
+  if (t == 0 && sh.n_first) list_base = __hip_atomic_fetch_add(&a.counters->n_listed, sh.n_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef WS_TAIL_TIMING
-  tf[3] = wall_clock64();
+  tf[2] = wall_clock64();
 #endif
-  for (uint32_t i = (uint32_t)t; i < total; i += 256u)
+  // the copy, four records per thread and step: the LDS reads of all four, then their cursor atomics, then the stores
+#ifndef WS_COPY_U
+#define WS_COPY_U 4
+#endif
+  constexpr int CU = WS_COPY_U;
+  for (uint32_t i0 = (uint32_t)t; i0 < total; i0 += 256u * CU)
   {
-    const uint32_t slot = sh.slot[i];
-    if (slot == SLOT_NONE) continue;
-    const unsigned long long rec = sh.rec[i];
-    const uint32_t base = sh.ht_base[slot];
-    const uint32_t q = base + atomicAdd(&sh.ht_cnt[slot], 1u);
-    const uint32_t jrel = (q >> CHUNK_BITS) - (base >> CHUNK_BITS);
-    // (a group of more than two chunks -- one tile took most of the staging area -- finds the others through the tile's table;
-    // this workgroup published them above)
-    const uint32_t id1 = jrel == 0 ? sh.ht_c0[slot] : (jrel == 1 ? sh.ht_c1[slot] : chunk_lookup(a, sh.ht_key[slot], q >> CHUNK_BITS));
-    store_rec(a, id1, q, rec);
+    uint32_t slot[CU], base[CU], q[CU];
+    unsigned long long rec[CU];
+#pragma unroll
+    for (int u = 0; u < CU; ++u)
+    {
+      const uint32_t i = i0 + 256u * (uint32_t)u;
+      slot[u] = i < total ? (uint32_t)sh.slot[i] : (uint32_t)SLOT_NONE;
+      rec[u] = sh.rec[i < total ? i : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u)
+    {
+      const uint32_t sl = slot[u] != SLOT_NONE ? slot[u] : 0u;
+      base[u] = sh.ht_base[sl];
+      q[u] = slot[u] != SLOT_NONE ? base[u] + atomicAdd(&sh.ht_cnt[sl], 1u) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u)
+    {
+      if (slot[u] == SLOT_NONE) continue;
+      const uint32_t jrel = (q[u] >> CHUNK_BITS) - (base[u] >> CHUNK_BITS);
+      // (a group of more than two chunks -- one tile took most of the staging area -- finds the others through the tile's table;
+      // this workgroup published them above)
+      const uint32_t id1 = jrel == 0 ? sh.ht_c0[slot[u]] : (jrel == 1 ? sh.ht_c1[slot[u]] : chunk_lookup(a, sh.ht_key[slot[u]], q[u] >> CHUNK_BITS));
+      store_rec(a, id1, q[u], rec[u]);
+    }
   }
   __syncthreads();
 #ifdef WS_TAIL_TIMING
-  tf[4] = wall_clock64();
+  tf[3] = wall_clock64();
   if (t == 0)
   {
     sh.t_flush[0] += (uint32_t)(tf[1] - tf[0]);
     sh.t_flush[1] += (uint32_t)(tf[2] - tf[1]);
     sh.t_flush[2] += (uint32_t)(tf[3] - tf[2]);
-    sh.t_flush[3] += (uint32_t)(tf[4] - tf[3]);
     sh.t_flush[4] += 1;
   }
 #endif
+  if (t == 0) sh.list_base = list_base;
+  __syncthreads();
+  if (first) list_tile(a, sh.list_base + first_rank, tile);
   sh.ht_key[t] = HT_EMPTY;
   sh.ht_cnt[t] = 0;
-  if (t == 0) sh.cursor = 0;
+  if (t == 0)
+  {
+    sh.cursor = 0;
+    sh.n_first = 0;
+    sh.n_records += total;
+    if (sh.block_next + CHUNK_BLOCK / 4 > CHUNK_BLOCK)
+    {
+      // a new block of ids for the flushes to come (what is left of the old one stays unused: chunks_needed() counts it)
+      sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh.block_next = 0;
+    }
+  }
   __syncthreads();
 }
 
@@ -841,6 +899,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     sh.done = 0;
     sh.n_records = 0;
     sh.n_groups = 0;
+    sh.block_next = 0;
+    sh.n_first = 0;
 #ifdef WS_TAIL_TIMING
     for (int q = 0; q < 5; ++q) sh.t_flush[q] = 0;
 #endif
@@ -848,6 +908,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   sh.ht_key[threadIdx.x] = HT_EMPTY;
   sh.ht_cnt[threadIdx.x] = 0;
   __syncthreads();
+  // the workgroup's block of chunk ids: requested now, needed at the first flush (only the first wave waits for it)
+  if (threadIdx.x == 0) sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
   const bool mark = !a.all_keyed;
@@ -985,7 +1047,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     const uint32_t incl = wave_incl_scan(nrec);
     const uint32_t batch = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     uint32_t base = 0;
-    if (batch)
+    const bool fits = batch <= (uint32_t)TAIL_STAGE; // (else: fans so wide that 64 samples overflow the whole area -- record by record to the tiles)
+    if (batch && fits)
     {
       if (lane == 0) base = stage_reserve(&sh.cursor, batch);
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -993,7 +1056,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     }
     qhead += n;
     if (batch == 0) return true;
-    uint32_t pos = base + incl - nrec;
+    uint32_t pos = fits ? base + incl - nrec : 0x80000000u;
     const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
                   lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
     auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
@@ -1109,8 +1172,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
 #ifdef WS_TAIL_TIMING
     if ((item & 255u) == 7u)
-      printf("tail item %u: %u records %u groups %u flushes | total %lld ticks, flush: reserve+scan %u, alloc %u, publish+lookup %u, copy %u (10 ns ticks)\n", item, sh.n_records,
-             sh.n_groups, sh.t_flush[4], wall_clock64() - t_item0, sh.t_flush[0], sh.t_flush[1], sh.t_flush[2], sh.t_flush[3]);
+      printf("tail item %u: %u records %u groups %u flushes | total %lld ticks, flush: reserve + open %u, look-up %u, copy %u (10 ns ticks)\n", item, sh.n_records,
+             sh.n_groups, sh.t_flush[4], wall_clock64() - t_item0, sh.t_flush[0], sh.t_flush[1], sh.t_flush[2]);
 #endif
   }
 }
@@ -1355,7 +1418,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 // ---------------------------------------------------------------------------------------------------------
 struct ResolveArgs
 {
-  const TileEntry *tile_list;
+  TileEntry *tile_list; // the tiles with records; the resolve appends the others it finds when a separate integrate pass follows
   uint32_t *tile_fill;
   uint32_t *tile_chunk;
   uint8_t *tile_dirty;
@@ -1371,10 +1434,9 @@ struct ResolveArgs
   int32_t tau, max_weight;
   uint32_t wM32;     // division by tau - tau/10 of the weight ramp (update_tsdf.cu:92) as one v_mul_hi_u32 + shift
   int32_t wS;
-  uint32_t *resolve_stats; // [grid]: contested voxels
+  uint32_t *resolve_stats; // [grid][2]: contested voxels, tiles with records
   TsdfCounters *counters;
   uint32_t *status;
-  TileEntry *tile_list_out; // == tile_list: the tiles found by the scan of the flag planes are appended for a separate integrate pass
   int64_t n_tiles;
 };
 static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
@@ -1433,7 +1495,7 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
 #define WS_RES_MAXR 8
 #endif
 #ifndef WS_RESOLVE_WGS
-#define WS_RESOLVE_WGS 4
+#define WS_RESOLVE_WGS 5 // (107 -> 102 VGPRs without spills, 29 KB of LDS: 4 -> 5 workgroups per CU, 139 -> 130 us)
 #endif
 constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
 static_assert(RES_MAXR <= TILE_DIRECT, "the register route reads the chunks of the tile's direct table");
@@ -1489,7 +1551,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
   __shared__ uint32_t s_unres[2];
-  const uint32_t n_list = a.counters->n_listed;
+  const uint32_t n_list = a.counters->n_listed; // the tiles with records
   const bool aborted = a.counters->abort != 0;
   const int32_t weight_epsilon = a.tau / 10;
   const uint32_t reset = pack_entry(a.tau, 0);
@@ -1611,14 +1673,16 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   {
     TsdfCounters *c = a.counters;
     c->last_chunks = c->chunk_cursor;
-    c->last_listed = n_list;
     c->last_need = c->ub_total & ((1ull << 48) - 1ull);
     c->ub_total = 0;
     __hip_atomic_store(a.status + 10, c->big_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 9, aborted ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  // The tiles with records: the scan's tile list (the marches appended every tile at its first reservation), dealt out
+  // evenly: workgroup b takes the entries b, b + G, ...
   const uint32_t e0 = blockIdx.x;
+  uint32_t n_mine = 0; // tiles this workgroup has folded
   if (e0 < n_list)
   {
   const uint32_t last = n_list - 1;
@@ -1651,6 +1715,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
   for (uint32_t e = e0; e < n_list; e += G)
   {
+    n_mine += 1;
     const TilePre p = p_cur;
     const uint32_t tile = tile_cur, fill = p.fill;
     const int nz = p.nz;
@@ -1964,7 +2029,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           TileEntry e;
           e.tile = tile;
           e.tx = tx; e.ty = ty; e.tz = tz;
-          a.tile_list_out[atomicAdd(&a.counters->n_listed, 1u)] = e;
+          a.tile_list[atomicAdd(&a.counters->n_listed, 1u)] = e;
         }
       }
       __syncthreads();
@@ -1978,7 +2043,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint32_t s_stat[4];
   if ((threadIdx.x & 63) == 0) s_stat[threadIdx.x >> 6] = n_contested;
   __syncthreads();
-  if (threadIdx.x == 0) a.resolve_stats[blockIdx.x] = s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
+  if (threadIdx.x == 0)
+  {
+    a.resolve_stats[2 * blockIdx.x + 0] = s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
+    a.resolve_stats[2 * blockIdx.x + 1] = n_mine;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2044,24 +2113,31 @@ __global__ __launch_bounds__(256) void tsdf_stats_kernel(TsdfCounters *c, const 
                                                          uint32_t n_resolve)
 {
   __shared__ uint32_t part[12];
-  uint32_t rec = 0, con = 0, grp = 0;
+  uint32_t rec = 0, con = 0, grp = 0, til = 0;
   for (uint32_t i = threadIdx.x; i < n_tail; i += 256)
   {
     rec += tail_stats[i];
     grp += tail_stats[WS_TAIL_STATS + i];
   }
-  for (uint32_t i = threadIdx.x; i < n_resolve; i += 256) con += resolve_stats[i];
+  for (uint32_t i = threadIdx.x; i < n_resolve; i += 256)
+  {
+    con += resolve_stats[2 * i + 0];
+    til += resolve_stats[2 * i + 1];
+  }
   for (int d = 32; d > 0; d >>= 1)
   {
     rec += __shfl_down(rec, d, 64);
     con += __shfl_down(con, d, 64);
     grp += __shfl_down(grp, d, 64);
+    til += __shfl_down(til, d, 64);
   }
+  __shared__ uint32_t part4[4];
   if ((threadIdx.x & 63) == 0)
   {
     part[(threadIdx.x >> 6) * 3 + 0] = rec;
     part[(threadIdx.x >> 6) * 3 + 1] = con;
     part[(threadIdx.x >> 6) * 3 + 2] = grp;
+    part4[threadIdx.x >> 6] = til;
   }
   __syncthreads();
   if (threadIdx.x == 0)
@@ -2069,6 +2145,7 @@ __global__ __launch_bounds__(256) void tsdf_stats_kernel(TsdfCounters *c, const 
     c->last_records = part[0] + part[3] + part[6] + part[9] + c->last_free_keyed; // tail records + free-space candidates that joined them
     c->last_contested = part[1] + part[4] + part[7] + part[10];
     c->last_runs = part[2] + part[5] + part[8] + part[11];
+    c->last_listed = part4[0] + part4[1] + part4[2] + part4[3];
   }
 }
 int launch_tsdf_stats(ws_map *m)
@@ -2255,7 +2332,7 @@ static uint32_t est_shift_of(const ws_map *m)
   if ((uint64_t)m->n_tiles * CHUNK_RECS * sizeof(unsigned long long) <= budget) return 0;
   return m->est_shift ? m->est_shift : 1u;
 }
-uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records) { return chunks_needed(need_records, (uint64_t)m->n_tiles, est_shift_of(m)); }
+uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points) { return chunks_needed(need_records, (uint64_t)m->n_tiles, est_shift_of(m), n_points); }
 
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
@@ -2378,7 +2455,6 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   ra.resolve_stats = m->block_stats + 2 * WS_TAIL_STATS;
   ra.counters = m->counters;
   ra.status = m->status_dev;
-  ra.tile_list_out = m->tile_list;
   ra.n_tiles = m->n_tiles;
   m->resolve_blocks = RESOLVE_GRID;
   prof_begin(ctx, WS_K_TILE_RESOLVE);
@@ -2419,7 +2495,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     int rc = wait_word(6, "TSDF update: the set-up pass did not report its record bound");
     if (rc != WS_OK) return rc;
     const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
-    const uint64_t want = chunks_for_scan(m, need);
+    const uint64_t want = chunks_for_scan(m, need, n);
     bool again = false;
     uint64_t grow_to = 0;
     if (want > m->chunk_cap)
@@ -2454,6 +2530,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     if (rc != WS_OK) return rc;
     sa.rec = m->rec;
     sa.chunk_cap = m->chunk_cap;
+    sa.tile_list = m->tile_list;
     sa.big_keys = m->big_keys;
     sa.big_mask = m->big_slots - 1;
     sa.scan_seq = ++m->scan_seq;

@@ -88,7 +88,7 @@ struct TileEntry // 16 bytes: one touched tile of the scan in flight
 struct TsdfCounters // device-resident
 {
   uint32_t chunk_cursor;  // chunks handed out (reset by the set-up pass of the next scan)
-  uint32_t n_listed;      // touched tiles (length of the tile list; survives until the next scatter)
+  uint32_t n_listed;      // tiles with records (length of the tile list; the resolve appends the other touched tiles when a separate integrate pass follows; survives until the next scatter)
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
   uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
@@ -286,7 +286,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
 int resize_records(ws_map *m, uint64_t chunks); // api.hip: (re)allocate the chunk buffer (waits for the stream)
-uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records); // chunks the map's buffer must hold for a scan of that record bound (hard bound, or the estimate for huge maps)
+uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points); // chunks the map's buffer must hold for a scan of that record bound (hard bound, or the estimate for huge maps)
 int launch_tsdf_integrate(ws_map *m);
 int launch_tsdf_stats(ws_map *m); // fills the last_* statistics of TsdfCounters from the per-workgroup slots
 int launch_box_copy(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
