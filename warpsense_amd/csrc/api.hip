@@ -182,21 +182,26 @@ static void map_free_records(ws_map *m)
   m->rec = nullptr;
   m->big_keys = nullptr;
   m->chunk_cap = 0;
+  m->raw_cap = 0;
   m->big_slots = 0;
 }
 
-// candidate records of the ray tails: chunks of 256 x 8 bytes that belong to one tile each, and the (tile, chunk number) ->
-// chunk hash for tiles of more than TILE_DIRECT chunks (two slots per chunk; keys, then uint32 values)
-static int map_alloc_records(ws_map *m, uint64_t chunks)
+// candidate records of the ray tails: chunks of 256 x 8 bytes that belong to one tile each, behind them the raw buffer (16
+// bytes per record on its way from the march to its chunk), and the (tile, chunk number) -> chunk hash for tiles of more
+// than TILE_DIRECT chunks (two slots per chunk; keys, then uint32 values)
+static int map_alloc_records(ws_map *m, uint64_t chunks, uint64_t raw_records)
 {
   if (chunks < 4096) chunks = 4096;
   if (chunks > 0xfffffff0ull) chunks = 0xfffffff0ull;
+  if (raw_records < (1u << 16)) raw_records = 1u << 16;
+  if (raw_records > 0xfffffff0ull) raw_records = 0xfffffff0ull;
   map_free_records(m);
   uint64_t slots = 1u << 16;
   while (slots < 2 * chunks && slots < (1ull << 31)) slots <<= 1;
-  WS_HIP(hipMalloc((void **)&m->rec, (size_t)chunks * CHUNK_RECS * sizeof(unsigned long long)));
+  WS_HIP(hipMalloc((void **)&m->rec, (size_t)chunks * CHUNK_RECS * sizeof(unsigned long long) + (size_t)raw_records * 16));
   WS_HIP(hipMalloc((void **)&m->big_keys, (size_t)slots * (sizeof(unsigned long long) + sizeof(uint32_t))));
   m->chunk_cap = (uint32_t)chunks;
+  m->raw_cap = (uint32_t)raw_records;
   m->big_slots = (uint32_t)slots;
   m->prepped = false; // the new hash is filled by the stand-alone preparation pass
   return WS_OK;
@@ -353,7 +358,7 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
   // chunks of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
   // every scan checks the buffer against its own bound and grows it first if it must, ws_tsdf_set_capacity() reserves up front
-  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20, 131072));
+  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20, 131072), 36ull << 20);
   if (rc != WS_OK)
   {
     map_free(m);
@@ -675,7 +680,7 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  return map_alloc_records(m, (records + CHUNK_RECS - 1) / CHUNK_RECS);
+  return map_alloc_records(m, (records + CHUNK_RECS - 1) / CHUNK_RECS, records);
 }
 
 int ws_debug_tsdf_chunk_policy(ws_map *m, uint64_t budget_bytes, uint32_t est_shift)
@@ -1359,9 +1364,9 @@ int ws_prof_reset(ws_context *ctx)
 
 namespace ws
 {
-int resize_records(ws_map *m, uint64_t chunks)
+int resize_records(ws_map *m, uint64_t chunks, uint64_t raw_records)
 {
   WS_HIP(hipStreamSynchronize(m->ctx->stream)); // nothing enqueued may still use the old buffers
-  return map_alloc_records(m, chunks);
+  return map_alloc_records(m, chunks, raw_records);
 }
 } // namespace ws

@@ -68,6 +68,8 @@ struct ScatterArgs
   unsigned long long *big_keys; // (tile, chunk number) -> chunk id beyond TILE_DIRECT: keys, then uint32 values (big_mask + 1 slots)
   uint32_t big_mask;
   uint32_t est_shift; // != 0: the chunk buffer is sized by estimate (need >> (est_shift - 1)), not by the hard bound: see chunks_needed()
+  uint32_t raw_cap;   // records the raw buffer holds (it lies behind the chunks: rec + chunk_cap * 256 * 8 bytes, 16 bytes per record)
+  uint32_t pad0;
   uint32_t *tail_stats; // records / flush groups per workgroup of the tail march
   TsdfCounters *counters;
   uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number, [8] / [9] see ws_map::status_host
@@ -79,9 +81,6 @@ constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
-#ifndef WS_FUSE_SETUP
-#define WS_FUSE_SETUP 0 // 1: ray set-up and direction sort in one launch (sort blocks wait for the set-up blocks)
-#endif
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
 #endif
@@ -190,20 +189,22 @@ __device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1,
 }
 
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
-__device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n_setup_blocks)
+__device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
 {
-  __shared__ unsigned long long ub_wave[4];
+  __shared__ unsigned long long ub_wave[8];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix == 0)
   {
     // what the marches of this scan count up (the previous scan's integrate pass has read its tile list by now)
     a.counters->chunk_cursor = 0;
+    a.counters->raw_cursor = 0;
     a.counters->n_listed = 0;
     a.counters->abort = 0;
     a.counters->error = 0;
     a.counters->last_free_keyed = 0;
     a.counters->last_unlisted = 0;
   }
+  unsigned long long ub_tail = 0;
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
@@ -317,7 +318,8 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
           r.kfirst = kfirst;
           // records this ray can make: the scatter targets of its tail + one per free-space step (a free-space candidate that
           // lands on a voxel with records joins them)
-          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps) + (unsigned long long)kfirst;
+          ub_tail = tail_bound(kfirst, steps, len_end, a.fan_steps);
+          const unsigned long long ub = ub_tail + (unsigned long long)kfirst;
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
@@ -347,49 +349,46 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a, uint32_t n
                        __HIP_MEMORY_SCOPE_AGENT);
     a.rays[ix] = r;
   }
-  // The record slots this scan can need (sum of the per-ray bounds): one 64-bit add per workgroup; the last workgroup to
-  // get here hands the total to the host (host-mapped memory: value, then the sequence number the host spins on), which
-  // sizes the record buffers BEFORE it enqueues the tail march -- the capacity never rests on a guess.
+  // The records this scan can make (sum of the per-ray bounds): every scan sizes the record buffers itself.
   unsigned long long ub = r.ub;
-  for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
-  if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this lane's (bin, rank) has been written through ...
-  __syncthreads();                                  // ... and so has everybody else's in the workgroup
+  for (int d = 32; d > 0; d >>= 1)
+  {
+    ub += __shfl_down(ub, d, 64);
+    ub_tail += __shfl_down(ub_tail, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0)
+  {
+    ub_wave[threadIdx.x >> 6] = ub;
+    ub_wave[4 + (threadIdx.x >> 6)] = ub_tail;
+  }
+  __syncthreads();
   if (threadIdx.x == 0)
   {
-    const unsigned long long t = ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3];
-    // ONE atomic per workgroup carries both the sum and the arrival count (bits 48..: workgroups, at most 3907 of them;
-    // below: record slots, < 2^32): the workgroup that finds everybody else's count in the old value also has the total in
-    // it -- no second atomic, no read-back, and no cache-wide fence (an agent-scope release / acquire pair walks the XCD's
-    // L2: 15-20 us on this kernel, measured; two dependent returning atomics + a coherent load: ~5 us at the kernel's tail).
-    const unsigned long long before = __hip_atomic_fetch_add(&a.counters->ub_total, t + (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)(before >> 48) == n_setup_blocks - 1)
-    {
-      const unsigned long long total = (before & ((1ull << 48) - 1ull)) + t;
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    // two fire-and-forget adds per workgroup: the records the scan can make (tails + free-space steps: what the chunks must
+    // hold) and the tail records alone (what the raw buffer must hold).  The direction sort -- the next launch -- hands the
+    // totals to the host.
+    atomicAdd(&a.counters->ub_tail, ub_wave[4] + ub_wave[5] + ub_wave[6] + ub_wave[7]);
+    atomicAdd(&a.counters->ub_total, ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3]);
   }
 }
 
-// Counting sort of the rays by direction bin, in the SAME launch as the set-up: blocks [0, S) are the set-up blocks above,
-// blocks [S, 2S) wait until all of them have counted (workgroups are dispatched in index order, so a sort block can only be
-// on the chip when every set-up block is there or done: no deadlock whatever the grid size) and place the rays.  One launch
-// and its ~10 us of dependent start-up less on the critical path.  Every sort block scans the 8193-entry histogram itself
-// (32 KB, one block scan).
-template <bool FUSED>
-__device__ __forceinline__ void ray_sort_block(const ScatterArgs &a, uint32_t n_setup_blocks)
+// Counting sort of the rays by direction bin (a launch of its own behind the set-up pass: fused into it, with the sort
+// blocks waiting for the set-up blocks' arrival count, it measured 50 us against 37 for two launches -- the waiting blocks'
+// polls queue in front of the adds they wait for).  Every sort block scans the 8193-entry histogram itself (32 KB, one block
+// scan).  Block 0 also hands the scan's record bounds to the host (host-mapped memory: the values, then the sequence number
+// the host spins on), which sizes the buffers before the marches may do anything -- the capacity never rests on a guess.
+__global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a)
 {
   __shared__ uint32_t s_off[AZ_BINS + 2];
   __shared__ uint32_t wave_sums[4];
   constexpr int TOTAL = AZ_BINS + 1;
   constexpr int PER = (TOTAL + 255) / 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (FUSED)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
   {
-    if (threadIdx.x == 0)
-      while ((uint32_t)(__hip_atomic_load(&a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48) < n_setup_blocks) __builtin_amdgcn_s_sleep(16);
-    __syncthreads();
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 12), a.counters->ub_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int lo = threadIdx.x * PER, hi = min(lo + PER, TOTAL);
   uint32_t h[PER];
@@ -398,8 +397,7 @@ __device__ __forceinline__ void ray_sort_block(const ScatterArgs &a, uint32_t n_
   for (int j = 0; j < PER; ++j)
   {
     const int i = lo + j;
-    // (a launch of its own sees the histogram through the kernel boundary; fused, it was counted on other XCDs in this launch)
-    h[j] = i < hi ? (FUSED ? __hip_atomic_load(&a.az_hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.az_hist[i]) : 0u;
+    h[j] = i < hi ? a.az_hist[i] : 0u;
     v += h[j];
   }
   uint32_t x = v;
@@ -422,25 +420,15 @@ __device__ __forceinline__ void ray_sort_block(const ScatterArgs &a, uint32_t n_
   }
   if (hi == TOTAL && lo < hi) s_off[TOTAL] = run;
   __syncthreads();
-  const uint32_t b = blockIdx.x - n_setup_blocks, nb = gridDim.x - n_setup_blocks;
+  const uint32_t b = blockIdx.x, nb = gridDim.x;
   if (b == 0 && threadIdx.x == 0) a.az_off[AZ_BINS] = s_off[AZ_BINS]; // rays that contribute: the tail march's grid
   for (uint32_t ix = b * 256u + threadIdx.x; ix < a.n; ix += nb * 256u)
   {
-    const unsigned long long br = FUSED ? __hip_atomic_load(reinterpret_cast<unsigned long long *>(&a.ray_bin[ix]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                        : *reinterpret_cast<const unsigned long long *>(&a.ray_bin[ix]);
+    const unsigned long long br = *reinterpret_cast<const unsigned long long *>(&a.ray_bin[ix]);
     a.ray_order[s_off[(uint32_t)br] + (uint32_t)(br >> 32)] = ix;
   }
 }
-
-// n_setup_blocks == gridDim.x: set-up only (the sort follows as a launch of its own)
-__global__ __launch_bounds__(256) void ray_setup_sort_kernel(ScatterArgs a, uint32_t n_setup_blocks)
-{
-  if (blockIdx.x < n_setup_blocks)
-    ray_setup_block(a, n_setup_blocks);
-  else
-    ray_sort_block<true>(a, n_setup_blocks);
-}
-__global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a) { ray_sort_block<false>(a, 0); }
+__global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a) { ray_setup_block(a); }
 
 // ---------------------------------------------------------------------------------------------------------
 // records of a tile: chunks, reservation, look-up
@@ -612,18 +600,18 @@ constexpr int HT_BITS = 8, HT_SLOTS = 1 << HT_BITS; // tiles a workgroup can sta
 #define WS_TAIL_SPLIT 2
 #endif
 #ifndef WS_TAIL_WGS
-#define WS_TAIL_WGS 4 // workgroups per CU the register budget is set for
+#define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (96 VGPRs; 6 = 80 VGPRs spills in the emit phase: 226 -> 292 us)
 #endif
-#ifndef WS_TAIL_STAGE
-#define WS_TAIL_STAGE 2048 // records a workgroup stages before it flushes (8 + 2 bytes of LDS each)
+#ifndef WS_TAIL_BLIND
+#define WS_TAIL_BLIND 1 // off-ray candidates of value +tau as marks in the second byte plane instead of records (2.1 M of the benchmark scan's 14.4 M)
+#endif
+#ifndef WS_COPY_U
+#define WS_COPY_U 4 // records a thread has in flight while it copies the workgroup's records to their tiles
 #endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
-constexpr int TAIL_STAGE = WS_TAIL_STAGE;
-static_assert(TAIL_STAGE >= 256 && TAIL_STAGE <= 65535, "staging slots are 16-bit; an emit phase whose records exceed the whole area (fans wider than TAIL_STAGE / 64) goes straight to the tiles");
 static_assert(HT_SLOTS == 256, "the flush gives every thread one slot of the tile table");
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
-constexpr uint16_t SLOT_NONE = 0xffffu;
 
 __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
 {
@@ -640,19 +628,6 @@ __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
     h = (h + 1) & (HT_SLOTS - 1);
   }
   return -1;
-}
-
-// n slots of the staging area, all or nothing (one lane calls; 0xffffffff: they do not fit before the next flush)
-__device__ __forceinline__ uint32_t stage_reserve(uint32_t *cursor, uint32_t n)
-{
-  uint32_t old = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (;;)
-  {
-    if (old + n > (uint32_t)TAIL_STAGE) return 0xffffffffu;
-    const uint32_t seen = atomicCAS(cursor, old, old + n);
-    if (seen == old) return old;
-    old = seen;
-  }
 }
 
 // inclusive prefix sum over the 64 lanes: four DPP shifts inside the rows of 16 (guarded: a lane whose source lies outside
@@ -685,7 +660,7 @@ __device__ __forceinline__ bool scan_fits(const ScatterArgs &a)
   // them on one address -- this line alone took the tail march from 190 to 500 us.)
   const unsigned long long need = a.counters->ub_total & ((1ull << 48) - 1ull);
   const unsigned long long n_tiles = (unsigned long long)a.ntx * (unsigned long long)a.nty * (unsigned long long)a.ntz;
-  return chunks_needed(need, n_tiles, a.est_shift, a.n) <= (unsigned long long)a.chunk_cap;
+  return chunks_needed(need, n_tiles, a.est_shift, a.n) <= (unsigned long long)a.chunk_cap && a.counters->ub_tail <= (unsigned long long)a.raw_cap;
 }
 
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
@@ -712,39 +687,33 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return excl;
 }
 
+// a record on its way: the workgroup's slice of the raw buffer holds what the march emits, in emission order
+struct RawRec // 16 bytes
+{
+  unsigned long long rec;
+  uint32_t tile;
+  uint32_t slot; // of the tile in the workgroup's table (SLOT_NONE: the record went straight to its tile)
+};
+constexpr uint32_t SLOT_NONE = 0xffffffffu;
+
 struct TailShared
 {
-  unsigned long long rec[TAIL_STAGE];
-  uint16_t slot[TAIL_STAGE]; // slot of the record's tile in the table below (SLOT_NONE: the record went straight to its tile)
   uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c0[HT_SLOTS], ht_c1[HT_SLOTS];
   uint32_t block_base, block_next; // this workgroup's block of chunk ids and how many of them are taken
-  uint32_t n_first, list_base;     // tiles this flush is the first to reserve in, and where they go in the scan's tile list
-  uint32_t cursor, done, n_records, n_groups;
-#ifdef WS_TAIL_TIMING
-  uint32_t t_flush[5];
-#endif
+  uint32_t n_first, list_base;     // tiles this workgroup is the first to reserve in, and where they go in the scan's tile list
+  uint32_t raw_base, n_groups;
+  uint32_t wave_ub[4];    // upper bound of the records of each wave's part of the tails: its private sub-slice of the workgroup's slice
+  uint32_t wave_count[4]; // records each wave has written into its sub-slice
 };
 
-// The staged records go to their tiles: thread t owns slot t of the tile table.  ONE memory round trip in front of the copy:
-// the reservation in the tile's record sequence (its count is known) travels together with a read of the tile's chunk
+// The workgroup's records go to their tiles: thread t owns slot t of the tile table.  ONE memory round trip in front of the
+// copy: the reservation in the tile's record sequence (its count is known) travels together with a read of the tile's chunk
 // table, the chunks the range opens come out of the workgroup's own block of ids (an LDS counter), and the chunk the range
 // starts in -- opened by whoever reserved its first record -- is in the table that was read along, unless that happened
-// in these very microseconds (then: poll).  total: staged records (uniform).
-#ifndef WS_FLUSH_INLINE
-#define WS_FLUSH_INLINE 1
-#endif
-#if WS_FLUSH_INLINE
-__device__ __forceinline__
-#else
-__device__ __attribute__((noinline))
-#endif
-void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
+// in these very microseconds (then: poll).  total: records in the slice (uniform).
+__device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const RawRec *raw, const uint32_t total)
 {
   const int t = threadIdx.x;
-#ifdef WS_TAIL_TIMING
-  long long tf[6];
-  tf[0] = wall_clock64();
-#endif
   const uint32_t c = sh.ht_cnt[t], tile = sh.ht_key[t];
   uint32_t old_fill = 0;
   unsigned long long tab[TILE_DIRECT / 2] = {0, 0, 0, 0};
@@ -766,13 +735,10 @@ void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
     const uint32_t k = atomicAdd(&sh.block_next, r.n_new);
     if (k + r.n_new <= CHUNK_BLOCK)
       cid = sh.block_base + k;
-    else // (the block is used up: this group asks the shared counter itself; the block is renewed at the end of the flush)
+    else // (the block is used up: this group asks the shared counter itself)
       cid = __hip_atomic_fetch_add(&a.counters->chunk_cursor, r.n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t q = 0; q < r.n_new; ++q) open_chunk(a, tile, r.j_new + q, cid + q);
   }
-#ifdef WS_TAIL_TIMING
-  tf[1] = wall_clock64();
-#endif
   asm volatile("" ::: "memory"); // everything this wave opens is published before any of its lanes polls
   if (c)
   {
@@ -800,81 +766,61 @@ void tail_flush(const ScatterArgs &a, TailShared &sh, const uint32_t total)
   __syncthreads();
   uint32_t list_base = 0;
   if (t == 0 && sh.n_first) list_base = __hip_atomic_fetch_add(&a.counters->n_listed, sh.n_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef WS_TAIL_TIMING
-  tf[2] = wall_clock64();
-#endif
-  // the copy, four records per thread and step: the LDS reads of all four, then their cursor atomics, then the stores
-#ifndef WS_COPY_U
-#define WS_COPY_U 4
-#endif
+  // the copy: COPY_U records per thread and step, their loads issued together (unconditional, clamped: a load under a branch
+  // would be waited for on the spot), then the cursor atomics, then the stores
   constexpr int CU = WS_COPY_U;
+  // (the slice is four sub-slices, one per wave of the march: record i of the workgroup sits at its wave's offset)
+  const uint32_t n0 = sh.wave_count[0], n1 = n0 + sh.wave_count[1], n2 = n1 + sh.wave_count[2];
+  const uint32_t o1 = sh.wave_ub[0], o2 = o1 + sh.wave_ub[1], o3 = o2 + sh.wave_ub[2];
   for (uint32_t i0 = (uint32_t)t; i0 < total; i0 += 256u * CU)
   {
-    uint32_t slot[CU], base[CU], q[CU];
-    unsigned long long rec[CU];
+    u32x4 rr[CU];
+    uint32_t base[CU], q[CU];
 #pragma unroll
     for (int u = 0; u < CU; ++u)
     {
       const uint32_t i = i0 + 256u * (uint32_t)u;
-      slot[u] = i < total ? (uint32_t)sh.slot[i] : (uint32_t)SLOT_NONE;
-      rec[u] = sh.rec[i < total ? i : 0u];
+      const uint32_t ic = i < total ? i : total - 1u;
+      const uint32_t at = ic < n0 ? ic : (ic < n1 ? o1 + (ic - n0) : (ic < n2 ? o2 + (ic - n1) : o3 + (ic - n2)));
+      rr[u] = *reinterpret_cast<const u32x4 *>(&raw[at]);
+      if (i >= total) rr[u].w = SLOT_NONE;
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u)
     {
-      const uint32_t sl = slot[u] != SLOT_NONE ? slot[u] : 0u;
+      const uint32_t sl = rr[u].w != SLOT_NONE ? rr[u].w : 0u;
       base[u] = sh.ht_base[sl];
-      q[u] = slot[u] != SLOT_NONE ? base[u] + atomicAdd(&sh.ht_cnt[sl], 1u) : 0u;
+      q[u] = rr[u].w != SLOT_NONE ? base[u] + atomicAdd(&sh.ht_cnt[sl], 1u) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u)
     {
-      if (slot[u] == SLOT_NONE) continue;
+      if (rr[u].w == SLOT_NONE) continue;
       const uint32_t jrel = (q[u] >> CHUNK_BITS) - (base[u] >> CHUNK_BITS);
-      // (a group of more than two chunks -- one tile took most of the staging area -- finds the others through the tile's table;
-      // this workgroup published them above)
-      const uint32_t id1 = jrel == 0 ? sh.ht_c0[slot[u]] : (jrel == 1 ? sh.ht_c1[slot[u]] : chunk_lookup(a, sh.ht_key[slot[u]], q[u] >> CHUNK_BITS));
-      store_rec(a, id1, q[u], rec[u]);
+      // (a group of more than two chunks finds the others through the tile's table; this workgroup published them above)
+      const uint32_t id1 = jrel == 0 ? sh.ht_c0[rr[u].w] : (jrel == 1 ? sh.ht_c1[rr[u].w] : chunk_lookup(a, rr[u].z, q[u] >> CHUNK_BITS));
+      store_rec(a, id1, q[u], (unsigned long long)rr[u].x | ((unsigned long long)rr[u].y << 32));
     }
   }
-  __syncthreads();
-#ifdef WS_TAIL_TIMING
-  tf[3] = wall_clock64();
-  if (t == 0)
-  {
-    sh.t_flush[0] += (uint32_t)(tf[1] - tf[0]);
-    sh.t_flush[1] += (uint32_t)(tf[2] - tf[1]);
-    sh.t_flush[2] += (uint32_t)(tf[3] - tf[2]);
-    sh.t_flush[4] += 1;
-  }
-#endif
   if (t == 0) sh.list_base = list_base;
   __syncthreads();
   if (first) list_tile(a, sh.list_base + first_rank, tile);
-  sh.ht_key[t] = HT_EMPTY;
-  sh.ht_cnt[t] = 0;
-  if (t == 0)
-  {
-    sh.cursor = 0;
-    sh.n_first = 0;
-    sh.n_records += total;
-    if (sh.block_next + CHUNK_BLOCK / 4 > CHUNK_BLOCK)
-    {
-      // a new block of ids for the flushes to come (what is left of the old one stays unused: chunks_needed() counts it)
-      sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh.block_next = 0;
-    }
-  }
-  __syncthreads();
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
-// targets fall into the same vertical slab of space, i.e. into few tiles
+// targets fall into the same vertical slab of space, i.e. into few tiles.  The march writes its records to the workgroup's
+// slice of the raw buffer (coalesced, read back by the same workgroup a few microseconds later) and counts them per tile
+// in an LDS table; then the workgroup hands them to their tiles (tail_flush).  (Staging the records in LDS instead -- 2048 of
+// them, flushed whenever the area filled up -- cost two workgroups per CU of occupancy and the march state stayed live
+// across the flushes: 243-258 us against 187 for this shape, measured in round 4.)
 __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
   __shared__ TailShared sh;
   __shared__ u32x4 s_queue[4 * TAIL_QCAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef WS_TAIL_TIMING
+  const long long t_begin = wall_clock64();
+#endif
   const uint32_t n_sorted = a.az_off[AZ_BINS];
   const uint32_t slot = (item / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
   const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
@@ -890,50 +836,88 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     ix = a.ray_order[slot];
     r = a.rays[ix];
   }
-#ifdef WS_TAIL_TIMING
-  const long long t_item0 = wall_clock64();
-#endif
+  // ---- phase 0: a slice of the raw buffer for the upper bound of this workgroup's records, a block of chunk ids
   if (threadIdx.x == 0)
   {
-    sh.cursor = 0;
-    sh.done = 0;
-    sh.n_records = 0;
     sh.n_groups = 0;
     sh.block_next = 0;
     sh.n_first = 0;
-#ifdef WS_TAIL_TIMING
-    for (int q = 0; q < 5; ++q) sh.t_flush[q] = 0;
-#endif
   }
   sh.ht_key[threadIdx.x] = HT_EMPTY;
   sh.ht_cnt[threadIdx.x] = 0;
+  int32_t k0 = 0, k1 = 0;
+  if (has_ray && r.steps > 0 && r.kfirst < r.steps)
+  {
+    const int32_t kbeg = r.kfirst, kend = r.steps;
+    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
+    k0 = min(kbeg + (part0 + wave) * ch, kend);
+    k1 = min(k0 + ch, kend);
+  }
+  const bool work = k0 < k1;
+  {
+    // every wave bounds the records of ITS part of the tails: its own sub-slice, so that positions in it are a count the
+    // wave keeps in a register (no cursor shared by the waves, no LDS atomic per emit phase)
+    unsigned long long ub = work ? tail_bound(k0, k1, (int64_t)r.distance + a.tau, a.fan_steps) : 0ull;
+    for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
+    if (lane == 0)
+    {
+      sh.wave_ub[wave] = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
+      sh.wave_count[wave] = 0;
+    }
+  }
   __syncthreads();
-  // the workgroup's block of chunk ids: requested now, needed at the first flush (only the first wave waits for it)
-  if (threadIdx.x == 0) sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long ub = (unsigned long long)sh.wave_ub[0] + sh.wave_ub[1] + sh.wave_ub[2] + sh.wave_ub[3];
+    uint32_t base = 0xffffffffu;
+    if (ub == 0)
+      base = 0;
+    else if (ub <= a.raw_cap)
+    {
+      const uint32_t b = atomicAdd(&a.counters->raw_cursor, (uint32_t)ub);
+      if (b <= a.raw_cap - (uint32_t)ub) base = b;
+    }
+    if (base == 0xffffffffu) raise_error(a.counters, a.status, ERR_INTERNAL); // (the buffer holds the scan's bound: scan_fits)
+    sh.raw_base = base;
+    sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (sh.raw_base == 0xffffffffu) return;
+  RawRec *const raw_wg = reinterpret_cast<RawRec *>(a.rec + (size_t)a.chunk_cap * CHUNK_RECS) + sh.raw_base;
+  uint32_t wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += sh.wave_ub[w];
+  RawRec *const raw = raw_wg + wave_off; // this wave's sub-slice
+  const uint32_t raw_ub = sh.wave_ub[wave];
+  uint32_t n_written = 0; // records this wave has written (uniform)
 
+  // ---- phase 1: march, one record per scatter target
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
   const bool mark = !a.all_keyed;
   uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
-  // a record into staging slot `pos` (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
-  auto stage_record = [&](uint32_t pos, uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
+  // a record into position `pos` of the slice (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
+  auto put_record = [&](uint32_t pos, uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
     // the free-space pass must know that this voxel takes part in the key order
     if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
     const unsigned long long rec = make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz));
-    // the workgroup's tile table is built on the fly; a full table sends the record straight to its tile
-    const int s = pos < (uint32_t)TAIL_STAGE ? ht_insert(sh.ht_key, tile) : -1;
+    // the workgroup's tile table is built on the fly (the slot travels with the record); a full table sends the record
+    // straight to its tile
+    const int s = ht_insert(sh.ht_key, tile);
     if (s >= 0)
+      atomicAdd(&sh.ht_cnt[s], 1u); // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
+    else
+      append_record(a, tile, rec);
+    if (pos < raw_ub)
     {
-      // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
-      atomicAdd(&sh.ht_cnt[s], 1u);
-      sh.rec[pos] = rec;
-      sh.slot[pos] = (uint16_t)s;
+      u32x4 out;
+      out.x = (uint32_t)rec;
+      out.y = (uint32_t)(rec >> 32);
+      out.z = tile;
+      out.w = s >= 0 ? (uint32_t)s : SLOT_NONE;
+      *reinterpret_cast<u32x4 *>(&raw[pos]) = out;
     }
     else
-    {
-      if (pos < (uint32_t)TAIL_STAGE) sh.slot[pos] = SLOT_NONE;
-      append_record(a, tile, rec);
-    }
+      raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
@@ -945,237 +929,191 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     if (tile != listed_tile) a.tile_dirty[tile] = 1;
   };
 
-  int32_t k0 = 0, k1 = 0;
-  if (has_ray && r.steps > 0 && r.kfirst < r.steps)
-  {
-    const int32_t kbeg = r.kfirst, kend = r.steps;
-    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
-    k0 = min(kbeg + (part0 + wave) * ch, kend);
-    k1 = min(k0 + ch, kend);
-  }
-  const bool work = k0 < k1;
   const bool general = !__all(!work || (r.pad & RAY_SIMPLE));
-
-  // ---- state of the compacting walk (ws_march.h): the sample phase queues (position, step, ray) of every sample that
-  // enters a new voxel column; the emit phase takes 64 of them and does update_tsdf.cu:81-125 with every lane busy
-  u32x4 *queue = s_queue + wave * TAIL_QCAP;
-  uint32_t qhead = 0, qtail = 0;
-  const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
-  const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
-  AxisRun ix0, iy0, iz0;
-  ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
-  ix0.gap = 0x3fffffff;
-  iy0 = ix0;
-  iz0 = ix0;
-  int32_t k = k0; // the next sample of this lane
-  if (work && !general)
+  if (general)
   {
-    const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-    run_init(ix0, f, r, r.dx, f.posx, kinit, true);
-    run_init(iy0, f, r, r.dy, f.posy, kinit, true);
-    run_init(iz0, f, r, r.dz, f.posz, kinit, false);
+    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record
+    if (work)
+      march_steps<false>(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+        const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
+                      sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+        if (WS_TAIL_BLIND && mark && !positive && value == a.tau)
+        {
+          mark_negative(sx, sy, sz, 0xffffffffu);
+          return;
+        }
+        // fan step - mid: update_tsdf.cu:103-104 (`positive` == the on-ray step)
+        const int32_t delta_z = wmul(DZ_PER_DISTANCE, 1 + kk * f.half) / MATRIX_RESOLUTION;
+        // (the lanes reach this point in varying company: the wave's count lives in LDS here, one atomic per call)
+        const unsigned long long active = __ballot(1);
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)active) - 1;
+        if (lane == leader) base = atomicAdd(&sh.wave_count[wave], (uint32_t)__popcll(active));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        put_record(base + (uint32_t)__popcll(active & ((1ull << lane) - 1ull)), ix, kk, step - delta_z / f.res, value, sx, sy, sz);
+      });
   }
-  // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
-  AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
-  auto push = [&](bool cand, bool cx, bool cy) {
-    const unsigned long long mask = __ballot(cand);
-    if (mask == 0) return;
-    if (cand)
-    {
-      u32x4 e;
-      e.x = (uint32_t)fast_proj(wx, cx, res);
-      e.y = (uint32_t)fast_proj(wy, cy, res);
-      e.z = (uint32_t)fast_proj(wz, false, res);
-      e.w = (uint32_t)k | ((uint32_t)lane << 16);
-      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
-    }
-    qtail += (uint32_t)__popcll(mask);
-  };
-  int32_t n_iter = 0, it = 0;
-  if (!general && __any(work))
+  else if (__any(work))
   {
-    // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk starts: out
-    // of the loop, so that every iteration is "step, then test"
-    bool first = false;
-    if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
-    push(first, false, false);
-    if (work && k0 == 0) k = 1;
+    // compacting walk (ws_march.h): the sample phase queues (position, step, ray) of every sample that enters a new
+    // voxel column; the emit phase pops 64 of them and does update_tsdf.cu:81-125 with every lane busy
+    u32x4 *queue = s_queue + wave * TAIL_QCAP;
+    uint32_t qhead = 0, qtail = 0;
+    const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
+    const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
+    AxisRun ix0, iy0, iz0;
+    ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
+    ix0.gap = 0x3fffffff;
+    iy0 = ix0;
+    iz0 = ix0;
+    int32_t k = k0; // the next sample of this lane
+    if (work)
+    {
+      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+      run_init(ix0, f, r, r.dx, f.posx, kinit, true);
+      run_init(iy0, f, r, r.dy, f.posy, kinit, true);
+      run_init(iz0, f, r, r.dz, f.posz, kinit, false);
+    }
+    // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
+    AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
+    auto push = [&](bool cand, bool cx, bool cy) {
+      const unsigned long long mask = __ballot(cand);
+      if (mask == 0) return;
+      if (cand)
+      {
+        u32x4 e;
+        e.x = (uint32_t)fast_proj(wx, cx, res);
+        e.y = (uint32_t)fast_proj(wy, cy, res);
+        e.z = (uint32_t)fast_proj(wz, false, res);
+        e.w = (uint32_t)k | ((uint32_t)lane << 16);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
+      }
+      qtail += (uint32_t)__popcll(mask);
+    };
+    {
+      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk starts: out
+      // of the loop, so that every iteration is "step, then test"
+      bool first = false;
+      if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
+      push(first, false, false);
+      if (work && k0 == 0) k = 1;
+    }
     int32_t todo = work ? k1 - k : 0;
     for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
-    n_iter = __builtin_amdgcn_readfirstlane(todo);
-  }
-
-  // emit phase: up to 64 queued samples, one per lane.  false: the staging area cannot take their records before the next
-  // flush (nothing has been consumed: the same call is repeated afterwards)
-  auto emit_batch = [&]() -> bool {
-    const uint32_t cnt = qtail - qhead;
-    const uint32_t n = cnt < 64 ? cnt : 64;
-    u32x4 e = {0, 0, 0, 0};
-    const bool has = (uint32_t)lane < n;
-    if (has) e = queue[(qhead + (uint32_t)lane) & (TAIL_QCAP - 1)];
-    // constants of the ray the sample belongs to (a lane of this wave)
-    const int src = (int)(e.w >> 16);
-    const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
-    const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
-    const int32_t s_dist = __shfl(r.distance, src, 64);
-    const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
-    const int32_t ek = (int32_t)(e.w & 0xffffu);
-    const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
-    const int32_t len = 1 + ek * half;
-    // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
-    const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
-                  ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
-    int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
-    value = value < tau ? value : tau;
-    if (len > s_dist) value = -value;
-    // update_tsdf.cu:101-105
-    const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
-    int32_t iter_steps = 0, mid = 0;
-    if (has && !tsdf_weight_is_zero(value, tau, f.weight_epsilon))
-    {
-      iter_steps = 1;
-      if (delta_z * 2 >= res)
+    const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
+    // emit phase: up to 64 queued samples, one per lane
+    auto emit_batch = [&]() {
+      const uint32_t cnt = qtail - qhead;
+      const uint32_t n = cnt < 64 ? cnt : 64;
+      u32x4 e = {0, 0, 0, 0};
+      const bool has = (uint32_t)lane < n;
+      if (has) e = queue[(qhead + (uint32_t)lane) & (TAIL_QCAP - 1)];
+      qhead += n;
+      // constants of the ray the sample belongs to (a lane of this wave)
+      const int src = (int)(e.w >> 16);
+      const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
+      const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
+      const int32_t s_dist = __shfl(r.distance, src, 64);
+      const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
+      const int32_t ek = (int32_t)(e.w & 0xffffu);
+      const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
+      const int32_t len = 1 + ek * half;
+      // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
+      const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
+                    ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
+      int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
+      value = value < tau ? value : tau;
+      if (len > s_dist) value = -value;
+      // update_tsdf.cu:101-105
+      const int32_t delta_z = (DZ_PER_DISTANCE * len) >> 15; // len > 0
+      int32_t iter_steps = 0, mid = 0;
+      if (has && !tsdf_weight_is_zero(value, tau, f.weight_epsilon))
       {
-        iter_steps = (int32_t)(__umulhi((uint32_t)(delta_z * 2), f.rM32) >> f.rS) + 1;
-        mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
+        iter_steps = 1;
+        if (delta_z * 2 >= res)
+        {
+          iter_steps = (int32_t)(__umulhi((uint32_t)(delta_z * 2), f.rM32) >> f.rS) + 1;
+          mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
+        }
       }
-    }
-    // the off-ray targets of a sample of value +tau are marks, not records
-    const bool blind = mark && value == tau;
-    const uint32_t nrec = iter_steps == 0 ? 0u : (blind ? 1u : (uint32_t)iter_steps);
-    const uint32_t incl = wave_incl_scan(nrec);
-    const uint32_t batch = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t base = 0;
-    const bool fits = batch <= (uint32_t)TAIL_STAGE; // (else: fans so wide that 64 samples overflow the whole area -- record by record to the tiles)
-    if (batch && fits)
-    {
-      if (lane == 0) base = stage_reserve(&sh.cursor, batch);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (base == 0xffffffffu) return false;
-    }
-    qhead += n;
-    if (batch == 0) return true;
-    uint32_t pos = fits ? base + incl - nrec : 0x80000000u;
-    const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
-                  lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
-    auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
-      const int32_t sm = step * res;
-      const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
-                    vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
-      sx = ring_fast(vx, f.ringK[0], a.map.size[0]);
-      sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
-      sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-    };
-    // the on-ray target (fan step `mid`) first: always a record, and its tile is on the list through it
-    uint32_t mid_tile = 0xffffffffu;
-    if (iter_steps > 0)
-    {
-      int32_t sx, sy, sz;
-      target(mid, sx, sy, sz);
-      mid_tile = stage_record(pos, s_ix, ek, 0, value, sx, sy, sz);
-      pos += 1;
-    }
-    // the off-ray targets (update_tsdf.cu:107-125)
-    int32_t widest = iter_steps;
-    for (int d = 32; d > 0; d >>= 1) widest = max(widest, __shfl_xor(widest, d, 64));
-    widest = __builtin_amdgcn_readfirstlane(widest);
-    for (int32_t step = 0; step < widest; ++step)
-    {
-      if (step < iter_steps && step != mid)
+      // the off-ray targets of a sample of value +tau are marks, not records; ONE reservation in the slice for the records
+      // of all 64 samples (a prefix sum over the lanes instead of a ballot + LDS atomic per fan step)
+      const bool blind = WS_TAIL_BLIND && mark && value == tau;
+      const uint32_t nrec = iter_steps == 0 ? 0u : (blind ? 1u : (uint32_t)iter_steps);
+      const uint32_t incl = wave_incl_scan(nrec);
+      const uint32_t batch = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (batch == 0) return;
+      uint32_t pos = n_written + incl - nrec;
+      n_written += batch;
+      const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
+                    lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
+      auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
+        const int32_t sm = step * res;
+        const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
+                      vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
+        sx = ring_fast(vx, f.ringK[0], a.map.size[0]);
+        sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
+        sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
+      };
+      // the on-ray target (fan step `mid`) first: always a record, and its tile is on the list through it
+      uint32_t mid_tile = 0xffffffffu;
+      if (iter_steps > 0)
       {
         int32_t sx, sy, sz;
-        target(step, sx, sy, sz);
-        if (blind)
-          mark_negative(sx, sy, sz, mid_tile);
-        else
+        target(mid, sx, sy, sz);
+        mid_tile = put_record(pos, s_ix, ek, 0, value, sx, sy, sz);
+        pos += 1;
+      }
+      // the off-ray targets (update_tsdf.cu:107-125)
+      // (the loop bound as a ballot per round: a maximum over the lanes by shuffles is six trips through the LDS pipe per emit phase)
+      for (int32_t step = 0; __any(step < iter_steps); ++step)
+      {
+        if (step < iter_steps && step != mid)
         {
-          stage_record(pos, s_ix, ek, step - mid, value, sx, sy, sz);
-          pos += 1;
+          int32_t sx, sy, sz;
+          target(step, sx, sy, sz);
+          if (blind)
+            mark_negative(sx, sy, sz, mid_tile);
+          else
+          {
+            put_record(pos, s_ix, ek, step - mid, value, sx, sy, sz);
+            pos += 1;
+          }
         }
       }
-    }
-    return true;
-  };
-
-  // The waves of the workgroup walk on their own and meet whenever one of them cannot stage its next records (and at the
-  // end): all four flush together, then go on.  A wave that has finished keeps joining the flushes of the others.
-  bool finished = false;
-  for (;;)
-  {
-    if (!finished)
+    };
+    for (int32_t it = 0; it < n_iter; ++it)
     {
-      if (general)
-      {
-        // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record
-        // (when the staging area is full its records go straight to their tiles)
-        if (work)
-          march_steps<false>(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
-            const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
-                          sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-            if (mark && !positive && value == tau)
-            {
-              mark_negative(sx, sy, sz, 0xffffffffu);
-              return;
-            }
-            // fan step - mid: update_tsdf.cu:103-104 (`positive` == the on-ray step)
-            const int32_t delta_z = wmul(DZ_PER_DISTANCE, 1 + kk * half) / MATRIX_RESOLUTION;
-            const int32_t fm = step - delta_z / res;
-            const unsigned long long active = __ballot(1);
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)active) - 1;
-            if (lane == leader) base = stage_reserve(&sh.cursor, (uint32_t)__popcll(active));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            const uint32_t pos = base == 0xffffffffu ? 0xffffffffu : base + (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
-            stage_record(pos, ix, kk, fm, value, sx, sy, sz);
-          });
-        finished = true;
-      }
-      else
-      {
-        for (;;)
-        {
-          const uint32_t cnt = qtail - qhead;
-          const bool alive = it < n_iter;
-          if (cnt >= 64 || (!alive && cnt > 0))
-          {
-            if (!emit_batch()) break; // flush first
-            continue;
-          }
-          if (!alive)
-          {
-            finished = true;
-            break;
-          }
-          // ---- sample phase
-          const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
-          fast_step_z(wz);
-          push((cx || cy) && k < k1, cx, cy);
-          k += 1;
-          it += 1;
-        }
-      }
-      if (finished && lane == 0) atomicAdd(&sh.done, 1u);
+      // ---- sample phase
+      const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
+      fast_step_z(wz);
+      push((cx || cy) && k < k1, cx, cy);
+      k += 1;
+      // ---- emit phase: 64 queued samples, one per lane
+      if (qtail - qhead >= 64) emit_batch();
     }
-    __syncthreads();
-    const uint32_t total = sh.cursor;
-    const bool all_done = sh.done == 4u;
-    if (total)
-      tail_flush(a, sh, total);
-    else
-      __syncthreads(); // (tail_flush ends with a barrier behind its last reads of the shared state; keep the waves together here too)
-    if (all_done) break;
+    while (qtail != qhead) emit_batch();
   }
+  if (lane == 0) sh.wave_count[wave] = min(general ? sh.wave_count[wave] : n_written, raw_ub);
+  __syncthreads();
+  const uint32_t total = sh.wave_count[0] + sh.wave_count[1] + sh.wave_count[2] + sh.wave_count[3];
+#ifdef WS_TAIL_TIMING
+  const long long t_mid = wall_clock64();
+#endif
+  if (threadIdx.x == 0) a.tail_stats[item] = total;
+  // ---- phase 2: the records to their tiles
+  if (total) tail_flush(a, sh, raw_wg, total);
+  if (threadIdx.x == 0) a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
+#ifdef WS_TAIL_TIMING
+  // (instead of the statistics: 10 ns ticks of the march and of the flush of this item, and when it started)
   if (threadIdx.x == 0)
   {
-    a.tail_stats[item] = sh.n_records;
-    a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
-#ifdef WS_TAIL_TIMING
-    if ((item & 255u) == 7u)
-      printf("tail item %u: %u records %u groups %u flushes | total %lld ticks, flush: reserve + open %u, look-up %u, copy %u (10 ns ticks)\n", item, sh.n_records,
-             sh.n_groups, sh.t_flush[4], wall_clock64() - t_item0, sh.t_flush[0], sh.t_flush[1], sh.t_flush[2]);
-#endif
+    a.tail_stats[item] = (uint32_t)(t_mid - t_begin);
+    a.tail_stats[WS_TAIL_STATS + item] = (uint32_t)(wall_clock64() - t_mid);
+    a.tail_stats[2 * WS_TAIL_STATS + 8192 + item] = (uint32_t)t_begin;
   }
+#endif
 }
 
 __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
@@ -1675,6 +1613,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     c->last_chunks = c->chunk_cursor;
     c->last_need = c->ub_total & ((1ull << 48) - 1ull);
     c->ub_total = 0;
+    c->ub_tail = 0;
     __hip_atomic_store(a.status + 10, c->big_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 9, aborted ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2391,6 +2330,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.big_keys = m->big_keys;
   sa.big_mask = m->big_slots - 1;
   sa.est_shift = est_shift_of(m);
+  sa.raw_cap = m->raw_cap;
+  sa.pad0 = 0;
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;
   sa.status = m->status_dev;
@@ -2412,13 +2353,8 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     m->status_host[10] = 0;
   }
   m->prepped = false;
-#if WS_FUSE_SETUP
-  // set-up blocks + direction-sort blocks in one launch
-  hipLaunchKernelGGL(ray_setup_sort_kernel, dim3(grid_setup.x + min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa, grid_setup.x);
-#else
-  hipLaunchKernelGGL(ray_setup_sort_kernel, grid_setup, block, 0, s, sa, grid_setup.x);
+  hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
   hipLaunchKernelGGL(ray_sort_kernel, dim3(min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa);
-#endif
   prof_end(ctx, WS_K_SETUP);
   prof_begin(ctx, WS_K_MARCH_TAILS);
   hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);
@@ -2495,14 +2431,16 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     int rc = wait_word(6, "TSDF update: the set-up pass did not report its record bound");
     if (rc != WS_OK) return rc;
     const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
+    const unsigned long long need_raw = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 12);
     const uint64_t want = chunks_for_scan(m, need, n);
     bool again = false;
-    uint64_t grow_to = 0;
-    if (want > m->chunk_cap)
+    uint64_t grow_to = m->chunk_cap, raw_to = m->raw_cap;
+    if (want > m->chunk_cap || need_raw > m->raw_cap)
     {
-      // the marches have skipped this scan (scan_fits): a larger buffer, and once more
+      // the marches have skipped this scan (scan_fits): larger buffers, and once more
       again = true;
-      grow_to = want + want / 8;
+      if (want > m->chunk_cap) grow_to = want + want / 8;
+      if (need_raw > m->raw_cap) raw_to = need_raw + need_raw / 8;
     }
     else if (sa.est_shift)
     {
@@ -2521,16 +2459,16 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
       set_error("TSDF update: the scan did not fit the chunk buffer it had just been given");
       return WS_ERR_INTERNAL;
     }
-    if (grow_to > 0xfffffff0ull)
+    if (grow_to > 0xfffffff0ull || raw_to > 0xfffffff0ull)
     {
-      set_error("TSDF update: the scan needs more than 2^32 record chunks");
+      set_error("TSDF update: the scan needs more than 2^32 record chunks / tail records");
       return WS_ERR_CAPACITY;
     }
-    rc = resize_records(m, grow_to); // (waits for the stream: the skipped / aborted update has drained and put its scratch back)
+    rc = resize_records(m, grow_to, raw_to); // (waits for the stream: the skipped / aborted update has drained and put its scratch back)
     if (rc != WS_OK) return rc;
     sa.rec = m->rec;
     sa.chunk_cap = m->chunk_cap;
-    sa.tile_list = m->tile_list;
+    sa.raw_cap = m->raw_cap;
     sa.big_keys = m->big_keys;
     sa.big_mask = m->big_slots - 1;
     sa.scan_seq = ++m->scan_seq;

@@ -36,7 +36,7 @@ constexpr uint64_t KEY_INF = ~0ull;
 // candidate (tau, -weight) landed here" (blind, idempotent byte stores of the free pass)
 __host__ __device__ inline size_t vstate_plane_bytes(int64_t n_vox) { return ((size_t)n_vox + 16 + 255) & ~(size_t)255; }
 constexpr uint32_t WS_TAIL_STATS = 65536; // per-workgroup slots of the tail march: records, flush groups (1 000 000 points / 64 rays x up to 2 workgroups), then 2 per resolve workgroup
-constexpr uint32_t WS_BLOCK_STATS = 2 * WS_TAIL_STATS + 2 * 4096;
+constexpr uint32_t WS_BLOCK_STATS = 2 * WS_TAIL_STATS + 2 * 4096 + WS_TAIL_STATS; // (+ start ticks per tail workgroup of a -DWS_TAIL_TIMING build)
 
 // ring-buffer parameters passed BY VALUE to kernels (the reference chases three device pointers per
 // access, device_map.h:93-101)
@@ -93,7 +93,8 @@ struct TsdfCounters // device-resident
   uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
   uint32_t big_inserted;  // keys ever put into the (tile, chunk) hash since it was last emptied (the host empties it when it fills up)
-  uint32_t pad0;
+  uint32_t raw_cursor;    // records of the raw buffer handed to the workgroups of the tail march (upper bounds; reset by the set-up pass)
+  unsigned long long ub_tail; // sum of the per-ray upper bounds of the TAIL records alone (what the raw buffer must hold)
   // statistics of the last update (ws_tsdf_stats)
   uint32_t last_records;
   uint32_t last_contested;
@@ -172,8 +173,9 @@ struct ws_map
   uint8_t *tile_dirty = nullptr;    // two planes of [n_tiles] bytes (tile_flag_plane_bytes): touched by the free-space pass / an off-ray mark; on the list
   ws::TileEntry *tile_list = nullptr; // [n_tiles] touched tiles of the scan in flight
   // candidate records of the ray tails: chunks of 256 x 8 bytes
-  unsigned long long *rec = nullptr;
+  unsigned long long *rec = nullptr;      // chunk_cap chunks, then the raw buffer: raw_cap records of 16 bytes on their way from the march to the chunks
   uint32_t chunk_cap = 0;
+  uint32_t raw_cap = 0;
   unsigned long long *big_keys = nullptr; // (tile, chunk number) -> chunk id for chunks beyond TILE_DIRECT: keys, then uint32 values
   uint32_t big_slots = 0;
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
@@ -187,7 +189,7 @@ struct ws_map
   ws::TsdfCounters *counters_host = nullptr; // pinned
   uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [4..5] record bound of the scan in flight (u64), [6] its sequence number,
                                              // [8] sequence number of the last scan whose marches have finished, [9] != 0: that scan was aborted (chunks exhausted),
-                                             // [10] keys in the (tile, chunk) hash
+                                             // [10] keys in the (tile, chunk) hash, [12..13] bound of the tail records of the scan in flight (u64)
   uint32_t *status_dev = nullptr;            // device view of status_host
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
@@ -285,7 +287,7 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
-int resize_records(ws_map *m, uint64_t chunks); // api.hip: (re)allocate the chunk buffer (waits for the stream)
+int resize_records(ws_map *m, uint64_t chunks, uint64_t raw_records); // api.hip: (re)allocate the chunk + raw buffer (waits for the stream)
 uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points); // chunks the map's buffer must hold for a scan of that record bound (hard bound, or the estimate for huge maps)
 int launch_tsdf_integrate(ws_map *m);
 int launch_tsdf_stats(ws_map *m); // fills the last_* statistics of TsdfCounters from the per-workgroup slots
