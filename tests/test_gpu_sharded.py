@@ -331,33 +331,66 @@ def _peer_worker(rank, world, port, q_out, drop):
         backend.connect_peers(blocks=256 // world)  # IPC handles all-gathered over gloo
         T_o, it_o, _ = O.register_cloud(oa, q, np.eye(4), 200, 0.1, 0.03, res)
         ok = True
+        routes = []
         for _ in range(3):
             T, it = sharded_register_cloud(backend, len(q), np.eye(4, dtype=np.float32), 200, 0.1, 0.03)
             ok = ok and it == it_o and bool(np.array_equal(T, T_o))
-        q_out.put((rank, ok, it, it_o))
+            routes.append(getattr(backend, "last_route", None))
+        q_out.put((rank, ok, it, it_o, routes))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("drop", [1])
-def test_peer_mailbox_loop_two_processes_over_ipc(drop):
-    """the deployment shape on the one GPU of the box: two PROCESSES, mailboxes exported with hipIpcGetMemHandle, gathered over
-    the process group and opened with hipIpcOpenMemHandle; sharded_register_cloud takes the device-side route"""
+@pytest.mark.parametrize("world,drop", [(2, 1), (8, 3)])
+def test_peer_mailbox_loop_processes_over_ipc(world, drop, monkeypatch):
+    """the deployment shape on the one GPU of the box: `world` PROCESSES (2, and 8 = a whole node's ranks), mailboxes exported
+    with hipIpcGetMemHandle, gathered over the process group and opened with hipIpcOpenMemHandle -- every rank maps all the
+    others' -- and sharded_register_cloud on a ragged cloud: every rank ends with the oracle's iterations and pose, bit for bit.
+    Two processes keep the device-side route; eight kernels of eight processes need not be on one GPU together, so there a
+    registration may fall back to the all-reduce route (still exact) -- the connect itself must work."""
     import torch.multiprocessing as mp
+    # ranks of different processes that SHARE a GPU start further apart than ranks with a GPU each (ws_reg_peer_connect reads this)
+    monkeypatch.setenv("WS_REG_PEER_TIMEOUT_MS", "250")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue()
-    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q_out, drop)) for r in range(2)]
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q_out, drop)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=900)
         assert p.exitcode == 0
-    got = sorted(q_out.get(timeout=10) for _ in range(2))
-    for rank, ok, it, it_o in got:
-        assert ok and it == it_o > 5, (rank, ok, it, it_o)
+    got = sorted(q_out.get(timeout=10) for _ in range(world))
+    for rank, ok, it, it_o, routes in got:
+        assert ok and it == it_o > 5, (rank, ok, it, it_o, routes)
+    if world == 2:
+        assert all(r == "device_mailboxes" for _, _, _, _, routes in got for r in routes), got
+
+
+def test_bench_dry_run_two_ranks_share_the_gpu():
+    """bench.py's N > 1 path cannot rot while there is no multi-GPU box to run it on: two ranks launched the way
+    the driver launches them, both on cuda:0 with a gloo group (WS_BENCH_SHARE_GPU=1 WS_BENCH_BACKEND=gloo) -- IPC mailboxes,
+    device-side exchange, replica pass, reductions of the timings, and the keys the first real 8-GPU line will be read by."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WS_BENCH_SHARE_GPU="1", WS_BENCH_BACKEND="gloo", WS_REG_PEER_TIMEOUT_MS="250", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=root)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr.decode(errors="replace")[-3000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["dry_run_shared_gpu"] is True
+    mg = out["multi_gpu"]
+    assert mg["route"] in ("device_mailboxes", "all_reduce") and mg["iterations"] > 5 and mg["us_per_iteration"] > 0 and "exchange_timeouts" in mg
+    assert out["replica_scans_per_s"] > 0
 
 
 def test_peer_mailbox_loop_eight_ranks_on_one_gpu():

@@ -1,7 +1,8 @@
 """CPU tests that PIN the oracle (oracle/ws_oracle.c) — no GPU needed.
 
 1. the reference's own known-answer tests for this path,
-2. golden vectors produced by the reference's own headers (oracle/_ref -> tests/golden/ref_headers.npz,
+2. golden vectors produced by the reference's own headers -- since round 4 also cu_avg_tsdf_krnl's body through TSDFEntry's
+   accessors and calc_jacobis_krnl's lookups through cuda::DeviceMap / Vector3::cross -- (oracle/_ref -> tests/golden/ref_headers.npz,
    generator: tests/golden/make_ref_goldens.py), and — where /root/reference is present — oracle/_ref live,
 3. the whole-scan counters the survey recorded from the reference kernel source.
 """
@@ -297,6 +298,50 @@ def _check_against(get_index, in_bounds, in_pos, in_neg, l2i, l2l, cross, ray_se
 
 def test_golden_reference_headers():
     _check_against(*[None] * 9)
+
+
+def test_golden_integrate_through_the_reference_accessors():
+    """cu_avg_tsdf_krnl's per-voxel body (update_tsdf.cu:19-41) evaluated with the reference's own TSDFEntry accessors
+    (oracle/ref_driver.cpp: ref_integrate_entry) on 12 000 entry pairs -- int16 wrap of the stored average and of the weight
+    sum, negative and zero weights on either side, the default entry -- against wso_update_avg (until round 4
+    this kernel was pinned by hand-derived vectors only)."""
+    g = np.load(GOLD)
+    mw, tau = (int(x) for x in g["avg_params"])
+    avg = g["avg_existing"].copy()
+    new = g["avg_fresh"].copy()
+    O.lib().wso_update_avg(new.ctypes.data_as(C.c_void_p), avg.ctypes.data_as(C.c_void_p), avg.size, mw, tau)
+    bad = np.nonzero(avg != g["avg_existing_out"])[0]
+    assert bad.size == 0, f"{bad.size} entries differ, first: existing {g['avg_existing'][bad[0]]:#x} fresh {g['avg_fresh'][bad[0]]:#x}"
+    assert np.array_equal(new, g["avg_fresh_out"])
+    # the cases the fixture is there for are in it
+    ew = (g["avg_existing"] >> 16).astype(np.int16).astype(np.int32)
+    nw = (g["avg_fresh"] >> 16).astype(np.int16).astype(np.int32)
+    assert ((ew > 0) & (nw > 0)).sum() > 2000 and ((nw != 0) & (ew <= 0)).sum() > 1000 and (nw == 0).sum() > 500 and (nw < 0).sum() > 1000
+    assert ((ew > 0) & (nw > 0) & (ew + nw > 32767)).sum() > 10  # the weight sum leaves int16 before the clamp
+
+
+def test_golden_jacobians_through_the_reference_types():
+    """calc_jacobis_krnl's map half (registration.cu:217-253) -- bounds test with the buffer, the seven lookups, the gradient
+    rule, the cross product -- evaluated through cuda::DeviceMap::value_unchecked / in_bounds_with_buffer_neg and
+    rmagine::Vector3::cross of the reference (oracle/ref_driver.cpp: ref_jacobi) on 24 maps of random entries x 500 points, ring
+    buffer offsets and window positions included, against wso_calc_jacobis driven with the pure integer translation that makes
+    the kernel's fixed-point transform exact (the transform itself: reference KAT test/cuda.cpp:760-827)."""
+    g = np.load(GOLD)
+    n_masked = 0
+    for case, (m, pts, want) in enumerate(zip(g["jac_maps"], g["jac_points"], g["jac_out"])):
+        size, pos, offset, res, t = m[0:3], m[3:6], m[6:9], int(m[9]), m[10:13]
+        om = O.OracleMap(size, 0, 0, pos=pos, offset=offset, data=g[f"jac_data_{case}"])
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = t
+        J, vals, mask = O.calc_jacobis(om, T, pts, res)
+        assert np.array_equal(mask.astype(np.int64), want[:, 0]), f"case {case}: mask differs at {np.nonzero(mask != want[:, 0])[0][:5]}"
+        on = mask.astype(bool)
+        assert np.array_equal(vals[on].astype(np.int64), want[on, 1]), f"case {case}: values differ"
+        assert np.array_equal(J[on], want[on, 2:]), f"case {case}: Jacobians differ at {np.nonzero((J[on] != want[on, 2:]).any(axis=1))[0][:5]}"
+        n_masked += int(on.sum())
+    assert n_masked > 2000  # thousands of points fall on observed voxels inside the window: the gradient rule is exercised, not just the bounds test
+    out = g["jac_out"]
+    assert (np.abs(out[:, :, 2:5]).max() > 2 ** 31 - 2 ** 27) or (np.abs(out[:, :, 5:]).max() > 1000)
 
 
 def test_live_reference_headers_if_present():
