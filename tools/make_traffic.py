@@ -5,7 +5,7 @@ dispatch, averaged over the dispatches of a kernel).
 
 Corrections (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE counts a wide coalesced stream (16 B per lane) at half
 its bytes — doubled for integrate_dense (128-bit streaming loads; verified: 2 x 527 MB + 1055 MB written == 16 B/voxel).
-For the other kernels (16-byte record streams mixed with scattered bytes / dwords) the counters are uncalibrated and
+For the other kernels (16- and 8-byte record streams mixed with scattered bytes / dwords) the counters are uncalibrated and
 recorded as they are.
 
     python tools/make_traffic.py gpurun_out/prof_r02  ->  profiles/pmc_traffic.json
@@ -38,14 +38,10 @@ def main(prefix):
         def kb(d, frag):
             return sum(v for k, v in d.items() if frag in k)
         for name, frag in (("march_tails", "march_tail_kernel"), ("march_free", "march_free_kernel"), ("tile_resolve", "tile_resolve_kernel"),
-                           ("ray_setup", "ray_s"), ("tile_bin", "tile_")):
-            if name == "tile_bin":
-                parts = ("tile_count", "tile_blockscan", "tile_list", "tile_scan", "desc_place")
-                val = sum(kb(f, q) + kb(w, q) for q in parts) * 1024
-            else:
-                val = (kb(f, frag) + kb(w, frag)) * 1024
+                           ("ray_setup", "ray_s")):
+            val = (kb(f, frag) + kb(w, frag)) * 1024
             out[f"{name}:{mode}"] = int(val)
-        scatter = sum(out[f"{k}:{mode}"] for k in ("march_tails", "march_free", "tile_resolve", "ray_setup", "tile_bin"))
+        scatter = sum(out[f"{k}:{mode}"] for k in ("march_tails", "march_free", "tile_resolve", "ray_setup"))
         out[f"scatter_total:{mode}"] = int(scatter)
         if mode == "dense":
             out["integrate:dense"] = int((2 * kb(f, "integrate_dense") + kb(w, "integrate_dense")) * 1024)

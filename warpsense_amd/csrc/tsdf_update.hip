@@ -783,7 +783,11 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
       const uint32_t ic = i < total ? i : total - 1u;
       const uint32_t at = ic < n0 ? ic : (ic < n1 ? o1 + (ic - n0) : (ic < n2 ? o2 + (ic - n1) : o3 + (ic - n2)));
       rr[u] = *reinterpret_cast<const u32x4 *>(&raw[at]);
-      if (i >= total) rr[u].w = SLOT_NONE;
+      if (i >= total)
+      {
+        rr[u].w = SLOT_NONE;
+        rr[u].z = HT_EMPTY;
+      }
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u)
@@ -795,7 +799,12 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
 #pragma unroll
     for (int u = 0; u < CU; ++u)
     {
-      if (rr[u].w == SLOT_NONE) continue;
+      if (rr[u].w == SLOT_NONE)
+      {
+        // (beyond the end of the slice: z == HT_EMPTY; else a record whose tile found no room in the table)
+        if (rr[u].z != HT_EMPTY) append_record(a, rr[u].z, (unsigned long long)rr[u].x | ((unsigned long long)rr[u].y << 32));
+        continue;
+      }
       const uint32_t jrel = (q[u] >> CHUNK_BITS) - (base[u] >> CHUNK_BITS);
       // (a group of more than two chunks finds the others through the tile's table; this workgroup published them above)
       const uint32_t id1 = jrel == 0 ? sh.ht_c0[rr[u].w] : (jrel == 1 ? sh.ht_c1[rr[u].w] : chunk_lookup(a, rr[u].z, q[u] >> CHUNK_BITS));
@@ -900,13 +909,11 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
     const unsigned long long rec = make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz));
-    // the workgroup's tile table is built on the fly (the slot travels with the record); a full table sends the record
-    // straight to its tile
+    // the workgroup's tile table is built on the fly (the slot travels with the record); a record the table has no room for
+    // (more than 256 tiles in one workgroup's records) is sent straight to its tile by the flush.  (Doing that HERE costs the
+    // march 15 vector registers for a path that never runs on a LiDAR scan: 91 instead of 76, five instead of six workgroups per CU.)
     const int s = ht_insert(sh.ht_key, tile);
-    if (s >= 0)
-      atomicAdd(&sh.ht_cnt[s], 1u); // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
-    else
-      append_record(a, tile, rec);
+    if (s >= 0) atomicAdd(&sh.ht_cnt[s], 1u); // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
     if (pos < raw_ub)
     {
       u32x4 out;
