@@ -595,7 +595,13 @@ void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
 // ---------------------------------------------------------------------------------------------------------
 // ray tails -> records, staged in LDS and handed to their tiles
 // ---------------------------------------------------------------------------------------------------------
-constexpr int HT_BITS = 8, HT_SLOTS = 1 << HT_BITS; // tiles a workgroup can stage between two flushes (one slot per thread)
+#ifndef WS_HT_BITS
+#define WS_HT_BITS 10
+#endif
+// tiles the table of a workgroup of the tail march holds.  64 rays x half their tails fall into ~40-140 tiles at 50 mm, but at
+// 20 mm -- 80 mm tiles, fans from 3.3 m on -- into 250 and more: with 256 slots most records of the 2049^3 @ 20 mm scan overflowed
+// the table and went to their tiles one by one (tail march 12.7 ms; 1024 slots: see DESIGN.md)
+constexpr int HT_BITS = WS_HT_BITS, HT_SLOTS = 1 << HT_BITS;
 #ifndef WS_TAIL_SPLIT
 #define WS_TAIL_SPLIT 2
 #endif
@@ -610,7 +616,7 @@ constexpr int HT_BITS = 8, HT_SLOTS = 1 << HT_BITS; // tiles a workgroup can sta
 #endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
-static_assert(HT_SLOTS == 256, "the flush gives every thread one slot of the tile table");
+static_assert(HT_SLOTS % 256 == 0 && HT_SLOTS <= 2048, "the flush gives every thread HT_SLOTS / 256 slots of the tile table");
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 
 __device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
@@ -714,53 +720,69 @@ struct TailShared
 __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const RawRec *raw, const uint32_t total)
 {
   const int t = threadIdx.x;
-  const uint32_t c = sh.ht_cnt[t], tile = sh.ht_key[t];
-  uint32_t old_fill = 0;
-  unsigned long long tab[TILE_DIRECT / 2] = {0, 0, 0, 0};
-  if (c)
-  {
-    old_fill = __hip_atomic_fetch_add(&a.tile_fill[tile], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long *tp = reinterpret_cast<const unsigned long long *>(a.tile_chunk + (size_t)tile * TILE_DIRECT);
+  constexpr int SPT = HT_SLOTS / 256; // slots of the tile table per thread
+  uint32_t c[SPT], tile[SPT], old_fill[SPT], cid[SPT], first_rank[SPT];
+  unsigned long long tab[SPT][TILE_DIRECT / 2];
+  // all reservations (and the reads of the chunk tables) of a thread's slots travel together: one round trip
 #pragma unroll
-    for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[q] = __hip_atomic_load(tp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const Reserve r = reserve_from(old_fill, c ? c : 1u);
-  // the first reservation of a tile in this scan puts it on the tile list: one request to the list's counter per workgroup,
-  // sent now, needed behind the copy (its round trip runs under it)
-  const bool first = c != 0 && old_fill == 0;
-  const uint32_t first_rank = first ? atomicAdd(&sh.n_first, 1u) : 0u;
-  uint32_t cid = 0;
-  if (c && r.n_new)
+  for (int sp = 0; sp < SPT; ++sp)
   {
-    const uint32_t k = atomicAdd(&sh.block_next, r.n_new);
-    if (k + r.n_new <= CHUNK_BLOCK)
-      cid = sh.block_base + k;
-    else // (the block is used up: this group asks the shared counter itself)
-      cid = __hip_atomic_fetch_add(&a.counters->chunk_cursor, r.n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t q = 0; q < r.n_new; ++q) open_chunk(a, tile, r.j_new + q, cid + q);
+    c[sp] = sh.ht_cnt[t + 256 * sp];
+    tile[sp] = sh.ht_key[t + 256 * sp];
+    old_fill[sp] = 0;
+#pragma unroll
+    for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[sp][q] = 0;
+    if (c[sp])
+    {
+      old_fill[sp] = __hip_atomic_fetch_add(&a.tile_fill[tile[sp]], c[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long *tp = reinterpret_cast<const unsigned long long *>(a.tile_chunk + (size_t)tile[sp] * TILE_DIRECT);
+#pragma unroll
+      for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[sp][q] = __hip_atomic_load(tp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#pragma unroll
+  for (int sp = 0; sp < SPT; ++sp)
+  {
+    const Reserve r = reserve_from(old_fill[sp], c[sp] ? c[sp] : 1u);
+    // the first reservation of a tile in this scan puts it on the tile list: one request to the list's counter per workgroup,
+    // sent behind this loop, needed behind the copy (its round trip runs under it)
+    first_rank[sp] = c[sp] != 0 && old_fill[sp] == 0 ? atomicAdd(&sh.n_first, 1u) : 0xffffffffu;
+    cid[sp] = 0;
+    if (c[sp] && r.n_new)
+    {
+      const uint32_t k = atomicAdd(&sh.block_next, r.n_new);
+      if (k + r.n_new <= CHUNK_BLOCK)
+        cid[sp] = sh.block_base + k;
+      else // (the block is used up: this group asks the shared counter itself)
+        cid[sp] = __hip_atomic_fetch_add(&a.counters->chunk_cursor, r.n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t q = 0; q < r.n_new; ++q) open_chunk(a, tile[sp], r.j_new + q, cid[sp] + q);
+    }
   }
   asm volatile("" ::: "memory"); // everything this wave opens is published before any of its lanes polls
-  if (c)
+#pragma unroll
+  for (int sp = 0; sp < SPT; ++sp)
   {
+    if (c[sp] == 0) continue;
+    const Reserve r = reserve_from(old_fill[sp], c[sp]);
     const bool aligned = (r.p0 & (uint32_t)(CHUNK_RECS - 1)) == 0;
     uint32_t c0, c1 = CHUNK_NONE;
     if (aligned)
     {
-      c0 = chunk_id1(a, cid);
-      if (r.n_new >= 2) c1 = chunk_id1(a, cid + 1u);
+      c0 = chunk_id1(a, cid[sp]);
+      if (r.n_new >= 2) c1 = chunk_id1(a, cid[sp] + 1u);
     }
     else
     {
       const uint32_t j0 = r.p0 >> CHUNK_BITS;
-      const unsigned long long w = j0 < 2 ? tab[0] : (j0 < 4 ? tab[1] : (j0 < 6 ? tab[2] : tab[3]));
+      const unsigned long long w = j0 < 2 ? tab[sp][0] : (j0 < 4 ? tab[sp][1] : (j0 < 6 ? tab[sp][2] : tab[sp][3]));
       c0 = j0 < (uint32_t)TILE_DIRECT ? (uint32_t)((j0 & 1u) ? (w >> 32) : w) : CHUNK_NONE;
-      if (c0 == CHUNK_NONE) c0 = chunk_lookup(a, tile, j0);
-      if (r.n_new >= 1) c1 = chunk_id1(a, cid);
+      if (c0 == CHUNK_NONE) c0 = chunk_lookup(a, tile[sp], j0);
+      if (r.n_new >= 1) c1 = chunk_id1(a, cid[sp]);
     }
-    sh.ht_base[t] = r.p0;
-    sh.ht_c0[t] = c0;
-    sh.ht_c1[t] = c1;
-    sh.ht_cnt[t] = 0; // now the slot's copy cursor
+    sh.ht_base[t + 256 * sp] = r.p0;
+    sh.ht_c0[t + 256 * sp] = c0;
+    sh.ht_c1[t + 256 * sp] = c1;
+    sh.ht_cnt[t + 256 * sp] = 0; // now the slot's copy cursor
     atomicAdd(&sh.n_groups, 1u);
   }
   __syncthreads();
@@ -813,7 +835,9 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
   }
   if (t == 0) sh.list_base = list_base;
   __syncthreads();
-  if (first) list_tile(a, sh.list_base + first_rank, tile);
+#pragma unroll
+  for (int sp = 0; sp < SPT; ++sp)
+    if (first_rank[sp] != 0xffffffffu) list_tile(a, sh.list_base + first_rank[sp], tile[sp]);
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
@@ -852,8 +876,11 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     sh.block_next = 0;
     sh.n_first = 0;
   }
-  sh.ht_key[threadIdx.x] = HT_EMPTY;
-  sh.ht_cnt[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
+  {
+    sh.ht_key[i] = HT_EMPTY;
+    sh.ht_cnt[i] = 0;
+  }
   int32_t k0 = 0, k1 = 0;
   if (has_ray && r.steps > 0 && r.kfirst < r.steps)
   {
