@@ -606,7 +606,7 @@ constexpr int HT_BITS = WS_HT_BITS, HT_SLOTS = 1 << HT_BITS;
 #define WS_TAIL_SPLIT 2
 #endif
 #ifndef WS_TAIL_WGS
-#define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (96 VGPRs; 6 = 80 VGPRs spills in the emit phase: 226 -> 292 us)
+#define WS_TAIL_WGS 6 // workgroups per CU the register budget is set for (80 VGPRs)
 #endif
 #ifndef WS_TAIL_BLIND
 #define WS_TAIL_BLIND 1 // off-ray candidates of value +tau as marks in the second byte plane instead of records (2.1 M of the benchmark scan's 14.4 M)
@@ -704,7 +704,9 @@ constexpr uint32_t SLOT_NONE = 0xffffffffu;
 
 struct TailShared
 {
-  uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c0[HT_SLOTS], ht_c1[HT_SLOTS];
+  // tile table: key (the tile; from the flush's reservations on: the chunk the slot's range starts in), count (then: copy
+  // cursor), first position of the range, the chunk behind the first -- 16 KB at 1024 slots: six workgroups per CU
+  uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c1[HT_SLOTS];
   uint32_t block_base, block_next; // this workgroup's block of chunk ids and how many of them are taken
   uint32_t n_first, list_base;     // tiles this workgroup is the first to reserve in, and where they go in the scan's tile list
   uint32_t raw_base, n_groups;
@@ -780,7 +782,7 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
       if (r.n_new >= 1) c1 = chunk_id1(a, cid[sp]);
     }
     sh.ht_base[t + 256 * sp] = r.p0;
-    sh.ht_c0[t + 256 * sp] = c0;
+    sh.ht_key[t + 256 * sp] = c0; // (the tile is in this thread's registers and in every raw record: the slot is free for it)
     sh.ht_c1[t + 256 * sp] = c1;
     sh.ht_cnt[t + 256 * sp] = 0; // now the slot's copy cursor
     atomicAdd(&sh.n_groups, 1u);
@@ -829,7 +831,7 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
       }
       const uint32_t jrel = (q[u] >> CHUNK_BITS) - (base[u] >> CHUNK_BITS);
       // (a group of more than two chunks finds the others through the tile's table; this workgroup published them above)
-      const uint32_t id1 = jrel == 0 ? sh.ht_c0[rr[u].w] : (jrel == 1 ? sh.ht_c1[rr[u].w] : chunk_lookup(a, rr[u].z, q[u] >> CHUNK_BITS));
+      const uint32_t id1 = jrel == 0 ? sh.ht_key[rr[u].w] : (jrel == 1 ? sh.ht_c1[rr[u].w] : chunk_lookup(a, rr[u].z, q[u] >> CHUNK_BITS));
       store_rec(a, id1, q[u], (unsigned long long)rr[u].x | ((unsigned long long)rr[u].y << 32));
     }
   }
@@ -966,9 +968,11 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   const bool general = !__all(!work || (r.pad & RAY_SIMPLE));
   if (general)
   {
-    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record
+    // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record.  (The
+    // literal form with its divisions for every ray of such a wave: exact for all of them, and without the carried-remainder
+    // walk's state the kernel fits 80 vector registers -- six workgroups per CU -- without a spill; such waves are rare.)
     if (work)
-      march_steps<false>(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
+      march_steps_direct(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
         const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
                       sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
         if (WS_TAIL_BLIND && mark && !positive && value == a.tau)
