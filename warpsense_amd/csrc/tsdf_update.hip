@@ -784,7 +784,6 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
     sh.ht_base[t + 256 * sp] = r.p0;
     sh.ht_key[t + 256 * sp] = c0; // (the tile is in this thread's registers and in every raw record: the slot is free for it)
     sh.ht_c1[t + 256 * sp] = c1;
-    sh.ht_cnt[t + 256 * sp] = 0; // now the slot's copy cursor
     atomicAdd(&sh.n_groups, 1u);
   }
   __syncthreads();
@@ -816,9 +815,10 @@ __device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh,
 #pragma unroll
     for (int u = 0; u < CU; ++u)
     {
-      const uint32_t sl = rr[u].w != SLOT_NONE ? rr[u].w : 0u;
+      const uint32_t sl = rr[u].w != SLOT_NONE ? rr[u].w & (uint32_t)(HT_SLOTS - 1) : 0u;
       base[u] = sh.ht_base[sl];
-      q[u] = rr[u].w != SLOT_NONE ? base[u] + atomicAdd(&sh.ht_cnt[sl], 1u) : 0u;
+      q[u] = rr[u].w != SLOT_NONE ? base[u] + (rr[u].w >> HT_BITS) : 0u; // (the record's rank in its tile: from the march)
+      if (rr[u].w != SLOT_NONE) rr[u].w = sl;
     }
 #pragma unroll
     for (int u = 0; u < CU; ++u)
@@ -942,14 +942,18 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     // (more than 256 tiles in one workgroup's records) is sent straight to its tile by the flush.  (Doing that HERE costs the
     // march 15 vector registers for a path that never runs on a LiDAR scan: 91 instead of 76, five instead of six workgroups per CU.)
     const int s = ht_insert(sh.ht_key, tile);
-    if (s >= 0) atomicAdd(&sh.ht_cnt[s], 1u); // (one LDS atomic per lane, most of them on the same counter: the hardware takes them together)
+    // the counter's old value is the record's rank among the workgroup's records of that tile: it travels with the record, so
+    // that the flush places it without a second atomic on the same word (the lanes of a wave mostly hit ONE counter, and the
+    // LDS takes such atomics one lane at a time: 17 M bank-conflict cycles per launch, most of the LDS pipe's time)
+    const uint32_t rank = s >= 0 ? atomicAdd(&sh.ht_cnt[s], 1u) : 0u;
     if (pos < raw_ub)
     {
       u32x4 out;
       out.x = (uint32_t)rec;
       out.y = (uint32_t)(rec >> 32);
       out.z = tile;
-      out.w = s >= 0 ? (uint32_t)s : SLOT_NONE;
+      out.w = s >= 0 ? (uint32_t)s | (rank << HT_BITS) : SLOT_NONE;
+      if (rank >= (1u << (32 - HT_BITS))) raise_error(a.counters, a.status, ERR_INTERNAL); // (4 M records of one tile in one work item: never)
       *reinterpret_cast<u32x4 *>(&raw[pos]) = out;
     }
     else
