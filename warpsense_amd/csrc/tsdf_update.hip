@@ -1599,6 +1599,31 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     return in_regs;
   };
   auto write_back = [&](const TilePost &w) {
+    if (w.nz == 4 && !HAS_S0) // (a non-default new_map keeps the entries of its untouched voxels: voxel by voxel below)
+    {
+      // the thread's four voxels as ONE access per array (byte stores are a transaction each: 14 M of them per scan were
+      // most of this kernel's write traffic)
+      if (w.vs & 0x07070707u) *reinterpret_cast<u32_a1 *>(a.vstate + w.idx0) = 0;
+      if (w.vs & 0x08080808u) *reinterpret_cast<u32_a1 *>(vneg + w.idx0) = 0;
+      if (w.touched == 0 || aborted) return;
+      u32x4 out;
+      if (FUSED)
+      {
+        out.x = (w.touched & 1u) ? integrate_entry(w.existing[0], w.value[0], a.max_weight) : w.existing[0];
+        out.y = (w.touched & 2u) ? integrate_entry(w.existing[1], w.value[1], a.max_weight) : w.existing[1];
+        out.z = (w.touched & 4u) ? integrate_entry(w.existing[2], w.value[2], a.max_weight) : w.existing[2];
+        out.w = (w.touched & 8u) ? integrate_entry(w.existing[3], w.value[3], a.max_weight) : w.existing[3];
+        if (out.x != w.existing[0] || out.y != w.existing[1] || out.z != w.existing[2] || out.w != w.existing[3])
+          *reinterpret_cast<u32x4_a4 *>(a.avg_data + w.idx0) = out;
+      }
+      else
+      {
+        // (the untouched voxels of a default new_map are (tau, 0), and that is what `value` holds for them)
+        out.x = w.value[0]; out.y = w.value[1]; out.z = w.value[2]; out.w = w.value[3];
+        *reinterpret_cast<u32x4_a4 *>(a.new_data + w.idx0) = out;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
@@ -2001,7 +2026,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         for (int j = 0; j < 4; ++j)
         {
           const uint32_t b = (vs4 >> (8 * j)) & 0xffu;
-          w.value[j] = pack_entry(a.tau, (b & VOX_TOUCHED) ? WEIGHT_RESOLUTION : -WEIGHT_RESOLUTION);
+          w.value[j] = (b & (VOX_TOUCHED | VOX_NEGFREE)) ? pack_entry(a.tau, (b & VOX_TOUCHED) ? WEIGHT_RESOLUTION : -WEIGHT_RESOLUTION) : reset;
           if (b & (VOX_TOUCHED | VOX_NEGFREE)) w.touched |= 1u << j;
         }
         write_back(w);
