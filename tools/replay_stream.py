@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--shift", type=float, default=5.0, help="map shift distance in metres (map/shift)")
     ap.add_argument("--room", type=float, nargs=3, default=(22.0, 16.0, 2.5), help="half extents of the room in metres")
     ap.add_argument("--h5", default=None)
+    ap.add_argument("--hz", type=float, default=0.0, help="pace the stream: scan k is handed over no earlier than k/hz seconds after the first "
+                    "(0 = back to back; the sensor of configs[2] delivers 10 Hz, and the slab filing of an asynchronous shift "
+                    "has the time between two shifts of a paced stream to finish)")
     ap.add_argument("--async-shift", action="store_true", help="map shift off the scan path (TSDFMapping.shift_map_async)")
     args = ap.parse_args()
     import warpsense_amd as W
@@ -45,8 +48,15 @@ def main():
         clouds.append(((pts.astype(np.float64) - sensor) / 1000.0).astype(np.float32))
     W.pause()
     t1 = time.perf_counter()
-    for c in clouds:
+    busy = 0.0
+    for k, c in enumerate(clouds):
+        if args.hz > 0.0:
+            wait = t1 + k / args.hz - time.perf_counter()
+            if wait > 0.0:
+                time.sleep(wait)
+        tb = time.perf_counter()
         app.cloud_callback(c)
+        busy += time.perf_counter() - tb
     W.pause()
     t2 = time.perf_counter()
     stages = {}
@@ -58,8 +68,8 @@ def main():
     app.terminate()
     t4 = time.perf_counter()
     print(json.dumps({"workload": f"{args.scans} synthetic OS1-128 scans (131072 pts), {args.map}^3 sliding map @ {args.res} mm, App replay",
-                      "args": {"step_m": args.step, "shift_m": args.shift, "room_m": list(args.room), "h5": bool(args.h5)},
-                      "scans_per_s": args.scans / (t2 - t1), "stream_s": t2 - t1, "setup_s": t_setup, **stages,
+                      "args": {"step_m": args.step, "shift_m": args.shift, "room_m": list(args.room), "h5": bool(args.h5), "hz": args.hz},
+                      "scans_per_s": args.scans / (t2 - t1), "stream_s": t2 - t1, "callback_busy_s": busy, "setup_s": t_setup, **stages,
                       "tsdf_updates": app.n_updates, "map_shifts": app.n_shifts, "async_shift": bool(args.async_shift),
                       "slowest_scan_ms": 1000.0 * float(max(t["total"] for t in app.timings[2:])),
                       "scans_over_100ms": int(sum(1 for t in app.timings[2:] if t["total"] > 0.1)),
