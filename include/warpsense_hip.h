@@ -281,9 +281,9 @@ int ws_scan_download(ws_scan *scan, int32_t *xyz_host, size_t capacity_points, s
 /* ------------------------------------------------------------------ measurement ---- */
 /* Kernel classes for hipEvent timing (bench.py's roofline leg). */
 #define WS_K_SETUP 0         /* per-ray set-up + direction sort                                    */
-#define WS_K_MARCH_TAILS 1   /* ray tails -> records, sorted by tile per workgroup                 */
+#define WS_K_MARCH_TAILS 1   /* ray tails -> records, handed to the chunks of their tiles            */
 #define WS_K_MARCH_FREE 2    /* free-space steps -> one byte per voxel                             */
-#define WS_K_TILE_BIN 3      /* runs per tile: count / scan / list / descriptor placement          */
+#define WS_K_TILE_BIN 3      /* rounds 1-3 only (no kernel of this class since round 4: always 0)   */
 #define WS_K_TILE_RESOLVE 4  /* exact per-tile fold in LDS (+ fused integrate)                     */
 #define WS_K_INTEGRATE 5     /* separate sparse or dense weighted-average pass (cu_avg_tsdf_krnl)  */
 #define WS_K_REG 6           /* Gauss-Newton iterations (accumulate + solve)                       */

@@ -234,7 +234,7 @@ static int map_free(ws_map *m)
   return WS_OK;
 }
 
-// Device-side error bits (record / descriptor / hash capacity exceeded, a ray outside the order-key range, internal
+// Device-side error bits (a ray outside the record's step / fan range, an aborted scan that was not repeated, internal
 // checks) are OR-ed into a host-mapped word by the kernels.  Every entry point that has just synchronised the stream
 // looks at it: an inexact map is reported ONCE, by the first such call after the update that produced it.
 static int map_take_error(ws_map *m)

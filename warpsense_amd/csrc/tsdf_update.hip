@@ -9,10 +9,12 @@
 //
 //   ray_setup / ray_sort     per-ray constants (update_tsdf.cu:52-63), rays grouped by direction.
 //   march_tail_kernel        walks the ray TAILS once (near-surface and fan candidates: everything whose result
-//                            depends on the order).  Every scatter target becomes an 8-byte record staged in LDS; when
-//                            the staging area fills up (and at the end) the workgroup reserves, with one atomic per tile
-//                            it touched, a range of that tile's record sequence and copies its records there: records
-//                            live in 2 KB chunks that belong to one tile each, HBM sees every record once.  Off-ray
+//                            depends on the order).  Every scatter target becomes an 8-byte record; a wave appends its
+//                            records to its own slice of a raw buffer in HBM and counts them per tile in a table in
+//                            LDS.  At the end the workgroup reserves, with ONE atomic per tile it touched, a range of
+//                            that tile's record sequence and copies its records there: records live in 2 KB chunks
+//                            that belong to one tile each.  (Staging the records in LDS instead of the raw buffer was
+//                            built and measured: exact, and slower — it costs occupancy)  Off-ray
 //                            candidates of value +tau are (tau, -64) whoever makes them and never take part in the
 //                            order: a byte in the second voxel plane instead of a record.
 //   march_free_kernel        walks the steps before the tails: all free space (tau, +64) whoever comes first ->
@@ -565,8 +567,8 @@ __device__ __forceinline__ void store_rec(const ScatterArgs &a, uint32_t id1, ui
   if (id1 != CHUNK_LOST) a.rec[(size_t)(id1 - 1u) * CHUNK_RECS + (q & (uint32_t)(CHUNK_RECS - 1))] = rec;
 }
 
-// one record, straight to its tile (a free-space candidate on a keyed voxel; the tail march when its staging area cannot
-// take a record).  All lanes publish what they have to open BEFORE any lane polls (two regions, in this order: a lane
+// one record, straight to its tile (a free-space candidate on a keyed voxel; the tail march when its tile table cannot
+// take another tile).  All lanes publish what they have to open BEFORE any lane polls (two regions, in this order: a lane
 // may be waiting for a chunk a neighbouring lane of its own wave opens).
 #ifndef WS_APPEND_INLINE
 #define WS_APPEND_INLINE 1
@@ -593,7 +595,7 @@ void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ray tails -> records, staged in LDS and handed to their tiles
+// ray tails -> records, through a per-wave slice of the raw buffer to the chunks of their tiles
 // ---------------------------------------------------------------------------------------------------------
 #ifndef WS_HT_BITS
 #define WS_HT_BITS 10
