@@ -181,27 +181,22 @@ static void map_free_records(ws_map *m)
   if (m->big_keys) (void)hipFree(m->big_keys);
   m->rec = nullptr;
   m->big_keys = nullptr;
-  m->chunk_cap = 0;
-  m->raw_cap = 0;
+  m->sub_cap = 0;
   m->big_slots = 0;
 }
 
-// candidate records of the ray tails: chunks of 256 x 8 bytes that belong to one tile each, behind them the raw buffer (16
-// bytes per record on its way from the march to its chunk), and the (tile, chunk number) -> chunk hash for tiles of more
-// than TILE_DIRECT chunks (two slots per chunk; keys, then uint32 values)
-static int map_alloc_records(ws_map *m, uint64_t chunks, uint64_t raw_records)
+// candidate records of the ray tails: the pool of sub-chunks (32 x 8 bytes, one tile each) and the (tile, entry number) ->
+// entry hash for tiles of more than TILE_DIRECT sub-chunks (two slots per sub-chunk of the pool; keys, then uint32 values)
+static int map_alloc_records(ws_map *m, uint64_t subs)
 {
-  if (chunks < 4096) chunks = 4096;
-  if (chunks > 0xfffffff0ull) chunks = 0xfffffff0ull;
-  if (raw_records < (1u << 16)) raw_records = 1u << 16;
-  if (raw_records > 0xfffffff0ull) raw_records = 0xfffffff0ull;
+  if (subs < 32768) subs = 32768;
+  if (subs > SUB_ID_LIMIT) subs = SUB_ID_LIMIT;
   map_free_records(m);
   uint64_t slots = 1u << 16;
-  while (slots < 2 * chunks && slots < (1ull << 31)) slots <<= 1;
-  WS_HIP(hipMalloc((void **)&m->rec, (size_t)chunks * CHUNK_RECS * sizeof(unsigned long long) + (size_t)raw_records * 16));
+  while (slots < 2 * subs && slots < (1ull << 31)) slots <<= 1;
+  WS_HIP(hipMalloc((void **)&m->rec, (size_t)subs * SUB_RECS * sizeof(unsigned long long)));
   WS_HIP(hipMalloc((void **)&m->big_keys, (size_t)slots * (sizeof(unsigned long long) + sizeof(uint32_t))));
-  m->chunk_cap = (uint32_t)chunks;
-  m->raw_cap = (uint32_t)raw_records;
+  m->sub_cap = (uint32_t)subs;
   m->big_slots = (uint32_t)slots;
   m->prepped = false; // the new hash is filled by the stand-alone preparation pass
   return WS_OK;
@@ -219,8 +214,8 @@ static int map_free(ws_map *m)
       break;
     }
   map_free_records(m);
-  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_fill,
-                  m->tile_chunk, m->tile_dirty, m->tile_list, m->block_stats, m->box_stage};
+  void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nsub,
+                  m->tile_ent, m->tile_dirty, m->tile_list, m->block_stats, m->box_stage};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (m->counters_host) (void)hipHostFree(m->counters_host);
@@ -342,13 +337,12 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));
   TRY(hipMalloc((void **)&m->counters, sizeof(TsdfCounters)));
   TRY(hipMemsetAsync(m->counters, 0, sizeof(TsdfCounters), s));
-  // per-tile bookkeeping of the scatter: record count, chunk table, a byte, one 16-byte list entry per 1024 voxels
-  TRY(hipMalloc((void **)&m->tile_fill, (size_t)m->n_tiles * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->tile_chunk, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t)));
+  // per-tile bookkeeping of the scatter: entry count, entry table (64 x 4 bytes), two bytes, one 16-byte list entry per 1024 voxels
+  TRY(hipMalloc((void **)&m->tile_nsub, (size_t)m->n_tiles * sizeof(uint32_t)));
+  TRY(hipMalloc((void **)&m->tile_ent, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t) + 256));
   TRY(hipMalloc((void **)&m->tile_dirty, 2 * tile_flag_plane_bytes(m->n_tiles)));
   TRY(hipMalloc((void **)&m->tile_list, (size_t)m->n_tiles * sizeof(TileEntry)));
-  TRY(hipMemsetAsync(m->tile_fill, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
-  TRY(hipMemsetAsync(m->tile_chunk, 0, (size_t)m->n_tiles * TILE_DIRECT * sizeof(uint32_t), s));
+  TRY(hipMemsetAsync(m->tile_nsub, 0, (size_t)m->n_tiles * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->tile_dirty, 0, 2 * tile_flag_plane_bytes(m->n_tiles), s));
   TRY(hipMalloc((void **)&m->block_stats, (size_t)WS_BLOCK_STATS * sizeof(uint32_t)));
   TRY(hipMemsetAsync(m->block_stats, 0, (size_t)WS_BLOCK_STATS * sizeof(uint32_t), s));
@@ -356,9 +350,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipHostMalloc((void **)&m->status_host, 64, hipHostMallocMapped));
   std::memset(m->status_host, 0, 64);
   TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
-  // chunks of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
-  // every scan checks the buffer against its own bound and grows it first if it must, ws_tsdf_set_capacity() reserves up front
-  rc = map_alloc_records(m, chunks_for_scan(m, 80ull << 20, 131072), 36ull << 20);
+  // the pool of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
+  // a scan that needs more is aborted and repeated with a larger pool, ws_tsdf_set_capacity() reserves up front
+  rc = map_alloc_records(m, subs_for_scan(m, 80ull << 20, 131072));
   if (rc != WS_OK)
   {
     map_free(m);
@@ -680,7 +674,7 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
-  return map_alloc_records(m, (records + CHUNK_RECS - 1) / CHUNK_RECS, records);
+  return map_alloc_records(m, (records + SUB_RECS - 1) / SUB_RECS);
 }
 
 int ws_debug_tsdf_chunk_policy(ws_map *m, uint64_t budget_bytes, uint32_t est_shift)
@@ -757,7 +751,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   out->runs = c->last_runs;
   out->free_space_hits = c->last_free_keyed;
   out->record_slots = (int64_t)c->last_need;
-  out->record_capacity = (int64_t)m->chunk_cap * CHUNK_RECS;
+  out->record_capacity = (int64_t)m->sub_cap * SUB_RECS;
   const int rc = map_take_error(m);
   out->error_flags = (int32_t)m->last_error_bits;
   out->pad = 0;
@@ -1364,9 +1358,9 @@ int ws_prof_reset(ws_context *ctx)
 
 namespace ws
 {
-int resize_records(ws_map *m, uint64_t chunks, uint64_t raw_records)
+int resize_records(ws_map *m, uint64_t sub_chunks)
 {
   WS_HIP(hipStreamSynchronize(m->ctx->stream)); // nothing enqueued may still use the old buffers
-  return map_alloc_records(m, chunks, raw_records);
+  return map_alloc_records(m, sub_chunks);
 }
 } // namespace ws

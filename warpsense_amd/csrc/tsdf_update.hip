@@ -61,18 +61,16 @@ struct ScatterArgs
   const int32_t *fan_steps; // [256], see tail_bound
   uint8_t *vstate;     // two planes of one byte per voxel: VOX_* / off-ray free-space mark
   uint8_t *tile_dirty; // one byte per tile: touched by the free-space pass
-  uint32_t *tile_fill;  // [tiles] records of the tile
-  uint32_t *tile_chunk; // [tiles][TILE_DIRECT] chunk id + 1
-  TileEntry *tile_list; // the tiles with records (the first reservation of a tile appends it; the resolve deals them out evenly)
-  unsigned long long *rec; // chunks of CHUNK_RECS records
-  uint32_t chunk_cap;
+  uint32_t *tile_nsub;  // [tiles] sub-chunks (entries) of the tile
+  uint32_t *tile_ent;   // [tiles][TILE_DIRECT] entries: sub-chunk id << 5 | records - 1
+  TileEntry *tile_list; // the tiles with records (the first entries of a tile append it; the resolve deals them out evenly)
+  unsigned long long *rec; // the pool: sub-chunks of SUB_RECS records
+  uint32_t sub_cap;
   uint32_t scan_seq;  // sequence number of this scatter
-  unsigned long long *big_keys; // (tile, chunk number) -> chunk id beyond TILE_DIRECT: keys, then uint32 values (big_mask + 1 slots)
+  unsigned long long *big_keys; // (tile, entry number) -> entry + 1 beyond TILE_DIRECT: keys, then uint32 values (big_mask + 1 slots)
   uint32_t big_mask;
-  uint32_t est_shift; // != 0: the chunk buffer is sized by estimate (need >> (est_shift - 1)), not by the hard bound: see chunks_needed()
-  uint32_t raw_cap;   // records the raw buffer holds (it lies behind the chunks: rec + chunk_cap * 256 * 8 bytes, 16 bytes per record)
   uint32_t pad0;
-  uint32_t *tail_stats; // records / flush groups per workgroup of the tail march
+  uint32_t *tail_stats; // records / (flush, tile) groups per workgroup of the tail march
   TsdfCounters *counters;
   uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number, [8] / [9] see ws_map::status_host
 };
@@ -92,7 +90,11 @@ constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTE
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
+#ifndef WS_SORT_CELLS
+#define WS_SORT_CELLS 1
+#endif
 constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
+static_assert(AZ_ONLY_BINS * EL_BINS == 64 * 64 * 2, "the cell sort uses the same 8192 bins");
 constexpr int AZ_BINS = AZ_ONLY_BINS * EL_BINS; // direction bins: azimuth major, elevation minor
 
 size_t ray_setup_bytes() { return sizeof(RaySetup); }
@@ -134,8 +136,7 @@ struct PrepArgs
   TsdfCounters *counters;
   uint32_t *az_hist;
   uint32_t n_hist;
-  uint32_t *tile_fill;
-  uint32_t *tile_chunk;
+  uint32_t *tile_nsub;
   uint8_t *tile_dirty;
   int64_t n_tiles;
   unsigned long long *big_keys;
@@ -146,9 +147,8 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
   for (int64_t i = tid; i < p.n_hist; i += stride) p.az_hist[i] = 0;
-  for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_fill[i] = 0;
+  for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nsub[i] = 0;
   for (int64_t i = tid; i < (int64_t)(2 * tile_flag_plane_bytes(p.n_tiles)); i += stride) p.tile_dirty[i] = 0;
-  for (int64_t i = tid; i < p.n_tiles * TILE_DIRECT; i += stride) p.tile_chunk[i] = 0;
   uint32_t *big_vals = reinterpret_cast<uint32_t *>(p.big_keys + p.big_slots);
   for (int64_t i = tid; i < p.big_slots; i += stride)
   {
@@ -157,19 +157,16 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
   }
 }
 
-// Chunks a scan whose records are bounded by `need` can use at most: every tile with records ends in one partly filled
-// chunk, so sum over tiles of ceil(r / 256) <= need / 256 + min(tiles, need).  est_shift != 0 (maps whose tile term alone
-// would cost gigabytes): an estimate instead -- the bound counts every sample as a candidate, about 2.3 x what a scan
-// makes -- and a scan that does exhaust the chunks is ABORTED (nothing of it reaches the maps) and repeated with more.
-// On top of either: the workgroups of the tail march take chunk ids in blocks of CHUNK_BLOCK (one request to the shared
-// counter per block instead of one per flush) and leave the rest of their last block unused.
-constexpr uint32_t CHUNK_BLOCK = 32;
-__host__ __device__ inline unsigned long long chunks_needed(unsigned long long need, unsigned long long n_tiles, uint32_t est_shift, unsigned long long n_points)
+// Sub-chunks the pool should hold for a scan of `n_points` rays whose records are bounded by `need`: the block every
+// workgroup of the tail march starts with, the records themselves (the bound counts every sample as a candidate, about 2.7 x
+// what a scan makes; est_shift > 1 takes a fraction of it: tests), and room for the partly filled ones.  An estimate -- the
+// number of (wave, tile) pairs has no useful bound -- and never more than that: a scan that does exhaust the pool is ABORTED
+// (nothing of it reaches the maps) and repeated with more (launch_tsdf_scatter).
+__host__ inline unsigned long long subs_needed(unsigned long long need, uint32_t est_shift, unsigned long long n_points)
 {
-  const unsigned long long blocks = ((n_points + 63) / 64 * 2 + 1) * CHUNK_BLOCK; // (TAIL_SPLIT == 2 workgroups per 64 rays)
-  if (est_shift) return ((need >> CHUNK_BITS) >> (est_shift - 1)) + 4096ull + blocks;
-  const unsigned long long used = (need >> CHUNK_BITS) + (n_tiles < need ? n_tiles : need);
-  return used + used / 4 + blocks + 64ull; // (a refill leaves up to a quarter of a block behind)
+  const unsigned long long items = (n_points + 63) / 64 * 2 + 1; // (TAIL_SPLIT == 2 workgroups per 64 rays)
+  const unsigned long long free_waves = (n_points + 63) / 64 * 4; // (64 rays per workgroup of the free pass)
+  return items * SUB_WG_BLOCK + free_waves * 16 + ((need >> SUB_BITS) >> (est_shift ? est_shift - 1 : 0)) + 8192ull;
 }
 
 // Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
@@ -193,20 +190,19 @@ __device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1,
 // update_tsdf.cu:52-63 for one ray per lane, plus the split of the ray into free-space steps and tail
 __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
 {
-  __shared__ unsigned long long ub_wave[8];
+  __shared__ unsigned long long ub_wave[4];
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix == 0)
   {
     // what the marches of this scan count up (the previous scan's integrate pass has read its tile list by now)
     a.counters->chunk_cursor = 0;
-    a.counters->raw_cursor = 0;
+    a.counters->free_cursor = 0;
     a.counters->n_listed = 0;
     a.counters->abort = 0;
     a.counters->error = 0;
     a.counters->last_free_keyed = 0;
     a.counters->last_unlisted = 0;
   }
-  unsigned long long ub_tail = 0;
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
@@ -217,6 +213,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
   const int32_t res = a.res, tau = a.tau, half = res / 2;
   bool ok = false;
   int32_t px = 0, py = 0, pz = 0;
+  int32_t hvx = 0, hvy = 0, hvz = 0; // voxel of the scan point
   if (ix < a.n)
   {
     px = a.xyz[3 * (size_t)ix + 0];
@@ -228,6 +225,9 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
     const int32_t cy = (int32_t)floorf(__fdiv_rn((float)py, fr));
     const int32_t cz = (int32_t)floorf(__fdiv_rn((float)pz, fr));
     ok = in_bounds_buffer(a.map, cx, cy, cz, (int64_t)(tau / res / 2));
+    hvx = cx;
+    hvy = cy;
+    hvz = cz;
   }
   if (ok)
   {
@@ -320,20 +320,29 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
           r.kfirst = kfirst;
           // records this ray can make: the scatter targets of its tail + one per free-space step (a free-space candidate that
           // lands on a voxel with records joins them)
-          ub_tail = tail_bound(kfirst, steps, len_end, a.fan_steps);
-          const unsigned long long ub = ub_tail + (unsigned long long)kfirst;
+          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps) + (unsigned long long)kfirst;
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
     }
   }
-  // direction bin of the ray (any monotone function of the direction would do: it only groups rays that lie in
-  // the same vertical plane, whose voxels share tiles); bin AZ_BINS = unused ray
+  // Sort bin of the ray; bin AZ_BINS = unused ray.  The tails are sorted by WHERE THE RAY ENDS: a 64 x 64 grid of cells over the
+  // map window (0.4 m at 513^3 / 50 mm), above / below the sensor -- the tail of a ray lies within tau of its end, so the 64
+  // rays of a wave of the tail march put their records into the few tiles around one cell.  (Until round 4 the key was the
+  // direction, 1024 azimuths x 8 elevations: rays of one direction bin that graze the floor end metres apart, a wave's
+  // records fell into 27 tiles on average, 28 records per (wave, tile) pair.)
   if (ix < a.n)
   {
     uint32_t bin = AZ_BINS;
     if (r.steps > 0)
     {
+#if WS_SORT_CELLS
+      const int32_t cwx = (a.map.size[0] + 63) / 64, cwy = (a.map.size[1] + 63) / 64;
+      int bx = (hvx - a.map.pos[0] + a.map.size[0] / 2) / cwx, by = (hvy - a.map.pos[1] + a.map.size[1] / 2) / cwy;
+      bx = bx < 0 ? 0 : (bx > 63 ? 63 : bx);
+      by = by < 0 ? 0 : (by > 63 ? 63 : by);
+      bin = (uint32_t)((bx * 64 + by) * 2 + (hvz >= a.scanner_pos[2] ? 1 : 0));
+#else
       const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
       int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
       b = b < 0 ? 0 : (b >= AZ_ONLY_BINS ? AZ_ONLY_BINS - 1 : b);
@@ -342,6 +351,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
       int e = (int)((se + 0.5f) * (float)EL_BINS);
       e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
       bin = (uint32_t)(b * EL_BINS + e);
+#endif
     }
     r.pad |= (int32_t)(bin << 1); // bits 1 .. 14 (RAY_SIMPLE is bit 30)
     // the histogram's old value is this ray's rank inside its bin: the sort blocks place it without a second atomic.
@@ -353,25 +363,11 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
   }
   // The records this scan can make (sum of the per-ray bounds): every scan sizes the record buffers itself.
   unsigned long long ub = r.ub;
-  for (int d = 32; d > 0; d >>= 1)
-  {
-    ub += __shfl_down(ub, d, 64);
-    ub_tail += __shfl_down(ub_tail, d, 64);
-  }
-  if ((threadIdx.x & 63) == 0)
-  {
-    ub_wave[threadIdx.x >> 6] = ub;
-    ub_wave[4 + (threadIdx.x >> 6)] = ub_tail;
-  }
+  for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
+  if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
   __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    // two fire-and-forget adds per workgroup: the records the scan can make (tails + free-space steps: what the chunks must
-    // hold) and the tail records alone (what the raw buffer must hold).  The direction sort -- the next launch -- hands the
-    // totals to the host.
-    atomicAdd(&a.counters->ub_tail, ub_wave[4] + ub_wave[5] + ub_wave[6] + ub_wave[7]);
-    atomicAdd(&a.counters->ub_total, ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3]);
-  }
+  // one fire-and-forget add per workgroup; the direction sort -- the next launch -- hands the total to the host
+  if (threadIdx.x == 0) atomicAdd(&a.counters->ub_total, ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3]);
 }
 
 // Counting sort of the rays by direction bin (a launch of its own behind the set-up pass: fused into it, with the sort
@@ -388,7 +384,6 @@ __global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 12), a.counters->ub_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.status + 4), a.counters->ub_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 6, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -433,29 +428,59 @@ __global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a)
 __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a) { ray_setup_block(a); }
 
 // ---------------------------------------------------------------------------------------------------------
-// records of a tile: chunks, reservation, look-up
+// records of a tile: the pool of sub-chunks, the tile's entry table
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void store_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-constexpr long long CHUNK_WAIT_TICKS = 2000000ll; // 20 ms on the 100 MHz wall clock: a chunk id that has not appeared by then never will
-
 __device__ __forceinline__ unsigned long long big_key(uint32_t tile, uint32_t j) { return ((unsigned long long)tile << 24) | j; } // j < 2^23
 __device__ __forceinline__ uint32_t big_slot(unsigned long long key, uint32_t mask) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask; }
 
-// a scan that runs out of chunks is aborted: its records are dropped from here on, the later kernels only put the scratch
-// back and the host repeats the scan with a larger buffer (launch_tsdf_scatter)
+// the scan in flight ran out of sub-chunks: from here on nothing of it may reach the maps -- the resolve only puts the scratch
+// back and the host repeats the scan with a larger pool (launch_tsdf_scatter)
 __device__ __forceinline__ void raise_abort(const ScatterArgs &a)
 {
   __hip_atomic_store(&a.counters->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// chunk number j of `tile` is chunk id1 - 1 (or CHUNK_LOST).  Never waits for anybody.
-__device__ __forceinline__ void chunk_publish(const ScatterArgs &a, uint32_t tile, uint32_t j, uint32_t id1)
+// The pool, bottom to top: [one block of SUB_WG_BLOCK ids per work item of the tail march | what its waves ask for on top of
+// that (chunk_cursor, upwards) ... (free_cursor, downwards) what the waves of the free pass ask for on top of | FREE_WAVE_FIRST
+// ids per wave of the free pass].  The fixed parts cost no request at all: a returning atomic on ONE address takes ~40 ns
+// under load (measured: 25 000 of them, one per free-space record, made the free pass 1.16 ms instead of 0.12), so the
+// shared counters are for the exceptions.
+constexpr uint32_t FREE_WAVE_FIRST = 16; // (subs_needed() counts them)
+#ifndef WS_TAIL_SPLIT
+#define WS_TAIL_SPLIT 2
+#endif
+__device__ __forceinline__ uint32_t tail_static_subs(const ScatterArgs &a) { return ((a.n + 63u) / 64u) * (uint32_t)WS_TAIL_SPLIT * SUB_WG_BLOCK; }
+__device__ __forceinline__ uint32_t free_static_subs(const ScatterArgs &a) { return ((a.n + 63u) / 64u) * 4u * FREE_WAVE_FIRST; }
+__device__ __forceinline__ bool pool_holds_static(const ScatterArgs &a)
+{
+  return (unsigned long long)tail_static_subs(a) + free_static_subs(a) <= (unsigned long long)a.sub_cap;
+}
+// n more consecutive sub-chunk ids for a wave of the tail march, or SUB_LOST
+__device__ __forceinline__ uint32_t pool_grab(const ScatterArgs &a, uint32_t n)
+{
+  const uint32_t b = __hip_atomic_fetch_add(&a.counters->chunk_cursor, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long lo = (unsigned long long)tail_static_subs(a) + b;
+  if (pool_holds_static(a) && lo + n <= (unsigned long long)a.sub_cap - free_static_subs(a)) return (uint32_t)lo;
+  raise_abort(a);
+  return SUB_LOST;
+}
+// ... for the free pass (the next launch: chunk_cursor is final), from the top down
+__device__ __forceinline__ uint32_t free_grab(const ScatterArgs &a, uint32_t n)
+{
+  const unsigned long long lo = (unsigned long long)tail_static_subs(a) + a.counters->chunk_cursor;
+  const uint32_t d = __hip_atomic_fetch_add(&a.counters->free_cursor, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long top = (unsigned long long)a.sub_cap - free_static_subs(a);
+  if (pool_holds_static(a) && lo + d + n <= top) return (uint32_t)(top - d - n);
+  raise_abort(a);
+  return SUB_LOST;
+}
+
+// entry number j of `tile`: into the tile's table, or -- beyond TILE_DIRECT -- into the hash (value: entry + 1)
+__device__ __forceinline__ void entry_publish(const ScatterArgs &a, uint32_t tile, uint32_t j, uint32_t ent)
 {
   if (j < (uint32_t)TILE_DIRECT)
   {
-    store_agent(&a.tile_chunk[(size_t)tile * TILE_DIRECT + j], id1);
+    a.tile_ent[(size_t)tile * TILE_DIRECT + j] = ent;
     return;
   }
   const unsigned long long key = big_key(tile, j);
@@ -466,90 +491,17 @@ __device__ __forceinline__ void chunk_publish(const ScatterArgs &a, uint32_t til
     const unsigned long long old = atomicCAS(&a.big_keys[h], KEY_INF, key);
     if (old == KEY_INF || old == key)
     {
-      // (a key stays in the table when its tile is released -- only the value goes back to "not published" -- so that the
-      // probe chains through it stay whole; the host empties the whole table before it fills up)
+      // (a key stays in the table when its tile is released -- only the value goes back to 0 -- so that the probe chains
+      // through it stay whole; the host empties the whole table before it fills up)
       if (old == KEY_INF) atomicAdd(&a.counters->big_inserted, 1u);
-      store_agent(&vals[h], id1);
+      vals[h] = ent + 1u;
       return;
     }
     h = (h + 1) & a.big_mask;
   }
-  raise_error(a.counters, a.status, ERR_INTERNAL); // (the table has two slots per chunk)
+  raise_error(a.counters, a.status, ERR_INTERNAL); // (the table has two slots per sub-chunk of the pool)
 }
-
-// the chunk somebody else had to open (the one whose reservation covered the chunk's first record): poll until its id is
-// there.  The owner publishes right after its own reservation and never waits in between, so this ends.
-__device__ __forceinline__ uint32_t chunk_lookup(const ScatterArgs &a, uint32_t tile, uint32_t j)
-{
-  uint32_t spins = 0;
-  long long t0 = 0;
-  const unsigned long long key = big_key(tile, j);
-  const uint32_t *vals = reinterpret_cast<const uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
-  for (;;)
-  {
-    uint32_t v = CHUNK_NONE;
-    if (j < (uint32_t)TILE_DIRECT)
-      v = load_agent(&a.tile_chunk[(size_t)tile * TILE_DIRECT + j]);
-    else
-    {
-      uint32_t h = big_slot(key, a.big_mask);
-      for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
-      {
-        const unsigned long long cur = __hip_atomic_load(&a.big_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == key)
-        {
-          v = load_agent(&vals[h]);
-          break;
-        }
-        if (cur == KEY_INF) break; // not inserted yet
-        h = (h + 1) & a.big_mask;
-      }
-    }
-    if (v != CHUNK_NONE) return v;
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 255u) == 0)
-    {
-      const long long now = wall_clock64();
-      if (t0 == 0) t0 = now;
-      if (now - t0 > CHUNK_WAIT_TICKS)
-      {
-        raise_error(a.counters, a.status, ERR_INTERNAL);
-        raise_abort(a);
-        return CHUNK_LOST;
-      }
-    }
-  }
-}
-
-// c records more for `tile`: the position of the first in the tile's record sequence, and the chunks that BEGIN inside the
-// range -- those are this caller's to open
-struct Reserve
-{
-  uint32_t p0;    // position of the first record
-  uint32_t j_new; // first chunk number to open
-  uint32_t n_new; // chunks to open
-};
-__device__ __forceinline__ Reserve reserve_from(uint32_t old_fill, uint32_t c)
-{
-  Reserve r;
-  r.p0 = old_fill;
-  r.j_new = (r.p0 + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
-  const uint32_t j_last = (r.p0 + c - 1u) >> CHUNK_BITS;
-  r.n_new = j_last >= r.j_new ? j_last - r.j_new + 1u : 0u;
-  return r;
-}
-__device__ __forceinline__ uint32_t chunk_id1(const ScatterArgs &a, uint32_t cid)
-{
-  if (cid < a.chunk_cap) return cid + 1u;
-  raise_abort(a);
-  return CHUNK_LOST;
-}
-// chunk number j of `tile` is chunk `cid`: into the tile's table
-__device__ __forceinline__ void open_chunk(const ScatterArgs &a, uint32_t tile, uint32_t j, uint32_t cid)
-{
-  chunk_publish(a, tile, j, chunk_id1(a, cid));
-}
-// the tile got its first records: entry `at` of the scan's tile list, and the flag byte that keeps the resolve's scan for
+// the tile got its first entries: place `at` of the scan's tile list, and the flag byte that keeps the resolve's scan for
 // tiles WITHOUT records away from it
 __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uint32_t tile)
 {
@@ -562,48 +514,21 @@ __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uin
   a.tile_list[at] = e;
   a.tile_dirty[tile_flag_plane_bytes((int64_t)a.ntx * a.nty * a.ntz) + tile] = 1;
 }
-__device__ __forceinline__ void store_rec(const ScatterArgs &a, uint32_t id1, uint32_t q, unsigned long long rec)
-{
-  if (id1 != CHUNK_LOST) a.rec[(size_t)(id1 - 1u) * CHUNK_RECS + (q & (uint32_t)(CHUNK_RECS - 1))] = rec;
-}
+__device__ __forceinline__ uint32_t make_entry(uint32_t id, uint32_t fill) { return (id << SUB_BITS) | (fill - 1u); }
 
-// one record, straight to its tile (a free-space candidate on a keyed voxel; the tail march when its tile table cannot
-// take another tile).  All lanes publish what they have to open BEFORE any lane polls (two regions, in this order: a lane
-// may be waiting for a chunk a neighbouring lane of its own wave opens).
-#ifndef WS_APPEND_INLINE
-#define WS_APPEND_INLINE 1
-#endif
-#if WS_APPEND_INLINE
-__device__ __forceinline__
-#else
-__device__ __attribute__((noinline))
-#endif
-void append_record(const ScatterArgs &a, uint32_t tile, unsigned long long rec)
+// one record in a sub-chunk of its own (a free-space candidate on a keyed voxel: 25 000 of the benchmark scan's 21 million)
+__device__ __forceinline__ void append_single(const ScatterArgs &a, uint32_t tile, uint32_t id, unsigned long long rec)
 {
-  const Reserve r = reserve_from(__hip_atomic_fetch_add(&a.tile_fill[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 1u);
-  uint32_t id1 = CHUNK_NONE;
-  if (r.n_new)
-  {
-    const uint32_t cid = __hip_atomic_fetch_add(&a.counters->chunk_cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    id1 = chunk_id1(a, cid);
-    open_chunk(a, tile, r.j_new, cid);
-    if (r.p0 == 0) list_tile(a, __hip_atomic_fetch_add(&a.counters->n_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tile);
-  }
-  asm volatile("" ::: "memory");
-  if (id1 == CHUNK_NONE) id1 = chunk_lookup(a, tile, r.p0 >> CHUNK_BITS);
-  store_rec(a, id1, r.p0, rec);
+  if (id == SUB_LOST) return;
+  a.rec[(size_t)id << SUB_BITS] = rec;
+  const uint32_t j = __hip_atomic_fetch_add(&a.tile_nsub[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  entry_publish(a, tile, j, make_entry(id, 1u));
+  if (j == 0) list_tile(a, __hip_atomic_fetch_add(&a.counters->n_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ray tails -> records, through a per-wave slice of the raw buffer to the chunks of their tiles
+// ray tails -> records, straight into sub-chunks of their tiles
 // ---------------------------------------------------------------------------------------------------------
-#ifndef WS_HT_BITS
-#define WS_HT_BITS 10
-#endif
-// tiles the table of a workgroup of the tail march holds.  64 rays x half their tails fall into ~40-140 tiles at 50 mm, but at
-// 20 mm -- 80 mm tiles, fans from 3.3 m on -- into 250 and more: with 256 slots most records of the 2049^3 @ 20 mm scan overflowed
-// the table and went to their tiles one by one (tail march 12.7 ms; 1024 slots: see DESIGN.md)
-constexpr int HT_BITS = WS_HT_BITS, HT_SLOTS = 1 << HT_BITS;
 #ifndef WS_TAIL_SPLIT
 #define WS_TAIL_SPLIT 2
 #endif
@@ -613,29 +538,54 @@ constexpr int HT_BITS = WS_HT_BITS, HT_SLOTS = 1 << HT_BITS;
 #ifndef WS_TAIL_BLIND
 #define WS_TAIL_BLIND 1 // off-ray candidates of value +tau as marks in the second byte plane instead of records (2.1 M of the benchmark scan's 14.4 M)
 #endif
-#ifndef WS_COPY_U
-#define WS_COPY_U 4 // records a thread has in flight while it copies the workgroup's records to their tiles
-#endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
-static_assert(HT_SLOTS % 256 == 0 && HT_SLOTS <= 2048, "the flush gives every thread HT_SLOTS / 256 slots of the tile table");
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 
-__device__ __forceinline__ int ht_insert(uint32_t *keys, uint32_t tile)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4; // four consecutive voxels of a column: dword aligned only
+typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate bytes
+
+// What a wave of the tail march keeps in LDS about the records it has made since it last published (wave_flush): nothing in
+// here is shared with another wave -- no barrier, no waiting; LDS operations of one wave are performed in order.
+//   key / cnt     the tiles of those records (open addressing) and how many each has: the counter's old value IS the record's
+//                 place -- sub-chunk rank >> 5 of the wave's sub-chunks for that tile, position rank & 31
+//   sub_of        the (local number of the) sub-chunks rank >> 5 = ..., modulo 4: one round of puts -- at most 64 records --
+//                 spans three of a tile's sub-chunks at most
+//   owner         local sub-chunk -> (slot, rank >> 5): what the flush publishes
+//   blk           local sub-chunk l lives in pool sub-chunk blk[(l >> 5) & 7] + (l & 31): the wave's ids come in runs of 32
+// Local numbers count up for the life of the wave; [flushed, n_local) are the ones not yet published, [n_local, covered) have
+// an id waiting.  All of it modulo 256: flushed, rounded down to 32, and covered are never more than 256 apart.
+constexpr int WT_BITS = 8, WT_SLOTS = 1 << WT_BITS;
+constexpr uint32_t WT_SLOT_LIMIT = 224; // tiles in the table before the wave publishes and starts over
+constexpr uint32_t WT_LOCAL_LIMIT = 160; // sub-chunks in flight before it does
+struct WaveTab
 {
-  uint32_t h = (tile * 0x9E3779B1u) >> (32 - HT_BITS);
-  for (int p = 0; p < HT_SLOTS; ++p)
+  uint32_t key[WT_SLOTS];
+  uint32_t cnt[WT_SLOTS]; // (wave_flush: | first entry number << 13)
+  uint8_t sub_of[WT_SLOTS][4];
+  uint16_t owner[256];
+  uint32_t blk[8];
+  uint32_t n_local, n_slots, flushed, covered;
+  uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
+};
+
+__device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile)
+{
+  uint32_t h = (tile * 0x9E3779B1u) >> (32 - WT_BITS);
+  for (int p = 0; p < WT_SLOTS; ++p)
   {
-    const uint32_t cur = keys[h];
+    const uint32_t cur = wt.key[h];
     if (cur == tile) return (int)h;
     if (cur == HT_EMPTY)
     {
-      const uint32_t old = atomicCAS(&keys[h], HT_EMPTY, tile);
+      const uint32_t old = atomicCAS(&wt.key[h], HT_EMPTY, tile);
+      if (old == HT_EMPTY) atomicAdd(&wt.n_slots, 1u);
       if (old == HT_EMPTY || old == tile) return (int)h;
     }
-    h = (h + 1) & (HT_SLOTS - 1);
+    h = (h + 1) & (WT_SLOTS - 1);
   }
-  return -1;
+  return -1; // (never: wave_room keeps 32 slots free)
 }
 
 // inclusive prefix sum over the 64 lanes: four DPP shifts inside the rows of 16 (guarded: a lane whose source lies outside
@@ -657,204 +607,169 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
   return v + (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 __attribute__((aligned(4))) u32x4_a4; // four consecutive voxels of a column: dword aligned only
-typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate bytes
-
-// does the scan in flight fit the chunk buffer?  (uniform: the set-up pass has finished, its total is final)
-__device__ __forceinline__ bool scan_fits(const ScatterArgs &a)
+// The wave publishes the sub-chunks it has filled since the last time and empties its table.  Any set of lanes may call it
+// (the general walk does, with whoever is there).  ONE memory round trip: a tile's entries are reserved with one atomic per
+// (wave, tile) -- four tiles per lane travel together -- and written behind it; a tile that had no entries yet goes on the
+// scan's tile list (one request to the list's counter per flush).
+__device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
 {
-  // a plain (scalar) load: the total was finished by an earlier kernel.  (As a coherent load by every thread -- a million of
-  // them on one address -- this line alone took the tail march from 190 to 500 us.)
-  const unsigned long long need = a.counters->ub_total & ((1ull << 48) - 1ull);
-  const unsigned long long n_tiles = (unsigned long long)a.ntx * (unsigned long long)a.nty * (unsigned long long)a.ntz;
-  return chunks_needed(need, n_tiles, a.est_shift, a.n) <= (unsigned long long)a.chunk_cap && a.counters->ub_tail <= (unsigned long long)a.raw_cap;
+  const unsigned long long act = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const uint32_t na = (uint32_t)__popcll(act), lr = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)act) - 1;
+  const uint32_t n_local = wt.n_local, flushed = wt.flushed;
+  if (n_local != flushed)
+  {
+    for (uint32_t s0 = 0; s0 < (uint32_t)WT_SLOTS; s0 += 4u * na)
+    {
+      uint32_t c[4], tile[4], j0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const uint32_t s = s0 + lr + (uint32_t)u * na;
+        c[u] = s < (uint32_t)WT_SLOTS ? wt.cnt[s] : 0u;
+        tile[u] = s < (uint32_t)WT_SLOTS ? wt.key[s] : 0u;
+        j0[u] = 0;
+        if (c[u]) j0[u] = __hip_atomic_fetch_add(&a.tile_nsub[tile[u]], (c[u] + (uint32_t)SUB_RECS - 1u) >> SUB_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      uint32_t my_first = 0, n_first = 0, n_used = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const uint32_t s = s0 + lr + (uint32_t)u * na;
+        const bool first = c[u] != 0 && j0[u] == 0;
+        const unsigned long long fm = __ballot(first);
+        if (first) my_first |= (n_first + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))) << (8 * u) | (0x80u << (8 * u));
+        n_first += (uint32_t)__popcll(fm);
+        n_used += (uint32_t)__popcll(__ballot(c[u] != 0));
+        if (c[u])
+        {
+          if (j0[u] >= (1u << 19) - 256u) raise_error(a.counters, a.status, ERR_INTERNAL); // (half a million entries of one tile: never)
+          wt.cnt[s] = c[u] | (j0[u] << 13);
+        }
+      }
+      // (n_first <= 4 * 64 would not fit the byte above for four full rounds of firsts: ranks are per lane below 2^7 only when
+      // n_first < 128 -- a flush of more than 127 new tiles takes the list places one by one)
+      if (n_first)
+      {
+        if (n_first < 128u)
+        {
+          uint32_t lb = 0;
+          if (lane == leader) lb = __hip_atomic_fetch_add(&a.counters->n_listed, n_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          lb = (uint32_t)__builtin_amdgcn_readlane((int)lb, leader);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (my_first & (0x80u << (8 * u))) list_tile(a, lb + ((my_first >> (8 * u)) & 0x7fu), tile[u]);
+        }
+        else
+        {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (my_first & (0x80u << (8 * u)))
+              list_tile(a, __hip_atomic_fetch_add(&a.counters->n_listed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), tile[u]);
+        }
+      }
+      if (lane == leader) wt.n_groups += n_used;
+    }
+    asm volatile("" ::: "memory");
+    // the sub-chunks: entry number = the tile's reservation + the sub-chunk's number among the wave's for that tile
+    const uint32_t nl = n_local - flushed;
+    for (uint32_t q = lr; q < nl; q += na)
+    {
+      const uint32_t gl = (flushed + q) & 255u;
+      const uint32_t o = wt.owner[gl];
+      const uint32_t s = o & 255u, sub = o >> 8;
+      const uint32_t cj = wt.cnt[s];
+      const uint32_t c = cj & 8191u, j0 = cj >> 13;
+      const uint32_t ns = (c + (uint32_t)SUB_RECS - 1u) >> SUB_BITS;
+      const uint32_t fill = sub + 1u == ns ? c - (sub << SUB_BITS) : (uint32_t)SUB_RECS;
+      const uint32_t base = wt.blk[(gl >> 5) & 7u];
+      if (base != SUB_LOST) entry_publish(a, wt.key[s], j0 + sub, make_entry(base + (gl & 31u), fill));
+    }
+    asm volatile("" ::: "memory");
+  }
+  for (uint32_t s = lr; s < (uint32_t)WT_SLOTS; s += na)
+  {
+    wt.key[s] = HT_EMPTY;
+    wt.cnt[s] = 0;
+  }
+  if (lane == leader)
+  {
+    wt.flushed = n_local;
+    wt.n_slots = 0;
+  }
+  asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long mine, unsigned long long *wave_sums, unsigned long long &total)
+// Room for `n_put` more records (n_put <= 64), whatever tiles they fall into: each can open one sub-chunk and one table slot
+// at most.  Publishes and / or asks the pool for 32 more ids when it must; returns how many records the wave can put before
+// it has to ask again (>= 64).  Uniform over the calling lanes.
+__device__ __forceinline__ uint32_t wave_room(const ScatterArgs &a, WaveTab &wt)
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
+  const unsigned long long act = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)act) - 1;
+  uint32_t nl = wt.n_local, ns = wt.n_slots, fl = wt.flushed, cov = wt.covered;
+  if (nl - fl + 64u > WT_LOCAL_LIMIT || ns + 64u > WT_SLOT_LIMIT || (cov - nl < 64u && cov + SUB_REFILL - (fl & ~31u) > 256u))
   {
-    const unsigned long long y = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += y;
+    wave_flush(a, wt);
+    fl = nl;
+    ns = 0;
   }
-  if (lane == 63) wave_sums[wave] = incl;
-  __syncthreads();
-  unsigned long long excl = incl - mine;
-  total = 0;
-  const int n_waves = blockDim.x >> 6;
-  for (int w = 0; w < n_waves; ++w)
+  while (cov - nl < 64u)
   {
-    if (w < wave) excl += wave_sums[w];
-    total += wave_sums[w];
+    // (flushed above if the ring of eight runs had no place for another)
+    uint32_t b = 0;
+    if (lane == leader)
+    {
+      b = pool_grab(a, SUB_REFILL);
+      wt.blk[(cov >> 5) & 7u] = b;
+      wt.covered = cov + SUB_REFILL;
+    }
+    cov += SUB_REFILL;
   }
-  __syncthreads();
-  return excl;
+  asm volatile("" ::: "memory");
+  const uint32_t r0 = WT_LOCAL_LIMIT - (nl - fl), r1 = WT_SLOT_LIMIT - ns, r2 = cov - nl;
+  return min(r0, min(r1, r2));
 }
 
-// a record on its way: the workgroup's slice of the raw buffer holds what the march emits, in emission order
-struct RawRec // 16 bytes
+// one record of the wave: its tile's slot, its rank there, the sub-chunk (opened by the record of rank 0 mod 32), its place
+__device__ __forceinline__ void wave_put(const ScatterArgs &a, WaveTab &wt, uint32_t tile, unsigned long long rec)
 {
-  unsigned long long rec;
-  uint32_t tile;
-  uint32_t slot; // of the tile in the workgroup's table (SLOT_NONE: the record went straight to its tile)
-};
-constexpr uint32_t SLOT_NONE = 0xffffffffu;
-
-struct TailShared
-{
-  // tile table: key (the tile; from the flush's reservations on: the chunk the slot's range starts in), count (then: copy
-  // cursor), first position of the range, the chunk behind the first -- 16 KB at 1024 slots: six workgroups per CU
-  uint32_t ht_key[HT_SLOTS], ht_cnt[HT_SLOTS], ht_base[HT_SLOTS], ht_c1[HT_SLOTS];
-  uint32_t block_base, block_next; // this workgroup's block of chunk ids and how many of them are taken
-  uint32_t n_first, list_base;     // tiles this workgroup is the first to reserve in, and where they go in the scan's tile list
-  uint32_t raw_base, n_groups;
-  uint32_t wave_ub[4];    // upper bound of the records of each wave's part of the tails: its private sub-slice of the workgroup's slice
-  uint32_t wave_count[4]; // records each wave has written into its sub-slice
-};
-
-// The workgroup's records go to their tiles: thread t owns slot t of the tile table.  ONE memory round trip in front of the
-// copy: the reservation in the tile's record sequence (its count is known) travels together with a read of the tile's chunk
-// table, the chunks the range opens come out of the workgroup's own block of ids (an LDS counter), and the chunk the range
-// starts in -- opened by whoever reserved its first record -- is in the table that was read along, unless that happened
-// in these very microseconds (then: poll).  total: records in the slice (uniform).
-__device__ __forceinline__ void tail_flush(const ScatterArgs &a, TailShared &sh, const RawRec *raw, const uint32_t total)
-{
-  const int t = threadIdx.x;
-  constexpr int SPT = HT_SLOTS / 256; // slots of the tile table per thread
-  uint32_t c[SPT], tile[SPT], old_fill[SPT], cid[SPT], first_rank[SPT];
-  unsigned long long tab[SPT][TILE_DIRECT / 2];
-  // all reservations (and the reads of the chunk tables) of a thread's slots travel together: one round trip
-#pragma unroll
-  for (int sp = 0; sp < SPT; ++sp)
+  const int s = wt_insert(wt, tile);
+  if (s < 0)
   {
-    c[sp] = sh.ht_cnt[t + 256 * sp];
-    tile[sp] = sh.ht_key[t + 256 * sp];
-    old_fill[sp] = 0;
-#pragma unroll
-    for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[sp][q] = 0;
-    if (c[sp])
-    {
-      old_fill[sp] = __hip_atomic_fetch_add(&a.tile_fill[tile[sp]], c[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long *tp = reinterpret_cast<const unsigned long long *>(a.tile_chunk + (size_t)tile[sp] * TILE_DIRECT);
-#pragma unroll
-      for (int q = 0; q < TILE_DIRECT / 2; ++q) tab[sp][q] = __hip_atomic_load(tp + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    raise_error(a.counters, a.status, ERR_INTERNAL);
+    return;
   }
-#pragma unroll
-  for (int sp = 0; sp < SPT; ++sp)
+  // (the lanes of a wave mostly hit ONE counter, and the LDS takes such atomics one lane at a time: the old value is used for
+  // everything -- no second atomic on the word)
+  const uint32_t rank = atomicAdd(&wt.cnt[s], 1u);
+  const uint32_t sub = rank >> SUB_BITS, pos = rank & (uint32_t)(SUB_RECS - 1);
+  if (pos == 0)
   {
-    const Reserve r = reserve_from(old_fill[sp], c[sp] ? c[sp] : 1u);
-    // the first reservation of a tile in this scan puts it on the tile list: one request to the list's counter per workgroup,
-    // sent behind this loop, needed behind the copy (its round trip runs under it)
-    first_rank[sp] = c[sp] != 0 && old_fill[sp] == 0 ? atomicAdd(&sh.n_first, 1u) : 0xffffffffu;
-    cid[sp] = 0;
-    if (c[sp] && r.n_new)
-    {
-      const uint32_t k = atomicAdd(&sh.block_next, r.n_new);
-      if (k + r.n_new <= CHUNK_BLOCK)
-        cid[sp] = sh.block_base + k;
-      else // (the block is used up: this group asks the shared counter itself)
-        cid[sp] = __hip_atomic_fetch_add(&a.counters->chunk_cursor, r.n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (uint32_t q = 0; q < r.n_new; ++q) open_chunk(a, tile[sp], r.j_new + q, cid[sp] + q);
-    }
+    const uint32_t g = atomicAdd(&wt.n_local, 1u);
+    wt.sub_of[s][sub & 3u] = (uint8_t)g;
+    wt.owner[g & 255u] = (uint16_t)((uint32_t)s | (sub << 8));
   }
-  asm volatile("" ::: "memory"); // everything this wave opens is published before any of its lanes polls
-#pragma unroll
-  for (int sp = 0; sp < SPT; ++sp)
-  {
-    if (c[sp] == 0) continue;
-    const Reserve r = reserve_from(old_fill[sp], c[sp]);
-    const bool aligned = (r.p0 & (uint32_t)(CHUNK_RECS - 1)) == 0;
-    uint32_t c0, c1 = CHUNK_NONE;
-    if (aligned)
-    {
-      c0 = chunk_id1(a, cid[sp]);
-      if (r.n_new >= 2) c1 = chunk_id1(a, cid[sp] + 1u);
-    }
-    else
-    {
-      const uint32_t j0 = r.p0 >> CHUNK_BITS;
-      const unsigned long long w = j0 < 2 ? tab[sp][0] : (j0 < 4 ? tab[sp][1] : (j0 < 6 ? tab[sp][2] : tab[sp][3]));
-      c0 = j0 < (uint32_t)TILE_DIRECT ? (uint32_t)((j0 & 1u) ? (w >> 32) : w) : CHUNK_NONE;
-      if (c0 == CHUNK_NONE) c0 = chunk_lookup(a, tile[sp], j0);
-      if (r.n_new >= 1) c1 = chunk_id1(a, cid[sp]);
-    }
-    sh.ht_base[t + 256 * sp] = r.p0;
-    sh.ht_key[t + 256 * sp] = c0; // (the tile is in this thread's registers and in every raw record: the slot is free for it)
-    sh.ht_c1[t + 256 * sp] = c1;
-    atomicAdd(&sh.n_groups, 1u);
-  }
-  __syncthreads();
-  uint32_t list_base = 0;
-  if (t == 0 && sh.n_first) list_base = __hip_atomic_fetch_add(&a.counters->n_listed, sh.n_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the copy: COPY_U records per thread and step, their loads issued together (unconditional, clamped: a load under a branch
-  // would be waited for on the spot), then the cursor atomics, then the stores
-  constexpr int CU = WS_COPY_U;
-  // (the slice is four sub-slices, one per wave of the march: record i of the workgroup sits at its wave's offset)
-  const uint32_t n0 = sh.wave_count[0], n1 = n0 + sh.wave_count[1], n2 = n1 + sh.wave_count[2];
-  const uint32_t o1 = sh.wave_ub[0], o2 = o1 + sh.wave_ub[1], o3 = o2 + sh.wave_ub[2];
-  for (uint32_t i0 = (uint32_t)t; i0 < total; i0 += 256u * CU)
-  {
-    u32x4 rr[CU];
-    uint32_t base[CU], q[CU];
-#pragma unroll
-    for (int u = 0; u < CU; ++u)
-    {
-      const uint32_t i = i0 + 256u * (uint32_t)u;
-      const uint32_t ic = i < total ? i : total - 1u;
-      const uint32_t at = ic < n0 ? ic : (ic < n1 ? o1 + (ic - n0) : (ic < n2 ? o2 + (ic - n1) : o3 + (ic - n2)));
-      rr[u] = *reinterpret_cast<const u32x4 *>(&raw[at]);
-      if (i >= total)
-      {
-        rr[u].w = SLOT_NONE;
-        rr[u].z = HT_EMPTY;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u)
-    {
-      const uint32_t sl = rr[u].w != SLOT_NONE ? rr[u].w & (uint32_t)(HT_SLOTS - 1) : 0u;
-      base[u] = sh.ht_base[sl];
-      q[u] = rr[u].w != SLOT_NONE ? base[u] + (rr[u].w >> HT_BITS) : 0u; // (the record's rank in its tile: from the march)
-      if (rr[u].w != SLOT_NONE) rr[u].w = sl;
-    }
-#pragma unroll
-    for (int u = 0; u < CU; ++u)
-    {
-      if (rr[u].w == SLOT_NONE)
-      {
-        // (beyond the end of the slice: z == HT_EMPTY; else a record whose tile found no room in the table)
-        if (rr[u].z != HT_EMPTY) append_record(a, rr[u].z, (unsigned long long)rr[u].x | ((unsigned long long)rr[u].y << 32));
-        continue;
-      }
-      const uint32_t jrel = (q[u] >> CHUNK_BITS) - (base[u] >> CHUNK_BITS);
-      // (a group of more than two chunks finds the others through the tile's table; this workgroup published them above)
-      const uint32_t id1 = jrel == 0 ? sh.ht_key[rr[u].w] : (jrel == 1 ? sh.ht_c1[rr[u].w] : chunk_lookup(a, rr[u].z, q[u] >> CHUNK_BITS));
-      store_rec(a, id1, q[u], (unsigned long long)rr[u].x | ((unsigned long long)rr[u].y << 32));
-    }
-  }
-  if (t == 0) sh.list_base = list_base;
-  __syncthreads();
-#pragma unroll
-  for (int sp = 0; sp < SPT; ++sp)
-    if (first_rank[sp] != 0xffffffffu) list_tile(a, sh.list_base + first_rank[sp], tile[sp]);
+  const uint32_t gl = wt.sub_of[s][sub & 3u];
+  const uint32_t base = wt.blk[(gl >> 5) & 7u];
+  if (base != SUB_LOST) a.rec[((size_t)(base + (gl & 31u)) << SUB_BITS) + pos] = rec;
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
-// targets fall into the same vertical slab of space, i.e. into few tiles.  The march writes its records to the workgroup's
-// slice of the raw buffer (coalesced, read back by the same workgroup a few microseconds later) and counts them per tile
-// in an LDS table; then the workgroup hands them to their tiles (tail_flush).  (Staging the records in LDS instead -- 2048 of
-// them, flushed whenever the area filled up -- cost two workgroups per CU of occupancy and the march state stayed live
-// across the flushes: 243-258 us against 187 for this shape, measured in round 4.)
+// targets of a wave fall into the same vertical slab of space, i.e. into few tiles.  Every wave is on its own: its records go
+// straight from the march into sub-chunks of their tiles (wave_put) and are published when it is through (wave_flush).
+// (Round 4 measured two other shapes first: the records through a slice of a raw buffer in HBM and a copy by the workgroup
+// into 2 KB chunks per tile -- 226-233 us, 66 of them the copy; and staged in LDS, flushed whenever the area filled up --
+// 243-258 us, it costs two workgroups per CU of occupancy.)
 __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
-  __shared__ TailShared sh;
+  __shared__ WaveTab s_tab[4];
   __shared__ u32x4 s_queue[4 * TAIL_QCAP];
+  __shared__ uint32_t s_stat[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveTab &wt = s_tab[wave];
 #ifdef WS_TAIL_TIMING
   const long long t_begin = wall_clock64();
 #endif
@@ -873,18 +788,29 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     ix = a.ray_order[slot];
     r = a.rays[ix];
   }
-  // ---- phase 0: a slice of the raw buffer for the upper bound of this workgroup's records, a block of chunk ids
+  // ---- phase 0: the work item's block of sub-chunk ids (fixed: no request to anybody), every wave's table
+  const uint32_t s_block = pool_holds_static(a) ? item * SUB_WG_BLOCK : SUB_LOST;
   if (threadIdx.x == 0)
   {
-    sh.n_groups = 0;
-    sh.block_next = 0;
-    sh.n_first = 0;
+    if (s_block == SUB_LOST) raise_abort(a);
+    s_stat[0] = s_stat[1] = 0;
+    a.tail_stats[item] = 0;
+    a.tail_stats[WS_TAIL_STATS + item] = 0;
   }
-  for (int i = threadIdx.x; i < HT_SLOTS; i += 256)
+  for (int i = lane; i < WT_SLOTS; i += 64)
   {
-    sh.ht_key[i] = HT_EMPTY;
-    sh.ht_cnt[i] = 0;
+    wt.key[i] = HT_EMPTY;
+    wt.cnt[i] = 0;
   }
+  if (lane == 0)
+  {
+    wt.n_local = wt.flushed = wt.n_slots = 0;
+    wt.covered = SUB_WAVE_FIRST;
+    wt.n_rec = wt.n_groups = 0;
+  }
+  __syncthreads();
+  if (s_block == SUB_LOST) return; // (the scan is aborted: the host repeats it with a larger pool)
+  if (lane < (int)(SUB_WAVE_FIRST / 32u)) wt.blk[lane] = s_block + (uint32_t)wave * SUB_WAVE_FIRST + (uint32_t)lane * 32u;
   int32_t k0 = 0, k1 = 0;
   if (has_ray && r.steps > 0 && r.kfirst < r.steps)
   {
@@ -894,72 +820,18 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     k1 = min(k0 + ch, kend);
   }
   const bool work = k0 < k1;
-  {
-    // every wave bounds the records of ITS part of the tails: its own sub-slice, so that positions in it are a count the
-    // wave keeps in a register (no cursor shared by the waves, no LDS atomic per emit phase)
-    unsigned long long ub = work ? tail_bound(k0, k1, (int64_t)r.distance + a.tau, a.fan_steps) : 0ull;
-    for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
-    if (lane == 0)
-    {
-      sh.wave_ub[wave] = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
-      sh.wave_count[wave] = 0;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    const unsigned long long ub = (unsigned long long)sh.wave_ub[0] + sh.wave_ub[1] + sh.wave_ub[2] + sh.wave_ub[3];
-    uint32_t base = 0xffffffffu;
-    if (ub == 0)
-      base = 0;
-    else if (ub <= a.raw_cap)
-    {
-      const uint32_t b = atomicAdd(&a.counters->raw_cursor, (uint32_t)ub);
-      if (b <= a.raw_cap - (uint32_t)ub) base = b;
-    }
-    if (base == 0xffffffffu) raise_error(a.counters, a.status, ERR_INTERNAL); // (the buffer holds the scan's bound: scan_fits)
-    sh.raw_base = base;
-    sh.block_base = __hip_atomic_fetch_add(&a.counters->chunk_cursor, CHUNK_BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (sh.raw_base == 0xffffffffu) return;
-  RawRec *const raw_wg = reinterpret_cast<RawRec *>(a.rec + (size_t)a.chunk_cap * CHUNK_RECS) + sh.raw_base;
-  uint32_t wave_off = 0;
-  for (int w = 0; w < wave; ++w) wave_off += sh.wave_ub[w];
-  RawRec *const raw = raw_wg + wave_off; // this wave's sub-slice
-  const uint32_t raw_ub = sh.wave_ub[wave];
-  uint32_t n_written = 0; // records this wave has written (uniform)
+  uint32_t n_written = 0; // records this wave has made (uniform; the general walk counts in LDS)
 
   // ---- phase 1: march, one record per scatter target
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
   const bool mark = !a.all_keyed;
   uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
-  // a record into position `pos` of the slice (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
-  auto put_record = [&](uint32_t pos, uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
+  // a record (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
+  auto put_record = [&](uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
     // the free-space pass must know that this voxel takes part in the key order
     if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    const unsigned long long rec = make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz));
-    // the workgroup's tile table is built on the fly (the slot travels with the record); a record the table has no room for
-    // (more than 256 tiles in one workgroup's records) is sent straight to its tile by the flush.  (Doing that HERE costs the
-    // march 15 vector registers for a path that never runs on a LiDAR scan: 91 instead of 76, five instead of six workgroups per CU.)
-    const int s = ht_insert(sh.ht_key, tile);
-    // the counter's old value is the record's rank among the workgroup's records of that tile: it travels with the record, so
-    // that the flush places it without a second atomic on the same word (the lanes of a wave mostly hit ONE counter, and the
-    // LDS takes such atomics one lane at a time: 17 M bank-conflict cycles per launch, most of the LDS pipe's time)
-    const uint32_t rank = s >= 0 ? atomicAdd(&sh.ht_cnt[s], 1u) : 0u;
-    if (pos < raw_ub)
-    {
-      u32x4 out;
-      out.x = (uint32_t)rec;
-      out.y = (uint32_t)(rec >> 32);
-      out.z = tile;
-      out.w = s >= 0 ? (uint32_t)s | (rank << HT_BITS) : SLOT_NONE;
-      if (rank >= (1u << (32 - HT_BITS))) raise_error(a.counters, a.status, ERR_INTERNAL); // (4 M records of one tile in one work item: never)
-      *reinterpret_cast<u32x4 *>(&raw[pos]) = out;
-    }
-    else
-      raise_error(a.counters, a.status, ERR_INTERNAL); // the upper bound must hold; never write out of the slice
+    wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz)));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
@@ -988,13 +860,10 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         }
         // fan step - mid: update_tsdf.cu:103-104 (`positive` == the on-ray step)
         const int32_t delta_z = wmul(DZ_PER_DISTANCE, 1 + kk * f.half) / MATRIX_RESOLUTION;
-        // (the lanes reach this point in varying company: the wave's count lives in LDS here, one atomic per call)
-        const unsigned long long active = __ballot(1);
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)active) - 1;
-        if (lane == leader) base = atomicAdd(&sh.wave_count[wave], (uint32_t)__popcll(active));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        put_record(base + (uint32_t)__popcll(active & ((1ull << lane) - 1ull)), ix, kk, step - delta_z / f.res, value, sx, sy, sz);
+        // (the lanes reach this point in varying company: room for whoever is here, counted in LDS)
+        (void)wave_room(a, wt);
+        atomicAdd(&wt.n_rec, 1u);
+        put_record(ix, kk, step - delta_z / f.res, value, sx, sy, sz);
       });
   }
   else if (__any(work))
@@ -1003,6 +872,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     // voxel column; the emit phase pops 64 of them and does update_tsdf.cu:81-125 with every lane busy
     u32x4 *queue = s_queue + wave * TAIL_QCAP;
     uint32_t qhead = 0, qtail = 0;
+    uint32_t cap_left = 0; // records the wave may put before it looks at its bookkeeping again (uniform)
     const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
     const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
     AxisRun ix0, iy0, iz0;
@@ -1081,15 +951,9 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
           mid = (int32_t)(__umulhi((uint32_t)delta_z, f.rM32) >> f.rS);
         }
       }
-      // the off-ray targets of a sample of value +tau are marks, not records; ONE reservation in the slice for the records
-      // of all 64 samples (a prefix sum over the lanes instead of a ballot + LDS atomic per fan step)
+      if (!__any(iter_steps > 0)) return;
+      // the off-ray targets of a sample of value +tau are marks, not records
       const bool blind = WS_TAIL_BLIND && mark && value == tau;
-      const uint32_t nrec = iter_steps == 0 ? 0u : (blind ? 1u : (uint32_t)iter_steps);
-      const uint32_t incl = wave_incl_scan(nrec);
-      const uint32_t batch = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      if (batch == 0) return;
-      uint32_t pos = n_written + incl - nrec;
-      n_written += batch;
       const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
                     lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
       auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
@@ -1100,29 +964,33 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
         sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
       };
-      // the on-ray target (fan step `mid`) first: always a record, and its tile is on the list through it
+      // Rounds of at most one target per lane: first the on-ray targets (fan step `mid`: always a record, and its tile is on
+      // the list through it), then the off-ray ones (update_tsdf.cu:107-125) fan step by fan step.  In front of every round
+      // the wave makes sure its bookkeeping has room for the records of the round (a scalar compare, nearly always).
       uint32_t mid_tile = 0xffffffffu;
-      if (iter_steps > 0)
+      for (int32_t round = -1;; ++round)
       {
-        int32_t sx, sy, sz;
-        target(mid, sx, sy, sz);
-        mid_tile = put_record(pos, s_ix, ek, 0, value, sx, sy, sz);
-        pos += 1;
-      }
-      // the off-ray targets (update_tsdf.cu:107-125)
-      // (the loop bound as a ballot per round: a maximum over the lanes by shuffles is six trips through the LDS pipe per emit phase)
-      for (int32_t step = 0; __any(step < iter_steps); ++step)
-      {
-        if (step < iter_steps && step != mid)
+        // (the loop bound as a ballot per round: a maximum over the lanes by shuffles is six trips through the LDS pipe per emit phase)
+        if (round >= 0 && !__any(round < iter_steps)) break;
+        const bool on = round < 0 ? iter_steps > 0 : (round < iter_steps && round != mid);
+        const bool puts = on && !(blind && round >= 0);
+        const uint32_t n_put = (uint32_t)__popcll(__ballot(puts));
+        if (n_put)
+        {
+          if (cap_left < n_put) cap_left = wave_room(a, wt);
+          cap_left -= n_put;
+          n_written += n_put;
+        }
+        if (on)
         {
           int32_t sx, sy, sz;
-          target(step, sx, sy, sz);
-          if (blind)
+          target(round < 0 ? mid : round, sx, sy, sz);
+          if (!puts)
             mark_negative(sx, sy, sz, mid_tile);
           else
           {
-            put_record(pos, s_ix, ek, step - mid, value, sx, sy, sz);
-            pos += 1;
+            const uint32_t tile = put_record(s_ix, ek, round < 0 ? 0 : round - mid, value, sx, sy, sz);
+            if (round < 0) mid_tile = tile;
           }
         }
       }
@@ -1139,16 +1007,22 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     }
     while (qtail != qhead) emit_batch();
   }
-  if (lane == 0) sh.wave_count[wave] = min(general ? sh.wave_count[wave] : n_written, raw_ub);
-  __syncthreads();
-  const uint32_t total = sh.wave_count[0] + sh.wave_count[1] + sh.wave_count[2] + sh.wave_count[3];
 #ifdef WS_TAIL_TIMING
   const long long t_mid = wall_clock64();
 #endif
-  if (threadIdx.x == 0) a.tail_stats[item] = total;
-  // ---- phase 2: the records to their tiles
-  if (total) tail_flush(a, sh, raw_wg, total);
-  if (threadIdx.x == 0) a.tail_stats[WS_TAIL_STATS + item] = sh.n_groups;
+  // ---- phase 2: the wave publishes what it has filled
+  wave_flush(a, wt);
+  if (lane == 0)
+  {
+    atomicAdd(&s_stat[0], n_written + wt.n_rec);
+    atomicAdd(&s_stat[1], wt.n_groups);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    a.tail_stats[item] = s_stat[0];
+    a.tail_stats[WS_TAIL_STATS + item] = s_stat[1];
+  }
 #ifdef WS_TAIL_TIMING
   // (instead of the statistics: 10 ns ticks of the march and of the flush of this item, and when it started)
   if (threadIdx.x == 0)
@@ -1165,10 +1039,6 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
-  // The whole update is enqueued before the host has seen the record bound of this scan (below: launch_tsdf_scatter).  If the
-  // scan does not fit the chunk buffer, NOTHING of it may happen: the tail march and the free pass leave at once (no byte
-  // of the map's state is touched, the later kernels find nothing to do), and the host grows the buffer and runs it again.
-  if (scan_fits(a) == false) return;
   if (blockIdx.x < n_items) tail_item(a, blockIdx.x);
 }
 
@@ -1202,18 +1072,68 @@ __device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFr
   p.k = k;
   p.b = a.vstate[p.idx];
 }
-__device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed)
+// the sub-chunks of the records the free pass makes (one each): a wave of the compacting walk keeps the rest of the 64 it
+// took from the pool (fb_next, fb_left: uniform); the general walk -- lanes in varying company -- asks for what it needs
+struct FreeBlock
 {
-  if (!p.valid) return;
+  uint32_t next, left;
+};
+#ifndef WS_FREE_SIMPLE
+#define WS_FREE_SIMPLE 0
+#endif
+template <bool CACHED>
+__device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed, FreeBlock &fb)
+{
   const uint32_t b = p.b;
-  if (b & VOX_KEYED)
+  const bool keyed = p.valid && (b & VOX_KEYED);
+#if WS_FREE_SIMPLE
+  if (keyed)
+  {
+    append_single(a, p.tile, free_grab(a, 1u), make_rec(p.ix, p.k, 0, a.tau, p.local));
+    n_keyed += 1;
+  }
+  const unsigned long long km = 0;
+#else
+  const unsigned long long km = __ballot(keyed);
+#endif
+  if (km)
   {
     // the voxel also has ordered candidates (from the tails): this one, (tau, +64) at its place in the order, joins the
     // records of the tile (25 000 of the benchmark scan's 21 million free-space candidates)
-    append_record(a, p.tile, make_rec(p.ix, p.k, 0, a.tau, p.local));
-    n_keyed += 1;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = (uint32_t)__popcll(km);
+    const int leader = __ffsll((long long)km) - 1;
+    uint32_t first;
+    if (CACHED)
+    {
+      if (fb.left < n)
+      {
+        uint32_t g = 0;
+        if (lane == leader) g = free_grab(a, 64u);
+        fb.next = (uint32_t)__builtin_amdgcn_readlane((int)g, leader);
+        fb.left = fb.next == SUB_LOST ? 0u : 64u;
+      }
+      first = fb.left ? fb.next : SUB_LOST;
+      if (fb.left)
+      {
+        fb.next += n;
+        fb.left -= n;
+      }
+    }
+    else
+    {
+      uint32_t g = 0;
+      if (lane == leader) g = free_grab(a, n);
+      first = (uint32_t)__builtin_amdgcn_readlane((int)g, leader);
+    }
+    if (keyed)
+    {
+      const uint32_t id = first == SUB_LOST ? SUB_LOST : first + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local));
+      n_keyed += 1;
+    }
   }
-  else if (b == 0)
+  if (p.valid && b == 0)
   {
     // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
     // whose loads both saw 0 both store: idempotent.)
@@ -1228,8 +1148,9 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
 __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz, uint32_t &n_keyed)
 {
   FreePending p;
+  FreeBlock none = {0, 0};
   free_request(a, f, p, true, ix, k, vx, vy, vz);
-  free_finish(a, p, n_keyed);
+  free_finish<false>(a, p, n_keyed, none);
 }
 
 constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
@@ -1247,7 +1168,7 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
 __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 {
-  if (scan_fits(a) == false || a.counters->abort != 0) return; // see march_tail_kernel
+  if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
   __shared__ uint32_t s_keyed[4];
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
@@ -1289,13 +1210,15 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
     // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
     // previous emit phase, then pop the next batch and request its bytes
     FreePending pend;
+    // (this wave's own few sub-chunks at the top of the pool)
+    FreeBlock fblock = {a.sub_cap - (blockIdx.x * 4u + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
     pend.valid = false;
     pend.idx = 0;
     pend.tile = pend.local = pend.ix = pend.b = 0;
     pend.k = 0;
     auto emit = [&]() {
 #if WS_FREE_PIPE
-      free_finish(a, pend, n_keyed);
+      free_finish<true>(a, pend, n_keyed, fblock);
 #endif
       const uint32_t cnt = qtail - qhead;
       const uint32_t n = cnt < 64 ? cnt : 64;
@@ -1305,7 +1228,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
       const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
       free_request(a, f, pend, has, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
 #if !WS_FREE_PIPE
-      free_finish(a, pend, n_keyed);
+      free_finish<true>(a, pend, n_keyed, fblock);
       pend.valid = false;
 #endif
       qhead += n;
@@ -1382,7 +1305,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
       if (qtail - qhead >= 64) emit();
     }
     while (qtail != qhead) emit();
-    free_finish(a, pend, n_keyed);
+    free_finish<true>(a, pend, n_keyed, fblock);
   }
   // statistics: free-space candidates that became records
   for (int d = 32; d > 0; d >>= 1) n_keyed += __shfl_down(n_keyed, d, 64);
@@ -1401,13 +1324,14 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
 struct ResolveArgs
 {
   TileEntry *tile_list; // the tiles with records; the resolve appends the others it finds when a separate integrate pass follows
-  uint32_t *tile_fill;
-  uint32_t *tile_chunk;
+  uint32_t *tile_nsub;
+  const uint32_t *tile_ent;
   uint8_t *tile_dirty;
   const unsigned long long *recs;
   unsigned long long *big_keys;
   uint32_t big_mask;
   uint32_t scan_seq;
+  uint32_t sub_cap;
   uint32_t *new_data;
   uint32_t *avg_data;
   uint8_t *vstate;
@@ -1435,42 +1359,43 @@ __device__ __forceinline__ uint64_t neg_key(uint64_t rec, int32_t av, int32_t va
 }
 __device__ __forceinline__ int32_t neg_key_abs(uint64_t N) { return (int32_t)(N >> 39); }
 
-// chunk number j of a tile at resolve time: every id has been published (the marches are over)
-__device__ __forceinline__ uint32_t resolve_chunk(const ResolveArgs &a, uint32_t tile, uint32_t j)
+constexpr uint32_t ENT_NONE = 0xffffffffu;
+// entry number j >= TILE_DIRECT of a tile: through the hash (the marches are over: everything is published)
+__device__ __forceinline__ uint32_t resolve_entry(const ResolveArgs &a, uint32_t tile, uint32_t j)
 {
-  if (j < (uint32_t)TILE_DIRECT) return a.tile_chunk[(size_t)tile * TILE_DIRECT + j];
   const unsigned long long key = big_key(tile, j);
   const uint32_t *vals = reinterpret_cast<const uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
   uint32_t h = big_slot(key, a.big_mask);
   for (uint32_t probe = 0; probe <= a.big_mask; ++probe)
   {
     const unsigned long long cur = a.big_keys[h];
-    if (cur == key) return vals[h];
+    if (cur == key) return vals[h] - 1u; // (0: released -> ENT_NONE)
     if (cur == KEY_INF) break;
     h = (h + 1) & a.big_mask;
   }
-  return CHUNK_LOST;
+  return ENT_NONE;
 }
 
-// every record of a tile, chunk by chunk from memory (wave w the chunks w, w + 4, ...): tiles of more than 2048 records, and
-// the ordered rounds
+// every record of a tile, sub-chunk by sub-chunk from memory (half-wave h of the workgroup takes the entries h, h + 8, ...):
+// tiles of more than TILE_DIRECT entries, and the ordered rounds.  cid: lane l of every wave holds entry l of the tile.
 template <class F>
-__device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t fill, F &&f)
+__device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t nsub, uint32_t cid, F &&f)
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n_chunks = (fill + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
-  for (uint32_t j = (uint32_t)wave; j < n_chunks; j += 4)
+  const int lane = threadIdx.x & 63;
+  const uint32_t half = threadIdx.x >> 5, pos = threadIdx.x & 31u;
+  for (uint32_t jb = 0; jb < nsub; jb += 8)
   {
-    const uint32_t id1 = resolve_chunk(a, tile, j);
-    if (id1 == CHUNK_NONE || id1 == CHUNK_LOST) continue;
-    const uint32_t count = min((uint32_t)CHUNK_RECS, fill - (j << CHUNK_BITS));
-    for (uint32_t i = (uint32_t)lane; i < count; i += 64)
+    const uint32_t j = jb + half;
+    uint32_t ent = (uint32_t)__shfl((int)cid, (int)(j & 63u), 64);
+    if (j >= (uint32_t)TILE_DIRECT) ent = j < nsub ? resolve_entry(a, tile, j) : ENT_NONE;
+    if (j < nsub && ent != ENT_NONE && pos <= (ent & 31u) && (ent >> SUB_BITS) < a.sub_cap)
     {
-      const unsigned long long rec = a.recs[(size_t)(id1 - 1u) * CHUNK_RECS + i];
+      const unsigned long long rec = a.recs[((size_t)(ent >> SUB_BITS) << SUB_BITS) + pos];
       const int32_t value = rec_value(rec);
       f((uint64_t)rec, value, value < 0 ? -value : value, (int)rec_local(rec));
     }
   }
+  (void)lane;
 }
 
 #ifndef WS_RES_MAXR
@@ -1479,16 +1404,16 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
 #ifndef WS_RESOLVE_WGS
 #define WS_RESOLVE_WGS 5 // (107 -> 102 VGPRs without spills, 29 KB of LDS: 4 -> 5 workgroups per CU, 139 -> 130 us)
 #endif
-constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 per tile); larger tiles re-read them per pass
-static_assert(RES_MAXR <= TILE_DIRECT, "the register route reads the chunks of the tile's direct table");
+constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 record places = 64 sub-chunks per tile); larger tiles re-read them per pass
+static_assert(RES_MAXR * 8 <= TILE_DIRECT, "the register route reads the sub-chunks of the tile's direct table");
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
 struct TilePre
 {
   int64_t idx0;
   int nz;
-  uint32_t fill; // records of the tile (uniform)
-  uint32_t cid;  // lane k < TILE_DIRECT of every wave: id + 1 of the tile's chunk k
+  uint32_t fill; // sub-chunks (entries) of the tile (uniform)
+  uint32_t cid;  // lane l of every wave: entry l of the tile
   uint32_t vs;   // four vstate bytes (both planes)
   uint32_t s0[4]; // new_map entries (HAS_S0)
 };
@@ -1552,8 +1477,8 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     int nz = a.map.size[2] - sz;
     p.nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
     p.idx0 = p.nz ? storage_index(a.map, sx, sy, sz) : 0;
-    p.fill = a.tile_fill[te.tile];
-    p.cid = a.tile_chunk[(size_t)te.tile * TILE_DIRECT + (uint32_t)(lane & (TILE_DIRECT - 1))];
+    p.fill = a.tile_nsub[te.tile];
+    p.cid = a.tile_ent[(size_t)te.tile * TILE_DIRECT + (uint32_t)lane];
     // four voxels of a column in one access each (the arrays carry 16 bytes of slack behind the last voxel)
     const uint32_t keep = p.nz >= 4 ? 0xffffffffu : ((1u << (8 * p.nz)) - 1u);
     p.vs = 0;
@@ -1579,23 +1504,25 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       mstate[l0 + j] = M_NONE;
     }
   };
-  // The records of a tile, in registers: a tile's chunks back to back are its record sequence, thread t takes the records
-  // t, t + 256, ... -- record t of chunk k, one coalesced 2 KB read per chunk, all RES_MAXR of them in flight together.
-  // Returns false (uniform over the workgroup) when the tile has more than 256 * RES_MAXR records: the waves then stream
-  // the chunks from memory in every pass.  The loads are UNCONDITIONAL (clamped address) and all issued before the first
-  // result is touched: a load under a branch, or a use right behind it, makes the compiler wait for each of them in turn.
+  // The records of a tile, in registers: thread t takes place t & 31 of the tile's sub-chunks t >> 5, (t >> 5) + 8, ... -- one
+  // coalesced 256-byte read per half-wave and sub-chunk, all RES_MAXR of them in flight together.  Returns false (uniform
+  // over the workgroup) when the tile has more than 8 * RES_MAXR sub-chunks: the waves then stream them from memory in every
+  // pass.  The loads are UNCONDITIONAL (clamped address) and all issued before the first result is touched: a load under a
+  // branch, or a use right behind it, makes the compiler wait for each of them in turn.
   unsigned long long rrec[RES_MAXR]; // REC_NONE: no record
   u32x4 ex_next = {0, 0, 0, 0}; // FUSED: the avg_map entries of the tile whose records are in flight
   auto fetch_records = [&](const TilePre &p) -> bool {
     if (FUSED) ex_next = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
-    const uint32_t fill = p.fill;
-    const bool in_regs = fill != 0 && fill <= (uint32_t)(CHUNK_RECS * RES_MAXR);
+    const uint32_t nsub = aborted ? 0u : p.fill;
+    const bool in_regs = nsub != 0 && nsub <= (uint32_t)(8 * RES_MAXR);
+    const uint32_t pos = threadIdx.x & 31u;
 #pragma unroll
     for (int k = 0; k < RES_MAXR; ++k)
     {
-      const uint32_t id1 = (uint32_t)__builtin_amdgcn_readlane((int)p.cid, k);
-      const bool ok = in_regs && (uint32_t)(k * CHUNK_RECS) + threadIdx.x < fill && id1 != CHUNK_NONE && id1 != CHUNK_LOST;
-      const unsigned long long v = a.recs[ok ? (size_t)(id1 - 1u) * CHUNK_RECS + threadIdx.x : (size_t)threadIdx.x];
+      const uint32_t j = (uint32_t)(8 * k) + (threadIdx.x >> 5);
+      const uint32_t ent = (uint32_t)__shfl((int)p.cid, (int)j, 64);
+      const bool ok = in_regs && j < nsub && pos <= (ent & 31u) && (ent >> SUB_BITS) < a.sub_cap;
+      const unsigned long long v = a.recs[ok ? ((size_t)(ent >> SUB_BITS) << SUB_BITS) + pos : (size_t)threadIdx.x];
       rrec[k] = ok ? v : REC_NONE;
     }
     return in_regs;
@@ -1644,16 +1571,14 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       }
     }
   };
-  // the tile's scratch goes back to zero for the next scan (no clean-up launch): record count, list flag, chunk table
-  // (and the entries of the chunks beyond it)
-  auto release_tile = [&](uint32_t tile, uint32_t fill) {
-    if (threadIdx.x < (uint32_t)TILE_DIRECT) a.tile_chunk[(size_t)tile * TILE_DIRECT + threadIdx.x] = 0;
-    if (threadIdx.x == 8) a.tile_fill[tile] = 0;
-    const uint32_t n_chunks = (fill + (uint32_t)CHUNK_RECS - 1u) >> CHUNK_BITS;
-    if (n_chunks > (uint32_t)TILE_DIRECT)
+  // the tile's scratch goes back to zero for the next scan (no clean-up launch): its entry count (the table itself is only
+  // ever read up to the count) and the values of its entries in the hash
+  auto release_tile = [&](uint32_t tile, uint32_t nsub) {
+    if (threadIdx.x == 8) a.tile_nsub[tile] = 0;
+    if (nsub > (uint32_t)TILE_DIRECT)
     {
       uint32_t *vals = reinterpret_cast<uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
-      for (uint32_t j = (uint32_t)TILE_DIRECT + threadIdx.x; j < n_chunks; j += 256u)
+      for (uint32_t j = (uint32_t)TILE_DIRECT + threadIdx.x; j < nsub; j += 256u)
       {
         const unsigned long long key = big_key(tile, j);
         uint32_t h = big_slot(key, a.big_mask);
@@ -1663,7 +1588,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           if (cur == key)
           {
             // (the slot keeps its key: emptying it would cut the probe chains that run through it; a key of an earlier
-            // scan with value 0 is "not published" to the marches and is overwritten by the tile's next chunk j)
+            // scan with value 0 is "nothing" to the resolve and is overwritten by the tile's next entry j)
             vals[h] = 0;
             break;
           }
@@ -1682,7 +1607,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     c->last_chunks = c->chunk_cursor;
     c->last_need = c->ub_total & ((1ull << 48) - 1ull);
     c->ub_total = 0;
-    c->ub_tail = 0;
     __hip_atomic_store(a.status + 10, c->big_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 9, aborted ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1725,7 +1649,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   {
     n_mine += 1;
     const TilePre p = p_cur;
-    const uint32_t tile = tile_cur, fill = p.fill;
+    const uint32_t tile = tile_cur, nsub_real = p.fill, fill = aborted ? 0u : p.fill; // (an aborted scan: the entries may be anything)
     const int nz = p.nz;
     const int64_t idx0 = p.idx0;
 
@@ -1781,7 +1705,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         }
         else
         {
-          for_each_record(a, tile, fill, [&](uint64_t rec, int32_t value, int32_t av, int l) {
+          for_each_record(a, tile, fill, p.cid, [&](uint64_t rec, int32_t value, int32_t av, int l) {
             if (HAS_S0 && av >= (int32_t)bound0[l]) return;
             f(rec, value, av, l);
           });
@@ -1946,7 +1870,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
     // Nobody reads the tile's tables again: every thread's prefetch of them was consumed before the last barrier of the
     // PREVIOUS iteration, the passes that stream the chunks from memory ended before the last barrier of this one.
-    release_tile(tile, fill);
+    release_tile(tile, nsub_real);
 
     // ---- this tile's result waits in registers until the next iteration's loads have arrived
     post.idx0 = idx0;
@@ -2300,8 +2224,7 @@ static PrepArgs make_prep_args(ws_map *m)
   p.counters = m->counters;
   p.az_hist = m->az_hist;
   p.n_hist = (uint32_t)(AZ_BINS + 1);
-  p.tile_fill = m->tile_fill;
-  p.tile_chunk = m->tile_chunk;
+  p.tile_nsub = m->tile_nsub;
   p.tile_dirty = m->tile_dirty;
   p.n_tiles = m->n_tiles;
   p.big_keys = m->big_keys;
@@ -2331,16 +2254,7 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res)
   }
 }
 
-// Chunk buffers up to this size are sized by the hard bound of chunks_needed() (a scan can never run out); maps whose
-// tile term alone is larger (2049^3: 8.7 M tiles x 2 KB) take the estimate and repeat a scan that does run out.
-constexpr uint64_t CHUNK_BUDGET_BYTES = 6ull << 30;
-static uint32_t est_shift_of(const ws_map *m)
-{
-  const uint64_t budget = m->chunk_budget_bytes ? m->chunk_budget_bytes : CHUNK_BUDGET_BYTES;
-  if ((uint64_t)m->n_tiles * CHUNK_RECS * sizeof(unsigned long long) <= budget) return 0;
-  return m->est_shift ? m->est_shift : 1u;
-}
-uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points) { return chunks_needed(need_records, (uint64_t)m->n_tiles, est_shift_of(m), n_points); }
+uint64_t subs_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points) { return subs_needed(need_records, m->est_shift, n_points); }
 
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
 {
@@ -2390,16 +2304,14 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   sa.fan_steps = m->fan_steps;
   sa.vstate = m->vstate;
   sa.tile_dirty = m->tile_dirty;
-  sa.tile_fill = m->tile_fill;
-  sa.tile_chunk = m->tile_chunk;
+  sa.tile_nsub = m->tile_nsub;
+  sa.tile_ent = m->tile_ent;
   sa.tile_list = m->tile_list;
   sa.rec = m->rec;
-  sa.chunk_cap = m->chunk_cap;
+  sa.sub_cap = m->sub_cap;
   sa.scan_seq = ++m->scan_seq;
   sa.big_keys = m->big_keys;
   sa.big_mask = m->big_slots - 1;
-  sa.est_shift = est_shift_of(m);
-  sa.raw_cap = m->raw_cap;
   sa.pad0 = 0;
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;
@@ -2437,8 +2349,9 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 
   ResolveArgs ra;
   ra.tile_list = m->tile_list;
-  ra.tile_fill = m->tile_fill;
-  ra.tile_chunk = m->tile_chunk;
+  ra.tile_nsub = m->tile_nsub;
+  ra.tile_ent = m->tile_ent;
+  ra.sub_cap = m->sub_cap;
   ra.tile_dirty = m->tile_dirty;
   ra.recs = m->rec;
   ra.big_keys = m->big_keys;
@@ -2470,13 +2383,12 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   else
     hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   prof_end(ctx, WS_K_TILE_RESOLVE);
-  // The set-up pass has counted the records this scan can make; its last workgroup writes the total and this scan's
-  // sequence number into host-mapped memory.  Everything above was enqueued WITHOUT waiting for that word (the march kernels
-  // check the bound themselves and do nothing if the scan does not fit), so the device runs the update back to back; the
-  // host looks at the word now -- it arrived while the later launches were being enqueued -- and, should the scan not have
-  // fitted, grows the buffer and runs the update again.  (Waiting for the word BEFORE the tail march was enqueued left the
-  // device idle for ~10 us per scan once the set-up pass got faster than the host's flag -> launch -> doorbell path.)  A hint
-  // from the previous scan is not enough: a door that opens multiplies the need.
+  // The pool of sub-chunks is sized by estimate (subs_needed): a scan that exhausts it raises the abort flag, the resolve
+  // -- which is enqueued already -- then only puts the scratch back and writes nothing to the maps, and this call repeats the
+  // scan with a larger pool: never an inexact map.  The verdict is there when the resolve starts, ~0.4 ms into the update
+  // (host-mapped memory: the flag, then the sequence number the host spins on); the resolve itself runs while the caller
+  // enqueues what comes next.  (Everything above was enqueued without waiting for anything: the device runs the update back
+  // to back.)
   {
     volatile uint32_t *st = m->status_host;
     auto wait_word = [&](int word, const char *what) -> int {
@@ -2497,47 +2409,26 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
       std::atomic_thread_fence(std::memory_order_acquire);
       return WS_OK;
     };
-    int rc = wait_word(6, "TSDF update: the set-up pass did not report its record bound");
+    int rc = wait_word(8, "TSDF update: the resolve did not report the end of the marches");
     if (rc != WS_OK) return rc;
-    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4);
-    const unsigned long long need_raw = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 12);
-    const uint64_t want = chunks_for_scan(m, need, n);
-    bool again = false;
-    uint64_t grow_to = m->chunk_cap, raw_to = m->raw_cap;
-    if (want > m->chunk_cap || need_raw > m->raw_cap)
-    {
-      // the marches have skipped this scan (scan_fits): larger buffers, and once more
-      again = true;
-      if (want > m->chunk_cap) grow_to = want + want / 8;
-      if (need_raw > m->raw_cap) raw_to = need_raw + need_raw / 8;
-    }
-    else if (sa.est_shift)
-    {
-      // sized by estimate: did the marches get through?  (they are over when the resolve starts: ~0.4 ms into the update)
-      rc = wait_word(8, "TSDF update: the resolve did not report the end of the marches");
-      if (rc != WS_OK) return rc;
-      if (st[9] != 0)
-      {
-        again = true;
-        grow_to = (uint64_t)m->chunk_cap * 2;
-      }
-    }
-    if (!again) break; // the normal case
+    if (st[9] == 0) break; // the normal case
     if (attempt >= 8)
     {
-      set_error("TSDF update: the scan did not fit the chunk buffer it had just been given");
+      set_error("TSDF update: the scan did not fit the record pool it had just been given");
       return WS_ERR_INTERNAL;
     }
-    if (grow_to > 0xfffffff0ull || raw_to > 0xfffffff0ull)
+    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4) & ((1ull << 48) - 1ull);
+    uint64_t grow_to = subs_for_scan(m, need, n);
+    if (grow_to < (uint64_t)m->sub_cap * 2) grow_to = (uint64_t)m->sub_cap * 2;
+    if (grow_to > SUB_ID_LIMIT)
     {
-      set_error("TSDF update: the scan needs more than 2^32 record chunks / tail records");
+      set_error("TSDF update: the scan needs more than 2^27 record sub-chunks");
       return WS_ERR_CAPACITY;
     }
-    rc = resize_records(m, grow_to, raw_to); // (waits for the stream: the skipped / aborted update has drained and put its scratch back)
+    rc = resize_records(m, grow_to); // (waits for the stream: the aborted update has drained and put its scratch back)
     if (rc != WS_OK) return rc;
     sa.rec = m->rec;
-    sa.chunk_cap = m->chunk_cap;
-    sa.raw_cap = m->raw_cap;
+    sa.sub_cap = m->sub_cap;
     sa.big_keys = m->big_keys;
     sa.big_mask = m->big_slots - 1;
     sa.scan_seq = ++m->scan_seq;

@@ -66,18 +66,23 @@ __host__ __device__ inline int32_t rec_value(uint64_t rec) { return (int32_t)(in
 __host__ __device__ inline uint32_t rec_local(uint64_t rec) { return (uint32_t)rec & ((1u << REC_VOX_BITS) - 1u); }
 __host__ __device__ inline bool rec_negative(uint64_t rec) { return (((uint32_t)(rec >> REC_T_SHIFT)) & 31u) != (uint32_t)REC_FAN_MID; }
 
-// Records live in CHUNKS of 256 (2 KB) that belong to one tile each: a workgroup of the tail march stages its records in
-// LDS, reserves a range of the tile's record sequence with one atomic per (flush, tile) and copies them there, so HBM sees
-// every record once and the resolve reads a tile's records as whole chunks.  tile_fill[tile] counts the records;
-// tile_chunk[tile][j] = id + 1 of the chunk holding records 256 j ..; chunks
-// beyond TILE_DIRECT are found through a small hash (tile, j) -> id (tiles of more than 2048 records: only a scan into a
-// non-default new_map, where every candidate is a record, has them).
-constexpr int CHUNK_BITS = 8, CHUNK_RECS = 1 << CHUNK_BITS, TILE_DIRECT = 8;
+// Records live in SUB-CHUNKS of 32 (256 bytes) that belong to one tile each.  A wave of the tail march owns a run of
+// sub-chunk ids (its share of the block its workgroup took from the pool, refilled 32 at a time); the first record a wave
+// makes for a tile opens a sub-chunk of that run, and every later one goes straight to its place there: position = the
+// record's rank among the wave's records of the tile, counted in LDS.  HBM sees a record once, where it stays.  When the wave
+// is through (or its LDS bookkeeping is full) it publishes its sub-chunks: ONE atomic per tile on tile_nsub[tile] reserves
+// places in the tile's entry table, tile_ent[tile][j] = id << 5 | (records - 1).  Entries beyond TILE_DIRECT go through a
+// hash (tile, j) -> entry + 1.  Nobody ever waits for anybody: the resolve -- a later kernel -- reads what is there.
+constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 64;
+constexpr uint32_t SUB_WAVE_FIRST = 128;            // sub-chunks a wave of the tail march starts with
+constexpr uint32_t SUB_WG_BLOCK = 4 * SUB_WAVE_FIRST; // ... taken from the pool by its workgroup in one request
+constexpr uint32_t SUB_REFILL = 32;                 // and what a wave asks for when it runs low
+constexpr uint32_t SUB_ID_LIMIT = (1u << 27) - 2u;  // an entry is id << 5 | fill - 1, + 1 in the hash
 // per-tile bytes, two planes in one allocation (tile_flag_plane_bytes apart): [0] "the free pass / an off-ray mark touched the
 // tile" (plain idempotent byte stores), [1] "the tile is on the scan's list" (it has records).  The resolve visits the listed
 // tiles through the list and finds the others by scanning these planes.
 __host__ __device__ inline size_t tile_flag_plane_bytes(int64_t n_tiles) { return ((size_t)n_tiles + 16 + 255) & ~(size_t)255; }
-constexpr uint32_t CHUNK_NONE = 0u, CHUNK_LOST = 0xffffffffu; // not published yet / the chunk buffer was exhausted (scan aborted)
+constexpr uint32_t SUB_LOST = 0xffffffffu; // the pool was exhausted (scan aborted): nothing is written, nothing published
 
 struct TileEntry // 16 bytes: one touched tile of the scan in flight
 {
@@ -87,14 +92,14 @@ struct TileEntry // 16 bytes: one touched tile of the scan in flight
 
 struct TsdfCounters // device-resident
 {
-  uint32_t chunk_cursor;  // chunks handed out (reset by the set-up pass of the next scan)
+  uint32_t chunk_cursor;  // sub-chunks handed out from the bottom of the pool by the tail march (reset by the set-up pass of the next scan)
   uint32_t n_listed;      // tiles with records (length of the tile list; the resolve appends the other touched tiles when a separate integrate pass follows; survives until the next scatter)
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
   uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
   uint32_t big_inserted;  // keys ever put into the (tile, chunk) hash since it was last emptied (the host empties it when it fills up)
-  uint32_t raw_cursor;    // records of the raw buffer handed to the workgroups of the tail march (upper bounds; reset by the set-up pass)
-  unsigned long long ub_tail; // sum of the per-ray upper bounds of the TAIL records alone (what the raw buffer must hold)
+  uint32_t free_cursor;   // sub-chunks handed out from the TOP of the pool by the free pass (one record each: a free-space candidate on a keyed voxel)
+  unsigned long long pad0;
   // statistics of the last update (ws_tsdf_stats)
   uint32_t last_records;
   uint32_t last_contested;
@@ -168,28 +173,27 @@ struct ws_map
   // tile grid (4 x 4 x 64 voxels of storage space)
   int32_t ntx = 0, nty = 0, ntz = 0;
   int64_t n_tiles = 0;
-  uint32_t *tile_fill = nullptr;    // [n_tiles] records of the tile in the scan in flight (zero between scans)
-  uint32_t *tile_chunk = nullptr;   // [n_tiles][TILE_DIRECT] chunk id + 1 (zero between scans)
+  uint32_t *tile_nsub = nullptr;    // [n_tiles] sub-chunks (= entries) of the tile in the scan in flight (zero between scans)
+  uint32_t *tile_ent = nullptr;     // [n_tiles][TILE_DIRECT] entries: sub-chunk id << 5 | records - 1 (never cleared: tile_nsub says how many are valid)
   uint8_t *tile_dirty = nullptr;    // two planes of [n_tiles] bytes (tile_flag_plane_bytes): touched by the free-space pass / an off-ray mark; on the list
   ws::TileEntry *tile_list = nullptr; // [n_tiles] touched tiles of the scan in flight
-  // candidate records of the ray tails: chunks of 256 x 8 bytes
-  unsigned long long *rec = nullptr;      // chunk_cap chunks, then the raw buffer: raw_cap records of 16 bytes on their way from the march to the chunks
-  uint32_t chunk_cap = 0;
-  uint32_t raw_cap = 0;
-  unsigned long long *big_keys = nullptr; // (tile, chunk number) -> chunk id for chunks beyond TILE_DIRECT: keys, then uint32 values
+  // candidate records of the ray tails: the pool of sub-chunks (32 x 8 bytes)
+  unsigned long long *rec = nullptr;
+  uint32_t sub_cap = 0;
+  unsigned long long *big_keys = nullptr; // (tile, entry number) -> entry + 1 for entries beyond TILE_DIRECT: keys, then uint32 values
   uint32_t big_slots = 0;
   uint32_t *block_stats = nullptr; // per-workgroup statistics (no shared counters in the hot kernels)
   uint32_t tail_blocks = 0;        // workgroups of the last tail march
   uint32_t resolve_blocks = 0;     // workgroups of the last tile resolve
   bool fused_done = false;         // the last scatter already integrated into avg_map
   uint32_t scan_seq = 0;           // scatters launched on this map (ray_setup reports its record bound under this number)
-  uint64_t chunk_budget_bytes = 0; // chunk buffers above this size are sized by estimate + abort / re-run instead of by the hard bound (0: default)
-  uint32_t est_shift = 0;          // the estimate is the record bound / 256 >> (est_shift - 1) (0: default 1; tests shrink it to force the abort route)
+  uint64_t chunk_budget_bytes = 0; // (test entry, unused since round 4's sub-chunks: the pool is always sized by estimate)
+  uint32_t est_shift = 0;          // the pool's share for the records is the record bound / 32 >> (est_shift - 1) (0: the whole bound; tests shrink it to force the abort route)
   ws::TsdfCounters *counters = nullptr;
   ws::TsdfCounters *counters_host = nullptr; // pinned
   uint32_t *status_host = nullptr;           // pinned + mapped: [0] sticky error bits, [4..5] record bound of the scan in flight (u64), [6] its sequence number,
-                                             // [8] sequence number of the last scan whose marches have finished, [9] != 0: that scan was aborted (chunks exhausted),
-                                             // [10] keys in the (tile, chunk) hash, [12..13] bound of the tail records of the scan in flight (u64)
+                                             // [8] sequence number of the last scan whose marches have finished, [9] != 0: that scan was aborted (pool exhausted),
+                                             // [10] keys in the (tile, entry) hash
   uint32_t *status_dev = nullptr;            // device view of status_host
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
@@ -287,8 +291,8 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
-int resize_records(ws_map *m, uint64_t chunks, uint64_t raw_records); // api.hip: (re)allocate the chunk + raw buffer (waits for the stream)
-uint64_t chunks_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points); // chunks the map's buffer must hold for a scan of that record bound (hard bound, or the estimate for huge maps)
+int resize_records(ws_map *m, uint64_t sub_chunks); // api.hip: (re)allocate the pool (waits for the stream)
+uint64_t subs_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points); // sub-chunks the pool should hold for a scan of that record bound
 int launch_tsdf_integrate(ws_map *m);
 int launch_tsdf_stats(ws_map *m); // fills the last_* statistics of TsdfCounters from the per-workgroup slots
 int launch_box_copy(ws_map *m, const ws::MapParams &par, int which, const int32_t lo[3], const int32_t ext[3], uint32_t *box_dev, bool pack, hipStream_t stream);
