@@ -81,6 +81,9 @@ constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
+#ifndef WS_FREE_FIRST
+#define WS_FREE_FIRST 32 // sub-chunks every wave of the free pass owns from the start (see pool_grab; 16: 136 us, 32: 121, 64: 120)
+#endif
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
 #endif
@@ -91,7 +94,7 @@ constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTE
 #define WS_EL_BINS 8
 #endif
 #ifndef WS_SORT_CELLS
-#define WS_SORT_CELLS 1
+#define WS_SORT_CELLS 2
 #endif
 constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
 static_assert(AZ_ONLY_BINS * EL_BINS == 64 * 64 * 2, "the cell sort uses the same 8192 bins");
@@ -166,7 +169,7 @@ __host__ inline unsigned long long subs_needed(unsigned long long need, uint32_t
 {
   const unsigned long long items = (n_points + 63) / 64 * 2 + 1; // (TAIL_SPLIT == 2 workgroups per 64 rays)
   const unsigned long long free_waves = (n_points + 63) / 64 * 4; // (64 rays per workgroup of the free pass)
-  return items * SUB_WG_BLOCK + free_waves * 16 + ((need >> SUB_BITS) >> (est_shift ? est_shift - 1 : 0)) + 8192ull;
+  return items * SUB_WG_BLOCK + free_waves * WS_FREE_FIRST + ((need >> SUB_BITS) >> (est_shift ? est_shift - 1 : 0)) + 8192ull;
 }
 
 // Upper bound of the scatter targets of the ray steps [k0, k1): sum of iter_steps = 2*delta_z/res + 1 (update_tsdf.cu:101-102)
@@ -191,6 +194,10 @@ __device__ __forceinline__ unsigned long long tail_bound(int64_t k0, int64_t k1,
 __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
 {
   __shared__ unsigned long long ub_wave[4];
+  __shared__ uint32_t s_bkey[512], s_bcnt[512]; // bins of this workgroup's rays: key, count (then: first rank)
+  s_bkey[threadIdx.x] = s_bkey[threadIdx.x + 256] = 0xffffffffu;
+  s_bcnt[threadIdx.x] = s_bcnt[threadIdx.x + 256] = 0;
+  uint32_t my_bin = 0;
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix == 0)
   {
@@ -341,7 +348,16 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
       int bx = (hvx - a.map.pos[0] + a.map.size[0] / 2) / cwx, by = (hvy - a.map.pos[1] + a.map.size[1] / 2) / cwy;
       bx = bx < 0 ? 0 : (bx > 63 ? 63 : bx);
       by = by < 0 ? 0 : (by > 63 ? 63 : by);
+#if WS_SORT_CELLS == 2
+      // Morton order of the cells, above / below the sensor as the major key: where rays are sparse a wave's 64 rays span
+      // several bins, and consecutive bins should still be neighbours in space
+      uint32_t mx = (uint32_t)bx, my = (uint32_t)by;
+      mx = (mx | (mx << 4)) & 0x0f0fu; mx = (mx | (mx << 2)) & 0x3333u; mx = (mx | (mx << 1)) & 0x5555u;
+      my = (my | (my << 4)) & 0x0f0fu; my = (my | (my << 2)) & 0x3333u; my = (my | (my << 1)) & 0x5555u;
+      bin = (hvz >= a.scanner_pos[2] ? 4096u : 0u) + ((mx << 1) | my);
+#else
       bin = (uint32_t)((bx * 64 + by) * 2 + (hvz >= a.scanner_pos[2] ? 1 : 0));
+#endif
 #else
       const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
       int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
@@ -354,18 +370,51 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
 #endif
     }
     r.pad |= (int32_t)(bin << 1); // bits 1 .. 14 (RAY_SIMPLE is bit 30)
-    // the histogram's old value is this ray's rank inside its bin: the sort blocks place it without a second atomic.
-    // Both travel at agent scope (performed at the coherent level): the sort blocks run on other XCDs in the same launch.
-    const uint32_t rank = __hip_atomic_fetch_add(&a.az_hist[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.ray_bin[ix]), (unsigned long long)bin | ((unsigned long long)rank << 32), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    my_bin = bin;
     a.rays[ix] = r;
+  }
+  // The ray's rank inside its bin comes from the bin's counter (the sort blocks place it without a second atomic) -- through
+  // the workgroup: its rays count themselves per bin in LDS first, and ONE add per (workgroup, bin) reserves their ranks.  A
+  // cell near the sensor holds thousands of rays, and a returning atomic per ray on such a counter took the set-up pass from
+  // 30 to 69 us; the 256 rays of a workgroup are neighbours in the scan and share a few dozen bins.  (It also keeps such
+  // neighbours together in the sorted order.)  Everything travels at agent scope (performed at the coherent level): the
+  // sort blocks run on other XCDs in the next launch.
+  __syncthreads(); // (the table was emptied on entry)
+  int my_slot = -1;
+  uint32_t my_lrank = 0;
+  if (ix < a.n)
+  {
+    uint32_t h = (my_bin * 0x9E3779B1u) >> (32 - 9);
+    for (;;)
+    {
+      const uint32_t cur = s_bkey[h];
+      if (cur == my_bin) break;
+      if (cur == 0xffffffffu)
+      {
+        const uint32_t old = atomicCAS(&s_bkey[h], 0xffffffffu, my_bin);
+        if (old == 0xffffffffu || old == my_bin) break;
+      }
+      h = (h + 1) & 511u;
+    }
+    my_slot = (int)h;
+    my_lrank = atomicAdd(&s_bcnt[h], 1u);
   }
   // The records this scan can make (sum of the per-ray bounds): every scan sizes the record buffers itself.
   unsigned long long ub = r.ub;
   for (int d = 32; d > 0; d >>= 1) ub += __shfl_down(ub, d, 64);
   if ((threadIdx.x & 63) == 0) ub_wave[threadIdx.x >> 6] = ub;
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+  {
+    const int sl = (int)threadIdx.x + 256 * q;
+    const uint32_t c = s_bcnt[sl];
+    if (c) s_bcnt[sl] = __hip_atomic_fetch_add(&a.az_hist[s_bkey[sl]], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (my_slot >= 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&a.ray_bin[ix]), (unsigned long long)my_bin | ((unsigned long long)(s_bcnt[my_slot] + my_lrank) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // one fire-and-forget add per workgroup; the direction sort -- the next launch -- hands the total to the host
   if (threadIdx.x == 0) atomicAdd(&a.counters->ub_total, ub_wave[0] + ub_wave[1] + ub_wave[2] + ub_wave[3]);
 }
@@ -445,7 +494,7 @@ __device__ __forceinline__ void raise_abort(const ScatterArgs &a)
 // ids per wave of the free pass].  The fixed parts cost no request at all: a returning atomic on ONE address takes ~40 ns
 // under load (measured: 25 000 of them, one per free-space record, made the free pass 1.16 ms instead of 0.12), so the
 // shared counters are for the exceptions.
-constexpr uint32_t FREE_WAVE_FIRST = 16; // (subs_needed() counts them)
+constexpr uint32_t FREE_WAVE_FIRST = WS_FREE_FIRST; // (subs_needed() counts them)
 #ifndef WS_TAIL_SPLIT
 #define WS_TAIL_SPLIT 2
 #endif
@@ -533,7 +582,7 @@ __device__ __forceinline__ void append_single(const ScatterArgs &a, uint32_t til
 #define WS_TAIL_SPLIT 2
 #endif
 #ifndef WS_TAIL_WGS
-#define WS_TAIL_WGS 6 // workgroups per CU the register budget is set for (80 VGPRs)
+#define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (six: 80 VGPRs, 16 of them spilled, 234 instead of 187 us)
 #endif
 #ifndef WS_TAIL_BLIND
 #define WS_TAIL_BLIND 1 // off-ray candidates of value +tau as marks in the second byte plane instead of records (2.1 M of the benchmark scan's 14.4 M)
@@ -1094,7 +1143,11 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
   }
   const unsigned long long km = 0;
 #else
+#ifdef WS_FREE_NOKEY
+  const unsigned long long km = 0;
+#else
   const unsigned long long km = __ballot(keyed);
+#endif
 #endif
   if (km)
   {
@@ -1129,6 +1182,7 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
     if (keyed)
     {
       const uint32_t id = first == SUB_LOST ? SUB_LOST : first + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+      // (the answer of the atomic in there picked up one emit phase later, under the next batch's voxel bytes: no gain, measured)
       append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local));
       n_keyed += 1;
     }
@@ -1376,26 +1430,48 @@ __device__ __forceinline__ uint32_t resolve_entry(const ResolveArgs &a, uint32_t
   return ENT_NONE;
 }
 
-// every record of a tile, sub-chunk by sub-chunk from memory (half-wave h of the workgroup takes the entries h, h + 8, ...):
-// tiles of more than TILE_DIRECT entries, and the ordered rounds.  cid: lane l of every wave holds entry l of the tile.
+// every record of a tile, from memory: tiles of more than 8 * RES_MAXR sub-chunks, and the ordered rounds.  64 entries at a
+// time -- lane l of every wave holds entry l of the batch: the first from the prefetched `cid`, the second from the tile's
+// table, further ones through the hash, every lane looking up its own -- and of those WS_STREAM_U sub-chunks per half-wave in
+// flight together (one after the other, each load waited for on the spot, this route took as long again as the whole fold).
+#ifndef WS_STREAM_U
+#define WS_STREAM_U 2 // (four: ten spilled registers in the fused resolve, 141 instead of 132 us)
+#endif
 template <class F>
 __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t nsub, uint32_t cid, F &&f)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t half = threadIdx.x >> 5, pos = threadIdx.x & 31u;
-  for (uint32_t jb = 0; jb < nsub; jb += 8)
+  constexpr int U = WS_STREAM_U;
+  for (uint32_t b0 = 0; b0 < nsub; b0 += 64)
   {
-    const uint32_t j = jb + half;
-    uint32_t ent = (uint32_t)__shfl((int)cid, (int)(j & 63u), 64);
-    if (j >= (uint32_t)TILE_DIRECT) ent = j < nsub ? resolve_entry(a, tile, j) : ENT_NONE;
-    if (j < nsub && ent != ENT_NONE && pos <= (ent & 31u) && (ent >> SUB_BITS) < a.sub_cap)
+    uint32_t ents = cid;
+    if (b0 == 64)
+      ents = a.tile_ent[(size_t)tile * TILE_DIRECT + 64u + (uint32_t)lane];
+    else if (b0 > 64)
+      ents = b0 + (uint32_t)lane < nsub ? resolve_entry(a, tile, b0 + (uint32_t)lane) : ENT_NONE;
+    const uint32_t nb = min(64u, nsub - b0);
+    for (uint32_t j0 = 0; j0 < nb; j0 += 8u * U)
     {
-      const unsigned long long rec = a.recs[((size_t)(ent >> SUB_BITS) << SUB_BITS) + pos];
-      const int32_t value = rec_value(rec);
-      f((uint64_t)rec, value, value < 0 ? -value : value, (int)rec_local(rec));
+      unsigned long long rec[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        const uint32_t j = j0 + 8u * (uint32_t)u + half;
+        const uint32_t ent = (uint32_t)__shfl((int)ents, (int)(j & 63u), 64);
+        ok[u] = j < nb && ent != ENT_NONE && pos <= (ent & 31u) && (ent >> SUB_BITS) < a.sub_cap;
+        rec[u] = a.recs[ok[u] ? ((size_t)(ent >> SUB_BITS) << SUB_BITS) + pos : (size_t)threadIdx.x];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u])
+        {
+          const int32_t value = rec_value(rec[u]);
+          f((uint64_t)rec[u], value, value < 0 ? -value : value, (int)rec_local(rec[u]));
+        }
     }
   }
-  (void)lane;
 }
 
 #ifndef WS_RES_MAXR
@@ -1405,7 +1481,7 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
 #define WS_RESOLVE_WGS 5 // (107 -> 102 VGPRs without spills, 29 KB of LDS: 4 -> 5 workgroups per CU, 139 -> 130 us)
 #endif
 constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 record places = 64 sub-chunks per tile); larger tiles re-read them per pass
-static_assert(RES_MAXR * 8 <= TILE_DIRECT, "the register route reads the sub-chunks of the tile's direct table");
+static_assert(RES_MAXR * 8 <= 64 && TILE_DIRECT == 128, "the register route reads the first 64 entries of the tile's direct table, the streaming route the other 64");
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
 struct TilePre

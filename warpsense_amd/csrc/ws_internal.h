@@ -73,7 +73,7 @@ __host__ __device__ inline bool rec_negative(uint64_t rec) { return (((uint32_t)
 // is through (or its LDS bookkeeping is full) it publishes its sub-chunks: ONE atomic per tile on tile_nsub[tile] reserves
 // places in the tile's entry table, tile_ent[tile][j] = id << 5 | (records - 1).  Entries beyond TILE_DIRECT go through a
 // hash (tile, j) -> entry + 1.  Nobody ever waits for anybody: the resolve -- a later kernel -- reads what is there.
-constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 64;
+constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 128;
 constexpr uint32_t SUB_WAVE_FIRST = 128;            // sub-chunks a wave of the tail march starts with
 constexpr uint32_t SUB_WG_BLOCK = 4 * SUB_WAVE_FIRST; // ... taken from the pool by its workgroup in one request
 constexpr uint32_t SUB_REFILL = 32;                 // and what a wave asks for when it runs low
