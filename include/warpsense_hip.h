@@ -47,8 +47,8 @@ typedef enum
   WS_ERR_INVALID = -1,     /* bad argument                                             */
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
-  WS_ERR_CAPACITY = -4,    /* returned at once by ws_tsdf_update* for a scan that needs more than 2^32 record chunks (the record
-                              buffer itself cannot overflow: every scan sizes it, or is repeated with a larger one) */
+  WS_ERR_CAPACITY = -4,    /* returned at once by ws_tsdf_update* for a scan that needs more than 2^27 record sub-chunks (the record
+                              pool itself cannot overflow: a scan that exhausts it is repeated with a larger one) */
   WS_ERR_RANGE = -5,       /* ray of more than 8192 steps or 31 fan steps: outside the record's fields; the
                               ray was dropped (sticky)                                                                */
   WS_ERR_TIMEOUT = -6,     /* ws_register_cloud_peers: a peer rank did not deliver (ws_register_cloud itself retries with one
@@ -57,13 +57,12 @@ typedef enum
 } ws_status;
 
 /* Sticky device-side errors.  ws_tsdf_update* return after ENQUEUEING the kernels (like the reference,
- * update_tsdf.cu:165; before returning they read the record bound the set-up pass has reported meanwhile -- the reference
- * blocks on its cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_RANGE / INTERNAL: the
+ * update_tsdf.cu:165; before returning they wait for the marches' verdict on the record pool -- the reference blocks on its
+ * cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_RANGE / INTERNAL: the
  * map is then not bit-exact) cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the
  * first call on the same map that synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.
- * compat.hpp turns it into the reference's print-and-exit (common.cuh:10-21).  Capacity is not among them: a scan either
- * fits the record buffer by construction (its set-up pass bounds it, the buffer grows first) or -- maps so large that the
- * buffer is sized by estimate -- is aborted without touching the maps and repeated with a larger buffer inside the call. */
+ * compat.hpp turns it into the reference's print-and-exit (common.cuh:10-21).  Capacity is not among them: a scan that does
+ * not fit the record pool is aborted without touching the maps and repeated with a larger pool inside the call. */
 
 #define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
 #define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
@@ -154,16 +153,15 @@ int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int
 /* only the integrate pass (cu_avg_tsdf_krnl, update_tsdf.cu:13-43) */
 int ws_tsdf_integrate(ws_map *map);
 int ws_tsdf_set_integrate(ws_map *map, int mode);
-/* Candidate-record capacity of the scatter: records of 8 bytes in chunks of 256 that belong to one 4x4x64-voxel tile each.
- * EVERY scan sizes the buffer itself: its set-up pass bounds the records it can make, the march kernels compare the chunks
- * that bound can need (bound / 256 + one partly filled chunk per tile) with the capacity and do nothing at all if the scan
- * does not fit, ws_tsdf_update* reads the bound before it returns and in that case grows the buffer and runs the update
- * again.  Maps whose tile term alone would cost gigabytes (2049^3) size the buffer by an estimate instead; a scan that runs
- * out of chunks there is aborted -- the maps stay untouched -- and repeated with twice the buffer, inside the same call.
- * Reserving up front only avoids such a re-run. */
+/* Candidate-record capacity of the scatter: records of 8 bytes in sub-chunks of 32 that belong to one 4x4x64-voxel tile each,
+ * taken from a pool.  The pool is sized from the scan's own record bound (its set-up pass counts every ray step as a candidate,
+ * ~2.7 x what a scan makes) plus a fixed share per work item -- an estimate: how many partly filled sub-chunks a scan leaves
+ * has no useful bound.  A scan that does exhaust the pool is ABORTED -- the maps stay untouched -- and repeated with a larger
+ * pool inside the same ws_tsdf_update* call, which therefore returns once the marches are over (~0.35 ms into the update, the
+ * resolve still running).  Reserving up front only avoids such a re-run. */
 int ws_tsdf_set_capacity(ws_map *map, uint64_t records);
-/* Test entry: chunk buffers above `budget_bytes` are sized by the estimate (record bound / 256 >> (est_shift - 1)) instead of
- * by the hard bound (0, 0: the defaults) -- a tiny budget and a large shift force the abort-and-repeat route on a small map. */
+/* Test entry: the pool's share for the records is (record bound / 32) >> (est_shift - 1) (0: the default, the whole bound) -- a
+ * large shift forces the abort-and-repeat route on a small map.  budget_bytes is unused (rounds 1-4 had a second policy). */
 int ws_debug_tsdf_chunk_policy(ws_map *map, uint64_t budget_bytes, uint32_t est_shift);
 
 typedef struct
@@ -174,10 +172,10 @@ typedef struct
   int64_t tiles;            /* touched 4x4x64-voxel tiles (resolved and integrated)                             */
   int32_t error_flags;      /* device error bits since the last call: 2 record-field range, 4 free-space bound, 8 internal */
   int32_t pad;
-  int64_t runs;             /* (workgroup flush, tile) groups of records: one reservation in the tile's sequence each */
+  int64_t runs;             /* (wave, tile) groups of records: one reservation in the tile's entry table each           */
   int64_t free_space_hits;  /* free-space candidates that met ordered candidates (and joined that tile's records)   */
   int64_t record_slots;     /* the scan's record bound (from its set-up pass) ...                                 */
-  int64_t record_capacity;  /* ... and the records the chunk buffer holds                                         */
+  int64_t record_capacity;  /* ... and the record places of the pool (sub-chunks x 32)                             */
 } ws_tsdf_stats_t;
 int ws_tsdf_stats(ws_map *map, ws_tsdf_stats_t *out); /* synchronises */
 

@@ -308,10 +308,10 @@ def test_room_larger_than_the_window_with_ring_seam():
 
 
 def test_record_buffers_are_sized_by_the_scan_itself():
-    """The record buffer never rests on a guess: every scan reports the records it can make from its set-up pass
-    and the host grows the chunk buffer before the marches do anything.  A reservation far too small for the scan, and a
-    small scan followed by one that needs ~60x more (a door opens: every step beyond ~3.3 m at 20 mm carries a fan), are both
-    exact, with no error to report afterwards."""
+    """The record pool follows the scan: a scan that does not fit the pool it finds is aborted -- nothing of it
+    reaches the maps -- and repeated inside the same call with a pool sized from the scan's own record bound.  A reservation
+    far too small for the scan, and a small scan followed by one that needs ~60x more (a door opens: every step beyond ~3.3 m
+    at 20 mm carries a fan), are both exact, with no error to report afterwards."""
     torch = _torch()
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
     lm, t, oa, on = make_pair(size, tau, res, mw)
@@ -332,10 +332,10 @@ def test_record_buffers_are_sized_by_the_scan_itself():
 
 
 def test_a_scan_that_runs_out_of_chunks_is_aborted_and_repeated():
-    """Maps so large that the chunk buffer is sized by estimate (2049^3: the hard bound's tile term alone is 18 GB) can run
-    out of chunks in the middle of the marches.  Such a scan leaves NO trace -- the resolve only puts the scratch back -- and
-    ws_tsdf_update repeats it with twice the buffer inside the same call (no inexact scans, ever).  Forced
-    here on a small map: a budget of one byte selects the estimate, a shift of 9 makes it ~1/256 of the bound."""
+    """The record pool is sized by an estimate, so a scan can run out of sub-chunks in the middle of the marches.  Such a scan
+    leaves NO trace -- the resolve only puts the scratch back -- and ws_tsdf_update repeats it with a larger pool inside the
+    same call (no inexact scans, ever).  Forced here on a small map: a shift of 9 makes the pool's share for the
+    records ~1/256 of the bound, and the reservation is far below the fixed share of the work items."""
     torch = _torch()
     tau, res, mw, size = 600, 20, 640, (400, 400, 100)
     lm, t, oa, on = make_pair(size, tau, res, mw)

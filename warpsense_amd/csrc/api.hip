@@ -242,7 +242,7 @@ static int map_take_error(ws_map *m)
   m->last_error_bits |= bits;
   if (bits & 8u)
   {
-    set_error("TSDF update: internal consistency check failed on the device (chunk table); the map is not exact");
+    set_error("TSDF update: internal consistency check failed on the device (record tables); the map is not exact");
     return WS_ERR_INTERNAL;
   }
   if (bits & 4u)

@@ -7,14 +7,16 @@
 // implementation computes the result of ONE fixed legal schedule — the serial one, ascending
 // (point, ray step, fan step) — deterministically, without a single global atomic per candidate:
 //
-//   ray_setup / ray_sort     per-ray constants (update_tsdf.cu:52-63), rays grouped by direction.
+//   ray_setup / ray_sort     per-ray constants (update_tsdf.cu:52-63), rays sorted by the cell of the map their END lies in
+//                            (the tail of a ray lies within tau of its end: 64 neighbours in that order put their records
+//                            into the same few tiles).
 //   march_tail_kernel        walks the ray TAILS once (near-surface and fan candidates: everything whose result
-//                            depends on the order).  Every scatter target becomes an 8-byte record; a wave appends its
-//                            records to its own slice of a raw buffer in HBM and counts them per tile in a table in
-//                            LDS.  At the end the workgroup reserves, with ONE atomic per tile it touched, a range of
-//                            that tile's record sequence and copies its records there: records live in 2 KB chunks
-//                            that belong to one tile each.  (Staging the records in LDS instead of the raw buffer was
-//                            built and measured: exact, and slower — it costs occupancy)  Off-ray
+//                            depends on the order).  Every scatter target becomes an 8-byte record and goes STRAIGHT to
+//                            its place: records live in 256-byte sub-chunks that belong to one 4x4x64-voxel tile each, a
+//                            wave opens sub-chunks out of its own run of ids and counts its records per tile in LDS (the
+//                            count is the place), and publishes its sub-chunks when it is through -- one atomic per
+//                            (wave, tile).  No wave waits for another, HBM sees a record once.  (Round 4 built two other
+//                            shapes first -- through a raw buffer and a copy, and staged in LDS: DESIGN.md §5.)  Off-ray
 //                            candidates of value +tau are (tau, -64) whoever makes them and never take part in the
 //                            order: a byte in the second voxel plane instead of a record.
 //   march_free_kernel        walks the steps before the tails: all free space (tau, +64) whoever comes first ->
@@ -28,8 +30,8 @@
 //   integrate_*_kernel       weighted average of new_map into avg_map and reset of new_map, over the touched
 //                            tiles only (sparse) or over every voxel (dense, the reference's kernel).
 //
-// The list of touched tiles is built on the way (the first reservation / the first free-space mark of a tile appends
-// it): no scan over the tile grid, no descriptors.  new_map after the resolve is bit-identical to what the reference
+// The list of tiles with records is built on the way (the first entries of a tile append it): no scan over the tile grid, no
+// descriptors.  new_map after the resolve is bit-identical to what the reference
 // kernel leaves there when its threads run one after the other (oracle/ws_oracle.c: wso_update_min).
 #include <atomic>
 #include <chrono>
@@ -79,7 +81,7 @@ static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of k
 
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
-constexpr uint32_t ERR_CAPACITY = 1, ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
+constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
 #ifndef WS_FREE_FIRST
 #define WS_FREE_FIRST 32 // sub-chunks every wave of the free pass owns from the start (see pool_grab; 16: 136 us, 32: 121, 64: 120)
@@ -637,25 +639,6 @@ __device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile)
   return -1; // (never: wave_room keeps 32 slots free)
 }
 
-// inclusive prefix sum over the 64 lanes: four DPP shifts inside the rows of 16 (guarded: a lane whose source lies outside
-// its row keeps its value), then the totals of the rows in front through the scalar unit
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-  const uint32_t rl = threadIdx.x & 15u, lane = threadIdx.x & 63u;
-  uint32_t t;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
-  v += rl >= 1 ? t : 0u;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
-  v += rl >= 2 ? t : 0u;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
-  v += rl >= 4 ? t : 0u;
-  t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
-  v += rl >= 8 ? t : 0u;
-  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
-                 r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
-  return v + (lane >= 16 ? r0 : 0u) + (lane >= 32 ? r1 : 0u) + (lane >= 48 ? r2 : 0u);
-}
-
 // The wave publishes the sub-chunks it has filled since the last time and empties its table.  Any set of lanes may call it
 // (the general walk does, with whoever is there).  ONE memory round trip: a tile's entries are reserved with one atomic per
 // (wave, tile) -- four tiles per lane travel together -- and written behind it; a tile that had no entries yet goes on the
@@ -1127,27 +1110,15 @@ struct FreeBlock
 {
   uint32_t next, left;
 };
-#ifndef WS_FREE_SIMPLE
-#define WS_FREE_SIMPLE 0
-#endif
 template <bool CACHED>
 __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed, FreeBlock &fb)
 {
   const uint32_t b = p.b;
   const bool keyed = p.valid && (b & VOX_KEYED);
-#if WS_FREE_SIMPLE
-  if (keyed)
-  {
-    append_single(a, p.tile, free_grab(a, 1u), make_rec(p.ix, p.k, 0, a.tau, p.local));
-    n_keyed += 1;
-  }
-  const unsigned long long km = 0;
-#else
 #ifdef WS_FREE_NOKEY
-  const unsigned long long km = 0;
+  const unsigned long long km = 0; // (knock-out build for timing: the free pass without its records, 106 instead of 120 us)
 #else
   const unsigned long long km = __ballot(keyed);
-#endif
 #endif
   if (km)
   {
@@ -1520,10 +1491,10 @@ struct TilePost
 // Memory pipeline.  gfx950 retires vector memory operations in order behind ONE counter (loads and stores), and the
 // counts here are data dependent, so every wait is a wait for everything outstanding.  The loop therefore has a single
 // such point per tile — the arrival of the tile's records — and everything else is arranged around it: entry, voxel
-// bytes and chunk table of later tiles and the records of the next tile are all requested together at the END of an
+// bytes and entry table of later tiles and the records of the next tile are all requested together at the END of an
 // iteration, and the stores of a tile are issued right AFTER the next wait, so they drain under the LDS phases.
 //
-// A scan that ran out of chunks (counters->abort) leaves no trace: the tiles' scratch is put back as always, nothing is
+// A scan that ran out of sub-chunks (counters->abort) leaves no trace: the tiles' scratch is put back as always, nothing is
 // written to the maps, and the host runs the scan again with a larger buffer.
 template <bool HAS_S0, bool FUSED>
 __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(ResolveArgs a)
@@ -1694,7 +1665,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   if (e0 < n_list)
   {
   const uint32_t last = n_list - 1;
-  // pipeline: tile i is processed while the voxel bytes / chunk table of tiles i+1 and i+2, the list entries up to i+3
+  // pipeline: tile i is processed while the voxel bytes / entry table of tiles i+1 and i+2, the list entries up to i+3
   // and (from the middle of the iteration on) the records of tile i+1 are in flight
   TileEntry te_n2 = a.tile_list[min(e0 + 2 * G, last)], te_n3 = te_n2;
   uint32_t tile_cur, tile_n1;
@@ -1945,7 +1916,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     }
 
     // Nobody reads the tile's tables again: every thread's prefetch of them was consumed before the last barrier of the
-    // PREVIOUS iteration, the passes that stream the chunks from memory ended before the last barrier of this one.
+    // PREVIOUS iteration, the passes that stream the sub-chunks from memory ended before the last barrier of this one.
     release_tile(tile, nsub_real);
 
     // ---- this tile's result waits in registers until the next iteration's loads have arrived
@@ -2347,7 +2318,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   }
 
   const bool s0 = !m->new_is_default;
-  // the (tile, chunk) hash keeps the keys of released tiles: empty it before it fills up
+  // the (tile, entry) hash keeps the keys of released tiles: empty it before it fills up
   if (m->status_host[10] > m->big_slots / 4) m->prepped = false;
   ScatterArgs sa;
   sa.xyz = xyz_dev;
