@@ -171,7 +171,7 @@ typedef struct
   int64_t records;          /* scatter targets that became records (ray tails + free-space candidates on keyed voxels) */
   int64_t tiles;            /* touched 4x4x64-voxel tiles (resolved and integrated)                             */
   int32_t error_flags;      /* device error bits since the last call: 2 record-field range, 4 free-space bound, 8 internal */
-  int32_t pad;
+  int32_t hash_entries;     /* entries beyond a tile's 128th that went through the (tile, number) hash since it was last emptied */
   int64_t runs;             /* (wave, tile) groups of records: one reservation in the tile's entry table each           */
   int64_t free_space_hits;  /* free-space candidates that met ordered candidates (and joined that tile's records)   */
   int64_t record_slots;     /* the scan's record bound (from its set-up pass) ...                                 */

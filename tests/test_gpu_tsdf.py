@@ -175,6 +175,27 @@ def test_fans_and_contested_voxels_match_oracle(up):
     assert stats["contested_voxels"] > 10_000  # the ordered rounds did real work
 
 
+def test_tiles_with_more_sub_chunks_than_their_table_holds():
+    """A scanner in a cupboard: 131 072 rays end on 3 m^2 of wall, thousands of records per 80 mm tile column.  A tile's
+    entry table holds 128 sub-chunks; the rest goes through the (tile, number) hash and the resolve streams such tiles from
+    memory in every pass.  Two scans (the second finds the hash populated with released keys), both bit-exact."""
+    torch = _torch()
+    tau, res, mw, size = 600, 20, 640, (160, 160, 100)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    for k, sensor in enumerate([(30.0, -20.0, 10.0), (60.0, 10.0, -15.0)]):
+        pts = S.os1_128_scan(sensor_mm=sensor, rings=128, azimuths=1024, half_extents_mm=(520.0, 470.0, 330.0), seed=21 + k)
+        pos = [int(np.floor(np.float32(c) / np.float32(res))) for c in sensor]
+        O.update_tsdf(oa, on, pts, pos, (0, 0, 32768), tau, mw, res)
+        t.update_tsdf(torch.from_numpy(pts).cuda(), pos, (0, 0, 32768))
+        st = t.stats()
+        assert st["status"] == 0 and st["error_flags"] == 0
+        assert st["hash_entries"] > 0, st
+        assert st["records"] > 128 * 32 * 4
+        got = download(t, lm, 0)
+        mism = np.nonzero(got != oa.data)[0]
+        assert mism.size == 0, f"scan {k}: {mism.size} voxels differ, stats={st}"
+
+
 def W_entry_weight(raw):
     return (np.asarray(raw, dtype=np.uint32) >> 16).astype(np.uint16).astype(np.int16)
 

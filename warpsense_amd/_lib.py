@@ -82,7 +82,7 @@ def check_h5(rc: int, what: str):
 
 class TsdfStats(C.Structure):
     _fields_ = [("contested_voxels", C.c_int64), ("records", C.c_int64), ("tiles", C.c_int64),
-                ("error_flags", C.c_int32), ("pad", C.c_int32), ("runs", C.c_int64), ("free_space_hits", C.c_int64),
+                ("error_flags", C.c_int32), ("hash_entries", C.c_int32), ("runs", C.c_int64), ("free_space_hits", C.c_int64),
                 ("record_slots", C.c_int64), ("record_capacity", C.c_int64)]
 
 

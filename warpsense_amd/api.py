@@ -579,7 +579,7 @@ class TSDFCuda:
         rc = self._L.ws_tsdf_stats(self.handle, C.byref(st))
         out = {"contested_voxels": st.contested_voxels, "records": st.records, "tiles": st.tiles, "error_flags": st.error_flags,
                "runs": st.runs, "free_space_hits": st.free_space_hits, "record_slots": st.record_slots,
-               "record_capacity": st.record_capacity, "status": rc}
+               "record_capacity": st.record_capacity, "hash_entries": st.hash_entries, "status": rc}
         if rc != 0 and raise_on_error:
             check(rc, "ws_tsdf_stats")
         return out

@@ -754,7 +754,7 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
   out->record_capacity = (int64_t)m->sub_cap * SUB_RECS;
   const int rc = map_take_error(m);
   out->error_flags = (int32_t)m->last_error_bits;
-  out->pad = 0;
+  out->hash_entries = (int32_t)m->status_host[10];
   m->last_error_bits = 0;
   return rc;
 }

@@ -861,6 +861,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   // a record (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
   auto put_record = [&](uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
     // the free-space pass must know that this voxel takes part in the key order
+    // (as a non-temporal store -- the marks push the half-filled sub-chunk lines out of the L2: 380 MB of writes for 98 MB of
+    // records -- the kernel takes 462 instead of 183 us)
     if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
     wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz)));
