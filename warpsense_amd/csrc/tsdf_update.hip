@@ -671,7 +671,7 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
         const uint32_t s = s0 + lr + (uint32_t)u * na;
         const bool first = c[u] != 0 && j0[u] == 0;
         const unsigned long long fm = __ballot(first);
-        if (first) my_first |= (n_first + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))) << (8 * u) | (0x80u << (8 * u));
+        if (first) my_first |= (((n_first + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))) & 0x7fu) | 0x80u) << (8 * u);
         n_first += (uint32_t)__popcll(fm);
         n_used += (uint32_t)__popcll(__ballot(c[u] != 0));
         if (c[u])
@@ -680,8 +680,7 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
           wt.cnt[s] = c[u] | (j0[u] << 13);
         }
       }
-      // (n_first <= 4 * 64 would not fit the byte above for four full rounds of firsts: ranks are per lane below 2^7 only when
-      // n_first < 128 -- a flush of more than 127 new tiles takes the list places one by one)
+      // (a lane's place among the firsts travels in seven bits: a flush of more than 127 new tiles takes the list places one by one)
       if (n_first)
       {
         if (n_first < 128u)
