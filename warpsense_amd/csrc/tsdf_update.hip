@@ -621,7 +621,7 @@ struct WaveTab
   uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
 };
 
-__device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile)
+__device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile, bool &fresh)
 {
   uint32_t h = (tile * 0x9E3779B1u) >> (32 - WT_BITS);
   for (int p = 0; p < WT_SLOTS; ++p)
@@ -631,7 +631,11 @@ __device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile)
     if (cur == HT_EMPTY)
     {
       const uint32_t old = atomicCAS(&wt.key[h], HT_EMPTY, tile);
-      if (old == HT_EMPTY) atomicAdd(&wt.n_slots, 1u);
+      if (old == HT_EMPTY)
+      {
+        atomicAdd(&wt.n_slots, 1u);
+        fresh = true;
+      }
       if (old == HT_EMPTY || old == tile) return (int)h;
     }
     h = (h + 1) & (WT_SLOTS - 1);
@@ -765,13 +769,15 @@ __device__ __forceinline__ uint32_t wave_room(const ScatterArgs &a, WaveTab &wt)
 }
 
 // one record of the wave: its tile's slot, its rank there, the sub-chunk (opened by the record of rank 0 mod 32), its place
-__device__ __forceinline__ void wave_put(const ScatterArgs &a, WaveTab &wt, uint32_t tile, unsigned long long rec)
+// Returns bit 0: the record opened a sub-chunk, bit 1: its tile is new in the table (what the caller's room shrinks by).
+__device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, uint32_t tile, unsigned long long rec)
 {
-  const int s = wt_insert(wt, tile);
+  bool fresh = false;
+  const int s = wt_insert(wt, tile, fresh);
   if (s < 0)
   {
     raise_error(a.counters, a.status, ERR_INTERNAL);
-    return;
+    return 0;
   }
   // (the lanes of a wave mostly hit ONE counter, and the LDS takes such atomics one lane at a time: the old value is used for
   // everything -- no second atomic on the word)
@@ -786,6 +792,7 @@ __device__ __forceinline__ void wave_put(const ScatterArgs &a, WaveTab &wt, uint
   const uint32_t gl = wt.sub_of[s][sub & 3u];
   const uint32_t base = wt.blk[(gl >> 5) & 7u];
   if (base != SUB_LOST) a.rec[((size_t)(base + (gl & 31u)) << SUB_BITS) + pos] = rec;
+  return (pos == 0 ? 1u : 0u) | (fresh ? 2u : 0u);
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
@@ -858,13 +865,13 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   const bool mark = !a.all_keyed;
   uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
   // a record (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
-  auto put_record = [&](uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz) -> uint32_t {
+  auto put_record = [&](uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz, uint32_t &used) -> uint32_t {
     // the free-space pass must know that this voxel takes part in the key order
     // (as a non-temporal store -- the marks push the half-filled sub-chunk lines out of the L2: 380 MB of writes for 98 MB of
     // records -- the kernel takes 462 instead of 183 us)
     if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz)));
+    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz)));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
@@ -896,7 +903,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         // (the lanes reach this point in varying company: room for whoever is here, counted in LDS)
         (void)wave_room(a, wt);
         atomicAdd(&wt.n_rec, 1u);
-        put_record(ix, kk, step - delta_z / f.res, value, sx, sy, sz);
+        uint32_t used = 0;
+        put_record(ix, kk, step - delta_z / f.res, value, sx, sy, sz, used);
       });
   }
   else if (__any(work))
@@ -1010,10 +1018,11 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         const uint32_t n_put = (uint32_t)__popcll(__ballot(puts));
         if (n_put)
         {
-          if (cap_left < n_put) cap_left = wave_room(a, wt);
-          cap_left -= n_put;
+          // (every record of the round could open a sub-chunk and bring a new tile: room for that, then count what they did)
+          if (cap_left < n_put) cap_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_room(a, wt));
           n_written += n_put;
         }
+        uint32_t used = 0;
         if (on)
         {
           int32_t sx, sy, sz;
@@ -1022,9 +1031,14 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
             mark_negative(sx, sy, sz, mid_tile);
           else
           {
-            const uint32_t tile = put_record(s_ix, ek, round < 0 ? 0 : round - mid, value, sx, sy, sz);
+            const uint32_t tile = put_record(s_ix, ek, round < 0 ? 0 : round - mid, value, sx, sy, sz, used);
             if (round < 0) mid_tile = tile;
           }
+        }
+        if (n_put)
+        {
+          const uint32_t n_open = (uint32_t)__popcll(__ballot(used & 1u)), n_new = (uint32_t)__popcll(__ballot(used & 2u));
+          cap_left -= n_open > n_new ? n_open : n_new;
         }
       }
     };
