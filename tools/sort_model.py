@@ -58,3 +58,9 @@ def entries(order,label):
     e = np.array(list(ent.values())); r=np.array([recs[k] for k in ent])
     print(label,'tiles',len(e),'entries mean',e.mean(),'>64:',(e>64).sum(),'>128:',(e>128).sum(),'records in >64 tiles',r[e>64].sum(),'of',r.sum(), 'slots',e.sum()*32)
 entries(np.argsort(zh*4096+morton(bx,by),kind='stable'),'morton')
+
+# polar cells around the sensor, far rings first (longest work items first): 32 rings x 128 sectors x above / below
+rr = np.hypot(pts[:,0], pts[:,1]); ang = np.arctan2(pts[:,1], pts[:,0])
+ring = np.clip((rr / 450.0).astype(int), 0, 31); sec = np.clip(((ang + np.pi) * (128 / (2 * np.pi))).astype(int), 0, 127)
+pairs(np.argsort(((31 - ring) * 2 + zh) * 128 + sec, kind='stable'), 'polar, far first (ring, z, sector)')
+pairs(np.argsort(((31 - ring) * 128 + sec) * 2 + zh, kind='stable'), 'polar, far first (ring, sector, z)')

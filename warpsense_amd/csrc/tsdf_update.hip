@@ -95,8 +95,11 @@ constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 #ifndef WS_EL_BINS
 #define WS_EL_BINS 8
 #endif
+#ifndef WS_SORT_RINGS
+#define WS_SORT_RINGS 16 // (tail march at 4 / 8 / 16 / 32 / 64 rings: 146 / 146 / 146 / 154 / 152 us, set-up pass 36 / 31 / 28 / 30 / 28)
+#endif
 #ifndef WS_SORT_CELLS
-#define WS_SORT_CELLS 2
+#define WS_SORT_CELLS 3
 #endif
 constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
 static_assert(AZ_ONLY_BINS * EL_BINS == 64 * 64 * 2, "the cell sort uses the same 8192 bins");
@@ -335,11 +338,12 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
       }
     }
   }
-  // Sort bin of the ray; bin AZ_BINS = unused ray.  The tails are sorted by WHERE THE RAY ENDS: a 64 x 64 grid of cells over the
-  // map window (0.4 m at 513^3 / 50 mm), above / below the sensor -- the tail of a ray lies within tau of its end, so the 64
-  // rays of a wave of the tail march put their records into the few tiles around one cell.  (Until round 4 the key was the
-  // direction, 1024 azimuths x 8 elevations: rays of one direction bin that graze the floor end metres apart, a wave's
-  // records fell into 27 tiles on average, 28 records per (wave, tile) pair.)
+  // Sort bin of the ray; bin AZ_BINS = unused ray.  The tails are sorted by WHERE THE RAY ENDS -- the tail of a ray lies within
+  // tau of its end, so the 64 rays of a wave of the tail march put their records into the few tiles around one cell -- in
+  // polar cells around the sensor (16 rings x 256 sectors, above / below the sensor), the FAR rings first: see below.
+  // (Rounds 1-3 sorted by direction, 1024 azimuths x 8 elevations: rays of one direction bin that graze the floor end metres
+  // apart -- 435 k (wave, tile) pairs per scan; a 64 x 64 grid of square cells in Morton order: 297 k, tail march 178 us; the
+  // polar cells: 244 k, 146 us -- two thirds of that gain is the order of the work items.)
   if (ix < a.n)
   {
     uint32_t bin = AZ_BINS;
@@ -350,7 +354,21 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
       int bx = (hvx - a.map.pos[0] + a.map.size[0] / 2) / cwx, by = (hvy - a.map.pos[1] + a.map.size[1] / 2) / cwy;
       bx = bx < 0 ? 0 : (bx > 63 ? 63 : bx);
       by = by < 0 ? 0 : (by > 63 ? 63 : by);
-#if WS_SORT_CELLS == 2
+#if WS_SORT_CELLS == 3
+      // polar cells around the sensor -- WS_SORT_RINGS rings x 4096 / WS_SORT_RINGS sectors, above / below -- the FAR rings first: rays that end far away
+      // carry fans (up to three times the records), and work items in descending order of their length leave the shortest
+      // for the end of the launch, when the compute units run empty
+      const float fdx = (float)r.dx, fdy = (float)r.dy;
+      constexpr int RINGS = WS_SORT_RINGS, SECTORS = 4096 / RINGS;
+      const float ringw = (float)(a.map.size[0] > a.map.size[1] ? a.map.size[0] : a.map.size[1]) * (float)res * (0.5f / (float)RINGS);
+      int ring = (int)(sqrtf(fdx * fdx + fdy * fdy) / ringw);
+      ring = ring < 0 ? 0 : (ring > RINGS - 1 ? RINGS - 1 : ring);
+      int sec = (int)((atan2f(fdy, fdx) + 3.14159265f) * ((float)SECTORS / 6.2831853f));
+      sec = sec < 0 ? 0 : (sec > SECTORS - 1 ? SECTORS - 1 : sec);
+      bin = (uint32_t)(((RINGS - 1 - ring) * 2 + (hvz >= a.scanner_pos[2] ? 1 : 0)) * SECTORS + sec);
+      (void)bx;
+      (void)by;
+#elif WS_SORT_CELLS == 2
       // Morton order of the cells, above / below the sensor as the major key: where rays are sparse a wave's 64 rays span
       // several bins, and consecutive bins should still be neighbours in space
       uint32_t mx = (uint32_t)bx, my = (uint32_t)by;
