@@ -1229,6 +1229,7 @@ __global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
   __shared__ uint32_t s_keyed[4];
+  // (the workgroups in descending order of their rays' lengths instead of scan order: no change, measured -- this pass has no idle tail)
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
   const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
   const int lane = threadIdx.x & 63;
@@ -1405,7 +1406,11 @@ struct ResolveArgs
 };
 static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
 
-constexpr int RESOLVE_GRID = 4096; // 1024 / 2048 / 8192 workgroups: the same 170 us, 3072: 182 (block_stats holds two words per workgroup)
+#ifndef WS_RESOLVE_GRID
+#define WS_RESOLVE_GRID 1280 // 256 compute units x five resident workgroups: every workgroup is on the chip from the start (1280 / 2560 / 4096: 124 / 129 / 130 us)
+#endif
+constexpr int RESOLVE_GRID = WS_RESOLVE_GRID; // (block_stats holds two words per workgroup, 4096 at most)
+static_assert(RESOLVE_GRID <= 4096, "resolve_stats");
 constexpr uint32_t M_IDLE = 0xffffffffu, M_NONE = 0x10000u; // mstate: voxel not in the ordered rounds / no earlier negative seen
 constexpr unsigned long long REC_NONE = ~0ull;
 
