@@ -32,3 +32,9 @@ start = (start - start.min()) & 0xffffffff
 end = start + march + flush
 print(f"items {n}: march mean {march.mean() / 100:.1f} us (max {march.max() / 100:.1f}), flush mean {flush.mean() / 100:.1f} us (max {flush.max() / 100:.1f}); "
       f"first start -> last end {end.max() / 100:.1f} us; sum of durations / span = {(march + flush).sum() / end.max():.0f} workgroups busy on average")
+# how the launch ends: workgroups still busy at the given fraction of the span
+dur = march + flush
+for frac in (0.5, 0.75, 0.85, 0.9, 0.95):
+    tt = frac * end.max()
+    print(f"  at {100 * frac:.0f} % of the span: {int(((start <= tt) & (end > tt)).sum())} workgroups busy")
+print(f"  item duration: p10 {np.percentile(dur, 10) / 100:.1f} us, p50 {np.percentile(dur, 50) / 100:.1f}, p90 {np.percentile(dur, 90) / 100:.1f}, max {dur.max() / 100:.1f}; last item starts at {start.max() / 100:.1f} us")

@@ -1447,12 +1447,12 @@ __device__ __forceinline__ uint32_t resolve_entry(const ResolveArgs &a, uint32_t
 #define WS_STREAM_U 2 // (four: ten spilled registers in the fused resolve, 141 instead of 132 us)
 #endif
 template <class F>
-__device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t nsub, uint32_t cid, F &&f)
+__device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t tile, uint32_t nsub, uint32_t cid, uint32_t first, F &&f)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t half = threadIdx.x >> 5, pos = threadIdx.x & 31u;
   constexpr int U = WS_STREAM_U;
-  for (uint32_t b0 = 0; b0 < nsub; b0 += 64)
+  for (uint32_t b0 = first; b0 < nsub; b0 += 64) // (first: 0 or 64 -- the first 64 entries may be in the caller's registers)
   {
     uint32_t ents = cid;
     if (b0 == 64)
@@ -1543,6 +1543,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
   __shared__ uint32_t s_unres[2];
+#ifdef WS_RESOLVE_TIMING
+  const long long t_begin = wall_clock64();
+#endif
   const uint32_t n_list = a.counters->n_listed; // the tiles with records
   const bool aborted = a.counters->abort != 0;
   const int32_t weight_epsilon = a.tau / 10;
@@ -1599,7 +1602,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   auto fetch_records = [&](const TilePre &p) -> bool {
     if (FUSED) ex_next = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + p.idx0);
     const uint32_t nsub = aborted ? 0u : p.fill;
-    const bool in_regs = nsub != 0 && nsub <= (uint32_t)(8 * RES_MAXR);
+    const bool in_regs = nsub != 0; // (a tile of more than 8 * RES_MAXR sub-chunks: the first 64 here, the rest streamed)
     const uint32_t pos = threadIdx.x & 31u;
 #pragma unroll
     for (int k = 0; k < RES_MAXR; ++k)
@@ -1788,9 +1791,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
               f((uint64_t)rrec[k], value, av, l);
             }
         }
-        else
+        // what the registers do not hold: everything (the ordered rounds: the registers hold the next tile's records by then),
+        // or the sub-chunks beyond the 64th of a heavy tile
+        if (!from_regs || fill > (uint32_t)(8 * RES_MAXR))
         {
-          for_each_record(a, tile, fill, p.cid, [&](uint64_t rec, int32_t value, int32_t av, int l) {
+          for_each_record(a, tile, fill, p.cid, from_regs ? (uint32_t)(8 * RES_MAXR) : 0u, [&](uint64_t rec, int32_t value, int32_t av, int l) {
             if (HAS_S0 && av >= (int32_t)bound0[l]) return;
             f(rec, value, av, l);
           });
@@ -2064,6 +2069,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   {
     a.resolve_stats[2 * blockIdx.x + 0] = s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3];
     a.resolve_stats[2 * blockIdx.x + 1] = n_mine;
+#ifdef WS_RESOLVE_TIMING
+    // (instead of the statistics: 10 ns ticks this workgroup was busy, and when it started)
+    a.resolve_stats[2 * blockIdx.x + 0] = (uint32_t)(wall_clock64() - t_begin);
+    a.resolve_stats[2 * blockIdx.x + 1] = (uint32_t)t_begin;
+#endif
   }
 }
 
