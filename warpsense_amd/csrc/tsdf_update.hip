@@ -83,6 +83,9 @@ constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
+#ifndef WS_TAIL_SPLIT
+#define WS_TAIL_SPLIT 2 // workgroups that share the tails of one group of 64 rays (four parts of 4 * WS_TAIL_SPLIT each)
+#endif
 #ifndef WS_FREE_FIRST
 #define WS_FREE_FIRST 32 // sub-chunks every wave of the free pass owns from the start (see pool_grab; 16: 136 us, 32: 121, 64: 120)
 #endif
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
 // (nothing of it reaches the maps) and repeated with more (launch_tsdf_scatter).
 __host__ inline unsigned long long subs_needed(unsigned long long need, uint32_t est_shift, unsigned long long n_points)
 {
-  const unsigned long long items = (n_points + 63) / 64 * 2 + 1; // (TAIL_SPLIT == 2 workgroups per 64 rays)
+  const unsigned long long items = (n_points + 63) / 64 * WS_TAIL_SPLIT + 1; // (TAIL_SPLIT workgroups per 64 rays)
   const unsigned long long free_waves = (n_points + 63) / 64 * 4; // (64 rays per workgroup of the free pass)
   return items * SUB_WG_BLOCK + free_waves * WS_FREE_FIRST + ((need >> SUB_BITS) >> (est_shift ? est_shift - 1 : 0)) + 8192ull;
 }
