@@ -668,6 +668,7 @@ __device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile, bool &fresh
 // (the general walk does, with whoever is there).  ONE memory round trip: a tile's entries are reserved with one atomic per
 // (wave, tile) -- four tiles per lane travel together -- and written behind it; a tile that had no entries yet goes on the
 // scan's tile list (one request to the list's counter per flush).
+template <bool LAST = false> // LAST: the wave is through (its table is not used again: not emptied)
 __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
 {
   const unsigned long long act = __ballot(1);
@@ -744,6 +745,7 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
     }
     asm volatile("" ::: "memory");
   }
+  if (LAST) return;
   for (uint32_t s = lr; s < (uint32_t)WT_SLOTS; s += na)
   {
     wt.key[s] = HT_EMPTY;
@@ -1079,7 +1081,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   const long long t_mid = wall_clock64();
 #endif
   // ---- phase 2: the wave publishes what it has filled
-  wave_flush(a, wt);
+  wave_flush<true>(a, wt);
   if (lane == 0)
   {
     atomicAdd(&s_stat[0], n_written + wt.n_rec);
