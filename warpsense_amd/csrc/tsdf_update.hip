@@ -1229,7 +1229,10 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // targets as marks in the second byte plane: 10.8 M records instead of 14.4 M and a tail march of 146 instead of 187 us, but
 // a free pass of 195-230 instead of 123 us whatever the lane layout: out there neighbouring rays are more than a voxel
 // apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
-__global__ __launch_bounds__(256) void march_free_kernel(ScatterArgs a)
+#ifndef WS_FREE_WGS
+#define WS_FREE_WGS 7 // workgroups per CU the register budget is set for (5 / 6 / 7 / 8: 121 / 120 / 117 / 147 us; seven: 72 VGPRs, 11 spilled outside the loop)
+#endif
+__global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
 {
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
