@@ -28,3 +28,7 @@ start = (start - start.min()) & 0xffffffff
 end = start + busy
 print(f"workgroups {n}: busy mean {busy.mean() / 100:.1f} us, min {busy.min() / 100:.1f}, max {busy.max() / 100:.1f}; "
       f"last start {start.max() / 100:.1f} us, kernel span {end.max() / 100:.1f} us; p50 end {np.percentile(end, 50) / 100:.1f}, p90 {np.percentile(end, 90) / 100:.1f}, p99 {np.percentile(end, 99) / 100:.1f}")
+# by XCD (workgroup b runs on XCD b % 8 under round-robin dispatch) and by CU slot
+for x in range(8):
+    sel = busy[x::8]
+    print(f"  XCD {x}: busy mean {sel.mean() / 100:.1f} us, max {sel.max() / 100:.1f}")
