@@ -123,6 +123,52 @@ def test_nondefault_new_map_first_update(tau, res, size, he, rings, az):
     assert np.all(download(t, lm, 1) == O.pack(tau, 0))
 
 
+@pytest.mark.parametrize("mode", ["sparse", "separate"])
+def test_updates_after_a_nondefault_start_stay_exact(mode):
+    """the scan into a non-default new_map left the 'listed' byte of every tile with records set; on the
+    NEXT scans such a tile, if it only got free-space or off-ray marks, was skipped by the flag scan -- its (tau, +-64)
+    results never reached the map and its voxel bytes surfaced later.  Three updates: the first from a filled map in a small
+    room (records in the wall tiles), then two in a LARGER room from moved poses (rays pass through the old walls: those tiles
+    now hold marks only), each compared with the oracle."""
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw, size = 600, 50, 640, (128, 128, 64)
+    rng = np.random.default_rng(11)
+    lm = W.LocalMap(*size, tau, 0)
+    n = lm.data.size
+    vals = rng.integers(-tau, tau + 1, n).astype(np.int16)
+    wts = rng.choice(np.array([0, 0, 0, 0, -64, 64, 23], dtype=np.int16), n)
+    lm.data[:] = O.pack(vals, wts)
+    oa = O.OracleMap(size, tau, 0, data=lm.data.copy())
+    on = oa.copy()
+    t = W.TSDFCuda(lm.device_map(), tau, mw, res)
+    t.set_integrate(W.WS_INTEGRATE_SPARSE if mode == "sparse" else W.WS_INTEGRATE_SPARSE_SEPARATE)
+    scans = [((1200.0, 1000.0, 600.0), (0, 0, 0), 5), ((2800.0, 2600.0, 1300.0), (3, -2, 1), 6), ((2900.0, 2500.0, 1200.0), (-4, 5, 0), 7)]
+    for he, sp, seed in scans:
+        sensor = tuple(float(c * res + res // 2) for c in sp)
+        pts = S.os1_128_scan(sensor_mm=sensor, rings=32, azimuths=256, half_extents_mm=he, seed=seed)
+        O.update_tsdf(oa, on, pts, sp, (0, 0, 32768), tau, mw, res)
+        t.update_tsdf(torch.from_numpy(pts).cuda(), sp, (0, 0, 32768))
+        assert np.array_equal(download(t, lm, 0), oa.data), (mode, seed)
+        assert np.all(download(t, lm, 1) == O.pack(tau, 0))
+
+
+def test_small_scans_with_idle_resolve_workgroups_keep_their_tile_list():
+    """the non-fused resolve appended the tiles without records through n_listed, the word every workgroup
+    reads on entry -- on scans with fewer listed tiles than workgroups the idle ones go straight to the flag scan and append
+    while others have not started.  Many small scans through the separate-integrate route, each against the oracle."""
+    torch = _torch()
+    import warpsense_amd as W
+    tau, res, mw, size = 1000, 50, 640, (96, 96, 48)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    t.set_integrate(W.WS_INTEGRATE_SPARSE_SEPARATE)
+    for k in range(12):
+        pts = S.os1_128_scan(rings=4 + k % 3, azimuths=64, half_extents_mm=(1800.0, 1500.0, 700.0), seed=20 + k)
+        O.update_tsdf(oa, on, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+        t.update_tsdf(torch.from_numpy(pts).cuda(), (0, 0, 0), (0, 0, 32768))
+        assert np.array_equal(download(t, lm, 0), oa.data), k
+
+
 def test_too_many_points_is_a_noop(capsys):
     """update_tsdf.cu:146-150: stderr message and no work."""
     tau, res, mw = 1000, 50, 640

@@ -213,6 +213,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
     a.counters->chunk_cursor = 0;
     a.counters->free_cursor = 0;
     a.counters->n_listed = 0;
+    a.counters->n_appended = 0;
     a.counters->abort = 0;
     a.counters->error = 0;
     a.counters->last_free_keyed = 0;
@@ -1028,16 +1029,21 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
         sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
       };
-      // Rounds of at most one target per lane: first the on-ray targets (fan step `mid`: always a record, and its tile is on
-      // the list through it), then the off-ray ones (update_tsdf.cu:107-125) fan step by fan step.  In front of every round
-      // the wave makes sure its bookkeeping has room for the records of the round (a scalar compare, nearly always).
-      uint32_t mid_tile = 0xffffffffu;
-      for (int32_t round = -1;; ++round)
+      // Rounds of at most one target per lane, fan step by fan step (update_tsdf.cu:107-125) IN THE FAN'S OWN ORDER: round j is
+      // fan step j of every sample whose fan has more than j steps -- the on-ray target (always a record) where j == mid, an
+      // off-ray one (a record, or a mark for a sample of value +tau) elsewhere.  The samples of a batch come from rays that
+      // end in the same cell, i.e. of nearly the same length, and the fan's width depends on the length alone: the rounds run
+      // 92 % full (tools/lane_model.py).  (Until round 5 the on-ray targets had a round of their own in front and every lane
+      // sat out the round j == mid: 381 k rounds of 59 % instead of 244 k for the benchmark scan's 14.4 M targets.)  In front
+      // of every round the wave makes sure its bookkeeping has room for the records of the round (a scalar compare, nearly always).
+      uint32_t mid_tile = 0xffffffffu; // the tile of the sample's on-ray record, once that is made (it is on the list through it)
+      for (int32_t round = 0;; ++round)
       {
         // (the loop bound as a ballot per round: a maximum over the lanes by shuffles is six trips through the LDS pipe per emit phase)
-        if (round >= 0 && !__any(round < iter_steps)) break;
-        const bool on = round < 0 ? iter_steps > 0 : (round < iter_steps && round != mid);
-        const bool puts = on && !(blind && round >= 0);
+        if (!__any(round < iter_steps)) break;
+        const bool on = round < iter_steps;
+        const bool onray = round == mid;
+        const bool puts = on && (onray || !blind);
         const uint32_t n_put = (uint32_t)__popcll(__ballot(puts));
         if (n_put)
         {
@@ -1049,13 +1055,13 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         if (on)
         {
           int32_t sx, sy, sz;
-          target(round < 0 ? mid : round, sx, sy, sz);
+          target(round, sx, sy, sz);
           if (!puts)
             mark_negative(sx, sy, sz, mid_tile);
           else
           {
-            const uint32_t tile = put_record(s_ix, ek, round < 0 ? 0 : round - mid, value, sx, sy, sz, used);
-            if (round < 0) mid_tile = tile;
+            const uint32_t tile = put_record(s_ix, ek, round - mid, value, sx, sy, sz, used);
+            if (onray) mid_tile = tile;
           }
         }
         if (n_put)
@@ -1671,6 +1677,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   // ever read up to the count) and the values of its entries in the hash
   auto release_tile = [&](uint32_t tile, uint32_t nsub) {
     if (threadIdx.x == 8) a.tile_nsub[tile] = 0;
+    // (the scan over the flag planes below owns the "listed" bytes and clears them; a scan into a non-default new_map has no
+    // such pass -- ADVICE r4: the bytes of its listed tiles stayed set and hid those tiles from the NEXT scan's flag scan)
+    if (HAS_S0 && threadIdx.x == 9) a.tile_dirty[tile_flag_plane_bytes(a.n_tiles) + tile] = 0;
     if (nsub > (uint32_t)TILE_DIRECT)
     {
       uint32_t *vals = reinterpret_cast<uint32_t *>(a.big_keys + (size_t)a.big_mask + 1);
@@ -2059,7 +2068,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           TileEntry e;
           e.tile = tile;
           e.tx = tx; e.ty = ty; e.tz = tz;
-          a.tile_list[atomicAdd(&a.counters->n_listed, 1u)] = e;
+          // behind the marches' entries, through a counter of its own: n_listed is what every workgroup of this launch read on
+          // entry (a workgroup that starts late must not take an appended tile for a listed one)
+          a.tile_list[n_list + atomicAdd(&a.counters->n_appended, 1u)] = e;
         }
       }
       __syncthreads();
@@ -2115,7 +2126,7 @@ constexpr int SPARSE_GRID = 4096;
 // tile_resolve_kernel (64-byte runs along z).
 __global__ __launch_bounds__(256) void integrate_sparse_kernel(IntegrateArgs a)
 {
-  const uint32_t n_list = a.counters->n_listed;
+  const uint32_t n_list = a.counters->n_listed + a.counters->n_appended; // tiles with records + the others the resolve found
   const uint32_t reset = pack_entry(a.tau, 0);
   // thread t owns the voxels 4t .. 4t+3 of the tile: column t >> (ZB - 2), four consecutive z
   const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
@@ -2370,6 +2381,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     m->resolve_blocks = 0;
     // nothing listed: a following integrate pass has nothing to do
     WS_HIP(hipMemsetAsync(&m->counters->n_listed, 0, sizeof(uint32_t), s));
+    WS_HIP(hipMemsetAsync(&m->counters->n_appended, 0, sizeof(uint32_t), s));
     return WS_OK;
   }
 

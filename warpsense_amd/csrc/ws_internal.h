@@ -93,13 +93,15 @@ struct TileEntry // 16 bytes: one touched tile of the scan in flight
 struct TsdfCounters // device-resident
 {
   uint32_t chunk_cursor;  // sub-chunks handed out from the bottom of the pool by the tail march (reset by the set-up pass of the next scan)
-  uint32_t n_listed;      // tiles with records (length of the tile list; the resolve appends the other touched tiles when a separate integrate pass follows; survives until the next scatter)
+  uint32_t n_listed;      // tiles with records (what the marches put on the tile list; final when the resolve starts; survives until the next scatter)
   uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
   uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
   uint32_t big_inserted;  // keys ever put into the (tile, chunk) hash since it was last emptied (the host empties it when it fills up)
   uint32_t free_cursor;   // sub-chunks handed out from the TOP of the pool by the free pass (one record each: a free-space candidate on a keyed voxel)
-  unsigned long long pad0;
+  uint32_t n_appended;    // tiles WITHOUT records the non-fused resolve has put behind the listed ones (tile_list[n_listed ...]) for the separate integrate pass;
+                          // a counter of its own: every workgroup of the resolve reads n_listed on entry, so nothing may move that word while the resolve runs
+  uint32_t pad0;
   // statistics of the last update (ws_tsdf_stats)
   uint32_t last_records;
   uint32_t last_contested;
