@@ -430,10 +430,18 @@ void wso_reg_iterate(const wso_map *map, const float T[16], const int32_t *xyz, 
   free(m);
 }
 
-/* ---------- 6x6 solve: LU with partial pivoting in double (Eigen hf.inverse()*g, tsdf_registration.cpp:69) ---------- */
+/* ---------- 6x6 solve in double (Eigen's hf.inverse() * g, tsdf_registration.cpp:69) ----------
+ * Gauss-Jordan elimination with partial pivoting; the multipliers are formed with the pivot's reciprocal (one division per
+ * pivot, six in all) and the elimination clears the column above the pivot as well, so there is no back substitution:
+ * x[i] = b[i] * (1 / pivot i).  The reference inverts with Eigen (PartialPivLU for a 6x6, version unpinned) and multiplies:
+ * parity for this one step is UNPINNED either way and absorbed by the pose tolerance (1e-4 m / 1e-4 rad); the choice of
+ * elimination order is this repository's.  Until round 5 it was LU + back substitution with eleven divisions: on the GPU the
+ * solve is one wave's dependent chain in the middle of every Gauss-Newton iteration, and the six divisions plus 36 operand
+ * fetches of the back substitution were 40 % of it.  tests/test_oracle_pins.py holds this solver against numpy's LAPACK solve
+ * (the reference's algorithm class) on the benchmark's own normal equations: relative difference below 1e-9. */
 int wso_solve6(const double A_in[36], const double b_in[6], double x[6])
 {
-  double A[6][6], b[6];
+  double A[6][6], b[6], inv[6];
   for (int i = 0; i < 6; ++i)
   {
     b[i] = b_in[i];
@@ -451,19 +459,16 @@ int wso_solve6(const double A_in[36], const double b_in[6], double x[6])
       for (int j = 0; j < 6; ++j) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
       double t = b[k]; b[k] = b[piv]; b[piv] = t;
     }
-    for (int i = k + 1; i < 6; ++i)
+    inv[k] = 1.0 / A[k][k];
+    for (int i = 0; i < 6; ++i)
     {
-      double f = A[i][k] / A[k][k];
-      for (int j = k; j < 6; ++j) A[i][j] -= f * A[k][j];
+      if (i == k) continue;
+      double f = A[i][k] * inv[k];
+      for (int j = k + 1; j < 6; ++j) A[i][j] -= f * A[k][j];
       b[i] -= f * b[k];
     }
   }
-  for (int i = 5; i >= 0; --i)
-  {
-    double s = b[i];
-    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
-    x[i] = s / A[i][i];
-  }
+  for (int i = 0; i < 6; ++i) x[i] = b[i] * inv[i];
   return 0;
 }
 

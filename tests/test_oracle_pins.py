@@ -380,3 +380,36 @@ def test_synthetic_scan_counters_match_reference_kernel():
     assert st.write_calls == 35_442_598
     assert int((new.data != O.pack(1000, 0)).sum()) == 13_901_324
     assert int((w < 0).sum()) == 1_522_214
+
+
+# ------------------------------------------------------------------ 4. the 6x6 solve against the reference's algorithm class
+def test_solver_agrees_with_a_lapack_solve_on_real_normal_equations():
+    """tsdf_registration.cpp:69 inverts with Eigen (PartialPivLU for a 6x6) and multiplies.  The oracle's wso_solve6 is a
+    Gauss-Jordan elimination with partial pivoting whose multipliers come from the pivots' reciprocals (the order of operations
+    is this repository's choice: on the GPU the solve is one wave's dependent chain).  Parity for that step is unpinned by
+    design -- the Eigen version is not fixed by the reference -- so it is held against LAPACK's partial-pivoting solve
+    (numpy), the same algorithm class: normal equations of a real registration (every iteration's h, g with the damping of
+    :66), relative difference far below what the pose's float32 keeps."""
+    import ctypes as C
+    size, tau, res, mw = (96, 96, 48), 1000, 50, 640
+    pts = S.os1_128_scan(rings=32, azimuths=256, half_extents_mm=(2000.0, 1700.0, 800.0), seed=1)
+    oa = O.OracleMap(size, tau, 0)
+    on = oa.copy()
+    O.update_tsdf(oa, on, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+    q = S.transform_points_mm(pts, S.perturbation(30, 20, 0, 1.5))
+    L = O.lib()
+    T = np.eye(4)
+    worst = 0.0
+    for it in range(12):
+        h, g, e, c = O.reg_iterate(oa, T, q, res)
+        assert c > 0
+        hf = np.asarray(h, dtype=np.float64).reshape(6, 6).T.copy() + np.eye(6) * float(np.float32(0.1 * it) * np.float32(c))
+        gf = np.asarray(g, dtype=np.float64).copy()
+        x = np.zeros(6)
+        assert L.wso_solve6(hf.ctypes.data_as(C.c_void_p), gf.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p)) == 0
+        ref = np.linalg.solve(hf, gf)
+        worst = max(worst, float(np.abs(x - ref).max() / np.abs(ref).max()))
+        # move on a little so that the systems differ
+        T = T.copy()
+        T[:3, 3] += (-2.0, -1.5, 0.0)
+    assert worst < 1e-9, worst

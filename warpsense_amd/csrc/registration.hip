@@ -218,7 +218,7 @@ __device__ __forceinline__ void expand_sums(const int64_t *terms, int64_t *sums)
   sums[43] = (int64_t)(int32_t)terms[28];
 }
 
-// ---- 6x6 solve on one wave: LU with partial pivoting in double, the same operations in the same order as
+// ---- 6x6 solve on one wave: Gauss-Jordan with partial pivoting in double, the same operations in the same order as
 // oracle/ws_oracle.c:wso_solve6 (Eigen hf.inverse()*g, tsdf_registration.cpp:69), so the result is bit-identical
 // to a serial solve.  Lane 8*r + c holds element (r, c) of the augmented matrix [A | b] (c == 6 is b): the 5
 // divisions and the rank-1 update of an elimination step are one instruction each instead of 5 / 35, and no
@@ -260,14 +260,21 @@ __device__ __forceinline__ void pin_vgpr(V &v)
 }
 
 // a: this lane's element of [A | b].  Returns 0 and x (identical in every lane), or -1 for a singular matrix.
+// Gauss-Jordan with partial pivoting, the same operations in the same order as oracle/ws_oracle.c:wso_solve6 (round 5; LU +
+// back substitution before): every step clears its column in ALL other rows -- in this layout the rows above the pivot cost
+// nothing, they are other lanes of the same instruction -- and the multipliers come from the pivot's reciprocal, so after the
+// sixth step x[i] = b[i] / pivot i is one multiplication.  Gone: the back substitution's six chained divisions, fifteen
+// multiply-subtracts and 42 operand fetches through v_readlane.
 __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
 {
   const int lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
   int singular = 0;
+  double inv[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k)
   {
     // pivot: first row of maximal |A[i][k]|, i >= k
+    double pv, an, rowk, colk;
 #if WS_SOLVE_DIAG_FIRST
     // The diagonal element keeps its place unless an element BELOW it is strictly larger (the search takes the first maximum):
     // every lane of the column compares its own element with the diagonal, one ballot decides.  Then nothing changes places
@@ -277,53 +284,38 @@ __device__ __forceinline__ int solve6_wave(double a, double (&x)[6])
     const bool below_larger = c == k && r > k && r < 6 && fabs(a) > fabs(dk);
     if (__ballot(below_larger) == 0ull)
     {
-      const double pv = in_vgpr(dk);
-      singular |= pv == 0.0 ? 1 : 0;
-      if (k == 5) break;
-      const double rowk = lane_gather(a, 8 * k + c);
-      const double colk = lane_gather(a, 8 * r + k);
-      const double f = colk / pv;
-      a = (r > k && c >= k) ? a - f * rowk : a;
-      continue;
+      pv = in_vgpr(dk);
+      an = a;
+      rowk = lane_gather(a, 8 * k + c);
+      colk = lane_gather(a, 8 * r + k);
     }
+    else
 #endif
-    int piv = k;
-    double pv = in_vgpr(lane_read(a, 8 * k + k));
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i)
     {
-      const double v = in_vgpr(lane_read(a, 8 * i + k));
-      const bool larger = fabs(v) > fabs(pv);
-      pv = larger ? v : pv;
-      piv = larger ? i : piv;
+      int piv = k;
+      pv = in_vgpr(lane_read(a, 8 * k + k));
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i)
+      {
+        const double v = in_vgpr(lane_read(a, 8 * i + k));
+        const bool larger = fabs(v) > fabs(pv);
+        pv = larger ? v : pv;
+        piv = larger ? i : piv;
+      }
+      // rows k and piv change places; fetch the swapped element, the pivot row and the k-th column in one go
+      const int rr = r == k ? piv : (r == piv ? k : r);
+      an = lane_gather(a, 8 * rr + c);
+      rowk = lane_gather(a, 8 * piv + c);
+      colk = lane_gather(a, 8 * rr + k);
     }
     singular |= pv == 0.0 ? 1 : 0; // the exit is taken once, below (x is not used then)
-    if (k == 5) break;
-    // rows k and piv change places; fetch the swapped element, the pivot row and the k-th column in one go
-    const int rr = r == k ? piv : (r == piv ? k : r);
-    const double an = lane_gather(a, 8 * rr + c);
-    const double rowk = lane_gather(a, 8 * piv + c);
-    const double colk = lane_gather(a, 8 * rr + k);
-    const double f = colk / pv;
-    a = (r > k && c >= k) ? an - f * rowk : an;
+    inv[k] = 1.0 / pv;
+    const double f = colk * inv[k];
+    a = (r != k && c > k) ? an - f * rowk : an;
   }
   if (__builtin_amdgcn_readfirstlane(singular) != 0) return -1;
-  double U[6][6], b[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-  {
-    b[i] = lane_read(a, 8 * i + 6);
-#pragma unroll
-    for (int j = i; j < 6; ++j) U[i][j] = lane_read(a, 8 * i + j);
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i)
-  {
-    double t = b[i];
-#pragma unroll
-    for (int j = i + 1; j < 6; ++j) t -= U[i][j] * x[j];
-    x[i] = t / U[i][i];
-  }
+  for (int i = 0; i < 6; ++i) x[i] = lane_read(a, 8 * i + 6) * inv[i];
   return 0;
 }
 
