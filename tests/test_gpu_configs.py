@@ -86,7 +86,7 @@ def test_config4_2049_map_at_20mm_equals_1025_map_on_the_overlap(tmp_path):
     import torch
     import warpsense_amd as W
     from warpsense_amd import build
-    _need_memory(_free_gpu_gb() >= 130 and _free_host_gb() >= 24,
+    _need_memory(_free_gpu_gb() >= 130 and _free_host_gb() >= 40,
                  "needs ~130 GB on the GPU (2049^3: two maps of 34.4 GB + 17 GB of voxel bytes + tile tables and records + the 1025^3 twin)")
     tau, res, mw = 1000, 20, 640
     room = (10_000.0, 8_000.0, 2_500.0)  # 1000 x 800 x 250 voxels at 20 mm: fits the small window
@@ -132,6 +132,31 @@ def test_config4_2049_map_at_20mm_equals_1025_map_on_the_overlap(tmp_path):
     # (the small window cuts the last metre of the rays that end near its border, so it sees fewer targets)
     assert stats["big"]["records"] >= stats["small"]["records"] > 10_000_000
     assert np.array_equal(boxes["small"], boxes["big"])
+    # The chain's anchor (big == small alone is HIP against HIP): the same two full 131 072-ray scans at
+    # 20 mm and the shift through the CPU oracle on a 1025^3 map (update_tsdf.cu:45-128 at map_resolution = 20, the host
+    # mirror of HDF5LocalMap::shift), the same box, voxel for voxel -- the 2049^3 result is then oracle-exact by transitivity.
+    lm_o = W.LocalMap(1024, 1024, 1024, tau, 0)
+    oa = O.OracleMap((1024, 1024, 1024), tau, 0)
+    on = oa.copy()
+    pos0 = [int(np.floor(np.float32(v) / np.float32(res))) for v in sensors[0]]
+    O.update_tsdf(oa, on, scans[0], pos0, (0, 0, 32768), tau, mw, res)
+    lm_o.data[:] = oa.data
+    lm_o.shift(shift)
+    oa = O.OracleMap((1024, 1024, 1024), tau, 0, pos=lm_o.pos, offset=lm_o.offset)
+    oa.data[:] = lm_o.data
+    on = O.OracleMap((1024, 1024, 1024), tau, 0, pos=lm_o.pos, offset=lm_o.offset)
+    del lm_o
+    pos1 = [int(np.floor(np.float32(v) / np.float32(res))) for v in sensors[1]]
+    O.update_tsdf(oa, on, scans[1], pos1, (0, 0, 32768), tau, mw, res)
+    del on
+    half_small = 1025 // 2 - 12
+    lo = (shift[0] - half_small, shift[1] - half_small, shift[2] - 160)
+    hi = (shift[0] + half_small, shift[1] + half_small, shift[2] + 160)
+    sz = np.asarray(oa.size, dtype=np.int64)
+    ax = [(np.arange(lo[k], hi[k] + 1, dtype=np.int64) - int(oa.pos[k]) + int(oa.offset[k]) + sz[k]) % sz[k] for k in range(3)]
+    want = oa.data.reshape(tuple(int(v) for v in sz))[np.ix_(ax[0], ax[1], ax[2])]
+    assert np.array_equal(np.asarray(boxes["small"]).reshape(want.shape), want)
+    del want, oa
     assert int(np.count_nonzero(boxes["big"] != O.pack(tau, 0))) > 50_000_000
     if export:
         g2 = W.GlobalMap(tau, 0, filename=export, open_existing=True)

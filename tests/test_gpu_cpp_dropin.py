@@ -39,6 +39,34 @@ def test_cpp_harness_matches_oracle(tmp_path):
     assert np.abs(T - To).max() < 1e-4
 
 
+def test_the_three_dropin_routes_agree(tmp_path):
+    """examples/dropin_bench.cpp: the reference's callers unchanged (host vectors, one perform_registration + host solve per
+    iteration -- tsdf_registration.cpp:55-92), the resident device loop behind the same host vectors, and device-resident
+    clouds: same iteration count and bit-identical pose on all three (the binary exits 3 otherwise), and the iteration count
+    is the oracle's."""
+    import json
+    exe = os.path.join(ROOT, "examples", "dropin_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    tau, res, mw, edge = 1000, 50, 640, 96
+    pts = S.os1_128_scan(rings=32, azimuths=256, half_extents_mm=(2000.0, 1700.0, 800.0), seed=2)
+    pert = S.transform_points_mm(pts, S.perturbation(35, -20, 8, 1.5))
+    pts.tofile(tmp_path / "scan.bin")
+    pert.tofile(tmp_path / "pert.bin")
+    out = subprocess.run([exe, str(tmp_path / "scan.bin"), str(tmp_path / "pert.bin"), str(len(pts)), str(edge), str(res), str(tau), str(mw), "3"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["routes_agree"] is True
+    # (every step applies the same scan again: the values of the map do not change after the first update -- the average of equal
+    # values -- and the registration reads values and zero / non-zero weights only, so all registrations see the same map)
+    oa = O.OracleMap((edge, edge, edge), tau, 0)
+    on = oa.copy()
+    O.update_tsdf(oa, on, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+    _, ito, _ = O.register_cloud(oa, pert, np.eye(4), 200, 0.1, 0.03, res)
+    assert d["iterations"] == ito
+
+
 @pytest.mark.parametrize("async_shift", [False, True])
 def test_cpp_replay_matches_python_app(tmp_path, async_shift):
     """(async_shift: MappingNode::shift_map_async in C++ against the synchronous Python App — the map shift off the scan

@@ -37,7 +37,11 @@ def main(prefix):
 
         def kb(d, frag):
             return sum(v for k, v in d.items() if frag in k)
-        for name, frag in (("march_tails", "march_tail_kernel"), ("march_free", "march_free_kernel"), ("tile_resolve", "tile_resolve_kernel"),
+        # the resolve of THIS route only (the sparse pass also ran bench.py's dense-equivalent leg, whose
+        # tile_resolve_kernel<false, false> was summed into the sparse figure -- 891.6 MB instead of 669.9; the passes now set
+        # WS_BENCH_SKIP_DENSE_EQ=1 as well, so a pass holds the kernels of one route)
+        resolve = "tile_resolve_kernel<false, true>" if mode == "sparse" else "tile_resolve_kernel<false, false>"
+        for name, frag in (("march_tails", "march_tail_kernel"), ("march_free", "march_free_kernel"), ("tile_resolve", resolve),
                            ("ray_setup", "ray_s")):
             val = (kb(f, frag) + kb(w, frag)) * 1024
             out[f"{name}:{mode}"] = int(val)
