@@ -36,8 +36,10 @@
 #include <atomic>
 #include <chrono>
 #include <cstddef>
+#include <type_traits>
 
 #include "ws_march.h"
+#include "ws_dda.h"
 
 namespace ws
 {
@@ -91,6 +93,15 @@ constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 #endif
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
+#endif
+#ifndef WS_FREE_DDA
+#define WS_FREE_DDA 1 // 1: the free pass walks from column change to column change (ws_dda.h); 0: rounds 3-4's sample phase + LDS queue
+#endif
+#ifndef WS_FREE_STATIC
+#define WS_FREE_STATIC 0 // 1: the free pass issues the same vector memory instructions in every step (two slots, stores into the slack)
+#endif
+#ifndef WS_FREE_KO
+#define WS_FREE_KO 0 // knock-out builds for timing (results wrong): 1 no tile byte, 2 no voxel store, 4 no voxel load
 #endif
 #ifndef WS_FREE_PIPE
 #define WS_FREE_PIPE 1 // 1: the voxel byte of a free-space candidate is requested one emit phase before it is used (126 -> 122 us)
@@ -1146,7 +1157,11 @@ __device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFr
   p.local = local_of(sx, sy, sz);
   p.ix = ix;
   p.k = k;
+#if WS_FREE_KO & 4
+  p.b = 0; // (knock-out build for timing: no load of the voxel byte)
+#else
   p.b = a.vstate[p.idx];
+#endif
 }
 // the sub-chunks of the records the free pass makes (one each): a wave of the compacting walk keeps the rest of the 64 it
 // took from the pool (fb_next, fb_left: uniform); the general walk -- lanes in varying company -- asks for what it needs
@@ -1154,7 +1169,7 @@ struct FreeBlock
 {
   uint32_t next, left;
 };
-template <bool CACHED>
+template <bool CACHED, bool TILE_MARK = true, bool STORE = true> // TILE_MARK false: the caller marks the candidate's tile itself; STORE false: the keyed half only
 __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed, FreeBlock &fb)
 {
   const uint32_t b = p.b;
@@ -1202,15 +1217,20 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
       n_keyed += 1;
     }
   }
-  if (p.valid && b == 0)
+  if (STORE && p.valid && b == 0)
   {
     // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
     // whose loads both saw 0 both store: idempotent.)
+#if !(WS_FREE_KO & 2)
     a.vstate[p.idx] = VOX_TOUCHED;
+#endif
     // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured; an atomic
     // that puts the tile on the scan's list at its first mark: 123 -> 355 us -- the load sees stale zeros from the L1 of its
     // compute unit all through the kernel, harmless for a byte store, a blocking round trip for a returning atomic)
-    if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
+#if !(WS_FREE_KO & 1)
+    if (TILE_MARK)
+      if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
+#endif
   }
 }
 // both halves at once (general walk)
@@ -1241,7 +1261,9 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
 {
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
+#if !WS_FREE_DDA
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
+#endif
   __shared__ uint32_t s_keyed[4];
   // (the workgroups in descending order of their rays' lengths instead of scan order: no change, measured -- this pass has no idle tail)
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
@@ -1260,11 +1282,13 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
   const bool work = k0 < k1;
   const int32_t tau = a.tau;
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
+#if !WS_FREE_DDA
   // wave-private ring buffer: LDS operations of one wave are performed in order, so no barrier between push and pop
   u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
   uint32_t qhead = 0, qtail = 0;
+#endif
   const int32_t res = f.res, half = f.half, dist = r.distance;
-  if (!__all(!work || (r.pad & RAY_SIMPLE)))
+  if (!__all(!work || ((r.pad & RAY_SIMPLE) && r.distance >= 2)))
   {
     // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests
     if (work)
@@ -1278,6 +1302,128 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
         free_emit(a, f, ix, k, vx, vy, vz, n_keyed);
       });
   }
+#if WS_FREE_DDA
+  else if (__any(work))
+  {
+    // One loop iteration per CANDIDATE (ws_dda.h): the lane walks from one column change of its part of the ray to the next --
+    // the steps at which x or y enters a new voxel are two Bresenham sequences -- and computes the sample's position from the
+    // step number by one exact multiply-shift per axis.  No sample phase, no queue: rounds 3-4 stepped every sample (613 k wave
+    // iterations of ~60 instructions for the benchmark scan) and moved the 21 M candidates through LDS to 333 k emit phases of
+    // ~85; this loop runs 370 k times (tools/lane_model.py: 89 % of its lane slots carry a candidate).  The voxel byte of a
+    // candidate is requested in one iteration and used in the next, as before.
+    FreePending pend;
+    FreeBlock fblock = {a.sub_cap - (blockIdx.x * 4u + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
+    pend.valid = false;
+    pend.idx = 0;
+    pend.tile = pend.local = pend.ix = pend.b = 0;
+    pend.k = 0;
+    const uint32_t adx = (uint32_t)(r.dx < 0 ? -r.dx : r.dx), ady = (uint32_t)(r.dy < 0 ? -r.dy : r.dy), adz = (uint32_t)(r.dz < 0 ? -r.dz : r.dz);
+    const int32_t smx = r.dx < 0 ? -1 : 0, smy = r.dy < 0 ? -1 : 0, smz = r.dz < 0 ? -1 : 0;
+    const int32_t sposx = (f.posx ^ smx) - smx, sposy = (f.posy ^ smy) - smy, sposz = (f.posz ^ smz) - smz;
+    // the fan base offset c0 = trunc(delta_z * iv / 32768) (update_tsdf.cu:103-110 with one fan step): delta_z >= 0, so the
+    // sign is iv's
+    const uint32_t aivx = (uint32_t)(r.ivx < 0 ? -r.ivx : r.ivx), aivy = (uint32_t)(r.ivy < 0 ? -r.ivy : r.ivy), aivz = (uint32_t)(r.ivz < 0 ? -r.ivz : r.ivz);
+    const int32_t sivx = r.ivx < 0 ? -1 : 0, sivy = r.ivy < 0 ? -1 : 0, sivz = r.ivz < 0 ? -1 : 0;
+    DdaRay R;
+    R.M32 = (uint32_t)r.div_m;
+    R.sh = r.div_k - 32;
+    DdaAxis wx, wy;
+    wx.K = wy.K = wx.Ksp = wy.Ksp = DDA_NEVER;
+    wx.rho = wy.rho = wx.wq = wy.wq = wx.wr = wy.wr = 0;
+    wx.D = wy.D = 1;
+    uint32_t k = DDA_NEVER; // the lane's next candidate (ray step)
+    uint32_t last_tile = 0xffffffffu; // the tile this lane has marked last
+    // (16 bytes of slack behind the voxel bytes of plane 0 and behind the tile bytes of plane 0: always zero)
+    const int64_t dummy_vox = (int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2];
+    const uint32_t dummy_tile = (uint32_t)(a.ntx * a.nty * a.ntz);
+    if (work)
+    {
+      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+      const int32_t len0 = 1 + kinit * half;
+      const uint32_t qx = dda_q(adx, len0, R), qy = dda_q(ady, len0, R);
+      dda_axis_init(wx, adx, sposx, qx, dist, res, half);
+      dda_axis_init(wy, ady, sposy, qy, dist, res, half);
+      k = min(wx.K, wy.K);
+      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71): a candidate of its own in front
+      if (k0 == 0 && (div_res(sposx + (int32_t)qx, f) != 0 || div_res(sposy + (int32_t)qy, f) != 0)) k = 0;
+    }
+    // One step of the walk: request the voxel byte of the lane's next candidate into `req`, THEN finish the candidate in `fin`
+    // (requested one step earlier: its byte has had a whole step), then move on to the next column change.
+    // gfx950 retires loads and stores in order behind one counter, and the compiler can only wait for "all but the N youngest"
+    // when N is the same on every path: so every step issues exactly one load and two stores -- a lane with nothing to store
+    // stores a zero into the slack behind its plane -- and the wait for fin's byte leaves this step's load and the previous
+    // step's stores in flight.  (With the stores under branches every wait was a wait for everything: the voxel store's
+    // acknowledgement and the next byte's round trip, one after the other, every iteration -- 55 % of the waves' time by
+    // SQ_WAIT_ANY.)  The loop below runs the step twice per trip with the two slots exchanged, so that a byte in flight is
+    // never copied from one register to another (a copy is a use: the wait would come right behind the load).
+    auto step = [&](auto special, FreePending &req, FreePending &fin) {
+      const bool active = k < (uint32_t)k1;
+      // ---- the sample's position (update_tsdf.cu:69) and its single on-ray target (:103-112 with iter_steps == 1)
+      const int32_t len = 1 + (int32_t)k * half;
+      const int32_t ax = sposx + (int32_t)dda_q(adx, len, R), ay = sposy + (int32_t)dda_q(ady, len, R), az = sposz + (int32_t)dda_q(adz, len, R);
+      const uint32_t dz = (uint32_t)(DZ_PER_DISTANCE * len) >> 15; // no fan in the free-space part: dz * 2 < res
+      const int32_t c0x = (int32_t)(((dz * aivx) >> 15) ^ (uint32_t)sivx) - sivx, c0y = (int32_t)(((dz * aivy) >> 15) ^ (uint32_t)sivy) - sivy,
+                    c0z = (int32_t)(((dz * aivz) >> 15) ^ (uint32_t)sivz) - sivz;
+      const int32_t ex = ((ax ^ smx) - smx) - c0x, ey = ((ay ^ smy) - smy) - c0y, ez = ((az ^ smz) - smz) - c0z;
+#if WS_FREE_STATIC
+      free_request(a, f, req, active, ix, (int32_t)k, div_res(ex, f), div_res(ey, f), div_res(ez, f));
+      // ---- the candidate of the step before
+      {
+        const uint32_t b = fin.b;
+        if (__ballot(fin.valid && (b & VOX_KEYED)))
+          free_finish<true, false, false>(a, fin, n_keyed, fblock); // (rare: the candidate joins the tile's records)
+        const bool fresh = fin.valid && b == 0;
+        a.vstate[fresh ? fin.idx : dummy_vox] = fresh ? VOX_TOUCHED : (uint8_t)0;
+        // the byte that tells the resolve about a tile WITHOUT records: a lane stays in a tile (4 x 4 columns) for several
+        // candidates and marks it when it enters it (marking a tile that turns out to be listed is harmless: the resolve's
+        // scan ignores listed tiles)
+        const bool mark = fin.valid && fin.tile != last_tile;
+        a.tile_dirty[mark ? fin.tile : dummy_tile] = mark ? (uint8_t)1 : (uint8_t)0;
+        last_tile = mark ? fin.tile : last_tile;
+      }
+#else
+      // (one slot: finish the candidate whose byte the previous step requested, then request this one's)
+      free_finish<true, true>(a, req, n_keyed, fblock);
+      free_request(a, f, req, active, ix, (int32_t)k, div_res(ex, f), div_res(ey, f), div_res(ez, f));
+#endif
+      // ---- on to the next column change
+      const bool cx = active && wx.K == k, cy = active && wy.K == k;
+      if (cx)
+      {
+        const bool sp = decltype(special)::value && wx.Ksp == k;
+        dda_axis_advance(wx);
+        if (decltype(special)::value && sp) dda_axis_after_zero_cell(wx, adx, sposx, dist, res);
+      }
+      if (cy)
+      {
+        const bool sp = decltype(special)::value && wy.Ksp == k;
+        dda_axis_advance(wy);
+        if (decltype(special)::value && sp) dda_axis_after_zero_cell(wy, ady, sposy, dist, res);
+      }
+      if (active) k = min(wx.K, wy.K);
+    };
+    FreePending pend2 = pend;
+    auto walk = [&](auto special) {
+      while (__any(k < (uint32_t)k1))
+      {
+#if WS_FREE_STATIC
+        step(special, pend2, pend);
+        step(special, pend, pend2); // (a lane that is through takes part without a candidate)
+#else
+        step(special, pend, pend2);
+#endif
+      }
+    };
+    // (a ray that crosses the cell around zero -- the one cell that is 2 res - 1 wide -- needs a look at every crossing: a
+    // loop of its own for the waves that hold such a ray)
+    if (__any(work && (wx.Ksp != DDA_NEVER || wy.Ksp != DDA_NEVER)))
+      walk(std::true_type{});
+    else
+      walk(std::false_type{});
+    // (after a pair of steps only `pend` holds a candidate that is not finished)
+    free_finish<true, true>(a, pend, n_keyed, fblock);
+  }
+#else
   else if (__any(work))
   {
     // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
@@ -1380,6 +1526,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     while (qtail != qhead) emit();
     free_finish<true>(a, pend, n_keyed, fblock);
   }
+#endif
   // statistics: free-space candidates that became records
   for (int d = 32; d > 0; d >>= 1) n_keyed += __shfl_down(n_keyed, d, 64);
   if (lane == 0) s_keyed[threadIdx.x >> 6] = n_keyed;
