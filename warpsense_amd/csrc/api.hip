@@ -322,8 +322,8 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   // 16 bytes of slack: the tile kernels read the four voxels of a column as one access, also at the very end
   TRY(hipMalloc((void **)&m->data[0], map_bytes + 16));
   TRY(hipMalloc((void **)&m->data[1], map_bytes + 16));
-  TRY(hipMalloc((void **)&m->vstate, 2 * vstate_plane_bytes(m->n_vox)));
-  TRY(hipMemsetAsync(m->vstate, 0, 2 * vstate_plane_bytes(m->n_vox), s));
+  TRY(hipMalloc((void **)&m->vstate, 2 * vstate_plane_bytes(m->n_tiles)));
+  TRY(hipMemsetAsync(m->vstate, 0, 2 * vstate_plane_bytes(m->n_tiles), s));
   TRY(hipMalloc((void **)&m->rays, MAX_SCAN_POINTS * ray_setup_bytes()));
   TRY(hipMalloc((void **)&m->az_hist, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));

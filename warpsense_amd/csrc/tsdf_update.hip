@@ -898,23 +898,23 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   // ---- phase 1: march, one record per scatter target
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, a.tau, a.map);
   const bool mark = !a.all_keyed;
-  uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
+  uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.ntx * a.nty * a.ntz);
   // a record (sx, sy, sz: storage coordinates of its voxel); returns the voxel's tile
   auto put_record = [&](uint32_t rix, int32_t k, int32_t fan_minus_mid, int32_t value, int32_t sx, int32_t sy, int32_t sz, uint32_t &used) -> uint32_t {
     // the free-space pass must know that this voxel takes part in the key order
     // (as a non-temporal store -- the marks push the half-filled sub-chunk lines out of the L2: 380 MB of writes for 98 MB of
     // records -- the kernel takes 462 instead of 183 us)
-    if (mark) a.vstate[storage_index(a.map, sx, sy, sz)] = VOX_KEYED;
-    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz)));
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), local = local_of(sx, sy, sz);
+    if (mark) a.vstate[((size_t)tile << 10) + vbrick(local)] = VOX_KEYED;
+    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
   auto mark_negative = [&](int32_t sx, int32_t sy, int32_t sz, uint32_t listed_tile) {
-    vneg[storage_index(a.map, sx, sy, sz)] = 1;
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
+    vneg[((size_t)tile << 10) + vbrick(local_of(sx, sy, sz))] = 1;
     // (the tile of the sample's on-ray record is on the list through that record -- nearly always this tile too; any other gets
     // the byte the resolve scans for.  A blind store: a load here would be a wait for everything the wave has in flight.)
-    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
     if (tile != listed_tile) a.tile_dirty[tile] = 1;
   };
 
@@ -1152,9 +1152,9 @@ __device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFr
   const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
                 sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
   p.valid = valid;
-  p.idx = valid ? storage_index(a.map, sx, sy, sz) : 0; // unconditional (clamped) load: nothing waits for it here
   p.tile = tile_of(a.nty, a.ntz, sx, sy, sz);
   p.local = local_of(sx, sy, sz);
+  p.idx = valid ? (int64_t)(((uint64_t)p.tile << 10) + vbrick(p.local)) : 0; // unconditional (clamped) load: nothing waits for it here
   p.ix = ix;
   p.k = k;
 #if WS_FREE_KO & 4
@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     uint32_t k = DDA_NEVER; // the lane's next candidate (ray step)
     uint32_t last_tile = 0xffffffffu; // the tile this lane has marked last
     // (16 bytes of slack behind the voxel bytes of plane 0 and behind the tile bytes of plane 0: always zero)
-    const int64_t dummy_vox = (int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2];
+    const int64_t dummy_vox = (int64_t)a.ntx * a.nty * a.ntz * 1024;
     const uint32_t dummy_tile = (uint32_t)(a.ntx * a.nty * a.ntz);
     if (work)
     {
@@ -1668,6 +1668,7 @@ struct TilePost
 {
   int64_t idx0;
   int nz;
+  uint32_t tile;
   uint32_t vs;
   uint32_t touched; // bit j
   uint32_t value[4];
@@ -1712,10 +1713,11 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   const int32_t weight_epsilon = a.tau / 10;
   const uint32_t reset = pack_entry(a.tau, 0);
   const int lane = threadIdx.x & 63;
-  uint8_t *const vneg = a.vstate + vstate_plane_bytes((int64_t)a.map.size[0] * a.map.size[1] * a.map.size[2]);
+  uint8_t *const vneg = a.vstate + vstate_plane_bytes(a.n_tiles);
   // thread t owns the voxels 4t .. 4t+3 of the tile: column t >> (ZB - 2), four consecutive z
   const int col = threadIdx.x >> (TILE_ZB - 2), lx = col >> TILE_YB, ly = col & ((1 << TILE_YB) - 1), z0 = (threadIdx.x & ((1 << (TILE_ZB - 2)) - 1)) * 4;
   const int l0 = threadIdx.x * 4;
+  const uint32_t voff = vbrick((uint32_t)l0); // where the thread's four voxel bytes lie in the tile's kilobyte: one aligned word
   const uint32_t G = gridDim.x;
   uint32_t n_contested = 0;
 
@@ -1732,7 +1734,8 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     const uint32_t keep = p.nz >= 4 ? 0xffffffffu : ((1u << (8 * p.nz)) - 1u);
     p.vs = 0;
     // both byte planes of the four voxels in one register: the second plane's mark becomes bit VOX_NEGFREE of the byte
-    if (!HAS_S0) p.vs = (*reinterpret_cast<const u32_a1 *>(a.vstate + p.idx0) | ((*reinterpret_cast<const u32_a1 *>(vneg + p.idx0) & 0x01010101u) << 3)) & keep;
+    const size_t vb = ((size_t)te.tile << 10) + voff;
+    if (!HAS_S0) p.vs = (*reinterpret_cast<const uint32_t *>(a.vstate + vb) | ((*reinterpret_cast<const uint32_t *>(vneg + vb) & 0x01010101u) << 3)) & keep;
     const u32x4 z4 = {reset, reset, reset, reset};
     u32x4 s4 = z4;
     if (HAS_S0) s4 = *reinterpret_cast<const u32x4_a4 *>(a.new_data + p.idx0);
@@ -1777,12 +1780,13 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     return in_regs;
   };
   auto write_back = [&](const TilePost &w) {
+    const size_t vb = ((size_t)w.tile << 10) + voff;
     if (w.nz == 4 && !HAS_S0) // (a non-default new_map keeps the entries of its untouched voxels: voxel by voxel below)
     {
       // the thread's four voxels as ONE access per array (byte stores are a transaction each: 14 M of them per scan were
       // most of this kernel's write traffic)
-      if (w.vs & 0x07070707u) *reinterpret_cast<u32_a1 *>(a.vstate + w.idx0) = 0;
-      if (w.vs & 0x08080808u) *reinterpret_cast<u32_a1 *>(vneg + w.idx0) = 0;
+      if (w.vs & 0x07070707u) *reinterpret_cast<uint32_t *>(a.vstate + vb) = 0;
+      if (w.vs & 0x08080808u) *reinterpret_cast<uint32_t *>(vneg + vb) = 0;
       if (w.touched == 0 || aborted) return;
       u32x4 out;
       if (FUSED)
@@ -1806,8 +1810,8 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     for (int j = 0; j < 4; ++j)
     {
       if (j >= w.nz) continue;
-      if (!HAS_S0 && ((w.vs >> (8 * j)) & (0xffu & ~(uint32_t)VOX_NEGFREE))) a.vstate[w.idx0 + j] = 0;
-      if (!HAS_S0 && ((w.vs >> (8 * j)) & VOX_NEGFREE)) vneg[w.idx0 + j] = 0;
+      if (!HAS_S0 && ((w.vs >> (8 * j)) & (0xffu & ~(uint32_t)VOX_NEGFREE))) a.vstate[vb + j] = 0;
+      if (!HAS_S0 && ((w.vs >> (8 * j)) & VOX_NEGFREE)) vneg[vb + j] = 0;
       if (!(w.touched & (1u << j)) || aborted) continue;
       if (FUSED)
       {
@@ -1892,6 +1896,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   TilePost post;
   post.nz = 0;
   post.idx0 = 0;
+  post.tile = 0;
   post.vs = post.touched = 0;
   if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
   init_lds();
@@ -2129,6 +2134,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     // ---- this tile's result waits in registers until the next iteration's loads have arrived
     post.idx0 = idx0;
     post.nz = nz;
+    post.tile = tile;
     post.vs = p.vs;
     post.touched = touched;
 #pragma unroll
@@ -2193,12 +2199,14 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         nz = !col_ok ? 0 : (nz > 4 ? 4 : (nz < 0 ? 0 : nz));
         const int64_t idx0 = nz ? storage_index(a.map, sx, sy, sz) : 0;
         const uint32_t keep = nz >= 4 ? 0xffffffffu : ((1u << (8 * nz)) - 1u);
-        const uint32_t vs4 = (*reinterpret_cast<const u32_a1 *>(a.vstate + idx0) | ((*reinterpret_cast<const u32_a1 *>(vneg + idx0) & 0x01010101u) << 3)) & keep;
+        const size_t vb = ((size_t)tile << 10) + voff;
+        const uint32_t vs4 = (*reinterpret_cast<const uint32_t *>(a.vstate + vb) | ((*reinterpret_cast<const uint32_t *>(vneg + vb) & 0x01010101u) << 3)) & keep;
         u32x4 ex = {0, 0, 0, 0};
         if (FUSED) ex = *reinterpret_cast<const u32x4_a4 *>(a.avg_data + idx0);
         TilePost w;
         w.idx0 = idx0;
         w.nz = nz;
+        w.tile = tile;
         w.vs = vs4;
         w.touched = 0;
         w.existing[0] = ex.x; w.existing[1] = ex.y; w.existing[2] = ex.z; w.existing[3] = ex.w;

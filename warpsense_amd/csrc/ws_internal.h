@@ -34,7 +34,17 @@ constexpr int TILE_VOXELS = 1 << (TILE_XB + TILE_YB + TILE_ZB); // 1024
 constexpr uint64_t KEY_INF = ~0ull;
 // the voxel bytes are two planes in one allocation: [0] keyed / touched / free-space hit (VOX_*), [1] "an off-ray free-space
 // candidate (tau, -weight) landed here" (blind, idempotent byte stores of the free pass)
-__host__ __device__ inline size_t vstate_plane_bytes(int64_t n_vox) { return ((size_t)n_vox + 16 + 255) & ~(size_t)255; }
+// Where a voxel's byte lives: tile-major, and inside a tile in BRICKS of 4 x 4 x 8 voxels (128 bytes, z fastest inside a brick,
+// the eight bricks of a tile one after the other): byte = tile * 1024 + vbrick(voxel in tile).  Rays of a LiDAR ring sweep
+// horizontally: with one byte per voxel in the maps' own z-fastest order every voxel column is a cache line of its own and a
+// wave's 64 candidates are 64 lines (2.3 CU-cycles each from the L2, 9 from beyond: tools/ta_bench.hip -- round 5's free pass,
+// 28 % fewer instructions than round 4's, took the same 118 us because of them); in bricks horizontal neighbours share lines,
+// a ray stays in a brick for four column changes, and a tile's bytes are ONE contiguous kilobyte for the resolve.
+__host__ __device__ inline size_t vstate_plane_bytes(int64_t n_tiles) { return ((size_t)n_tiles * 1024u + 16 + 255) & ~(size_t)255; }
+__host__ __device__ inline uint32_t vbrick(uint32_t local /* lx(2) ly(2) lz(6), local_of() */)
+{
+  return ((local & 0x38u) << 4) | ((local >> 3) & 0x78u) | (local & 7u);
+}
 constexpr uint32_t WS_TAIL_STATS = 65536; // per-workgroup slots of the tail march: records, flush groups (1 000 000 points / 64 rays x up to 2 workgroups), then 2 per resolve workgroup
 constexpr uint32_t WS_BLOCK_STATS = 2 * WS_TAIL_STATS + 2 * 4096 + WS_TAIL_STATS; // (+ start ticks per tail workgroup of a -DWS_TAIL_TIMING build)
 
@@ -161,7 +171,7 @@ struct ws_map
   ws::MapParams par[2]; // [WS_MAP_AVG], [WS_MAP_NEW]
   int64_t n_vox = 0;
   uint32_t *data[2] = {nullptr, nullptr};
-  uint8_t *vstate = nullptr; // two planes of one byte per voxel (vstate_plane_bytes): keyed / touched by free space / free-space hit on a keyed voxel; off-ray free-space hit
+  uint8_t *vstate = nullptr; // two planes of one byte per voxel, tile-major in bricks (vstate_plane_bytes, vbrick): keyed / touched by free space / free-space hit on a keyed voxel; off-ray free-space hit
   void *rays = nullptr;      // per-ray set-up records (sizeof(RaySetup) x 1 000 000)
   uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
   void *ray_bin = nullptr;   // [1 000 000] uint2: (direction bin, rank inside the bin) per ray
