@@ -98,6 +98,14 @@ static void copy3(int32_t dst[3], const int32_t src[3])
 size_t reg_partials_bytes();
 } // namespace ws
 static int ctx_take_errors(ws_context *ctx);
+// every entry point that takes a map looks at the verdict of the scan in flight first (settle_tsdf, tsdf_update.hip)
+#define WS_SETTLE(map_ptr)                                                   \
+  do                                                                         \
+  {                                                                          \
+    const int rc_settle__ = ws::settle_tsdf(const_cast<ws_map *>(map_ptr));  \
+    if (rc_settle__ != WS_OK) return rc_settle__;                            \
+  } while (0)
+
 namespace ws
 {
 constexpr size_t AZ_ALLOC = 1024 * 64 + 8; // direction-bin histogram / offsets (tsdf_update.hip: AZ_BINS + 2 entries)
@@ -164,6 +172,11 @@ int ws_ctx_set_stream(ws_context *ctx, void *hip_stream)
 int ws_sync(ws_context *ctx)
 {
   if (!ctx) return invalid("ws_sync: ctx is NULL");
+  for (ws_map *m : ctx->maps)
+  {
+    const int rc = settle_tsdf(m); // (an aborted scan is repeated before the stream is drained)
+    if (rc != WS_OK) return rc;
+  }
   WS_HIP(hipStreamSynchronize(ctx->stream));
   return ctx_take_errors(ctx);
 }
@@ -389,6 +402,7 @@ int ws_map_destroy(ws_map *map) { return map_free(map); }
 int ws_map_set_params(ws_map *m, int which, const int32_t size[3], const int32_t pos[3], const int32_t offset[3])
 {
   if (!m || !size || !pos || !offset || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("ws_map_set_params: bad argument");
+  WS_SETTLE(m);
   if ((int64_t)size[0] * size[1] * size[2] != m->n_vox) return invalid("ws_map_set_params: voxel count differs from the allocation");
   // parameters are kernel arguments: order against work already enqueued is automatic
   copy3(m->par[which].size, size);
@@ -412,6 +426,7 @@ int ws_map_upload(ws_map *m, int which, const int32_t size[3], const int32_t pos
 int ws_map_download(ws_map *m, int which, int32_t size[3], int32_t pos[3], int32_t offset[3], uint32_t *host_data)
 {
   if (!m || (which != WS_MAP_AVG && which != WS_MAP_NEW)) return invalid("ws_map_download: bad argument");
+  WS_SETTLE(m);
   if (size) copy3(size, m->par[which].size);
   if (pos) copy3(pos, m->par[which].pos);
   if (offset) copy3(offset, m->par[which].offset);
@@ -453,6 +468,7 @@ static int box_check(ws_map *m, int which, const int32_t lo[3], const int32_t hi
 int ws_map_extract_box(ws_map *m, int which, const int32_t lo[3], const int32_t hi[3], uint32_t *host_out)
 {
   if (!host_out) return invalid("ws_map_extract_box: host_out is NULL");
+  WS_SETTLE(m);
   int32_t ext[3];
   size_t n = 0;
   int rc = box_check(m, which, lo, hi, ext, &n);
@@ -467,6 +483,7 @@ int ws_map_extract_box(ws_map *m, int which, const int32_t lo[3], const int32_t 
 int ws_map_insert_box(ws_map *m, int which, const int32_t lo[3], const int32_t hi[3], const uint32_t *host_in)
 {
   if (!host_in) return invalid("ws_map_insert_box: host_in is NULL");
+  WS_SETTLE(m);
   int32_t ext[3];
   size_t n = 0;
   int rc = box_check(m, which, lo, hi, ext, &n);
@@ -508,6 +525,7 @@ int ws_shift_reserve(ws_map *m, uint64_t voxels)
 int ws_shift_begin(ws_map *m, const int32_t new_pos[3], uint32_t fill_entry, ws_shift **out)
 {
   if (!m || !new_pos || !out) return invalid("ws_shift_begin: NULL argument");
+  WS_SETTLE(m);
   if (m->shift_open) return invalid("ws_shift_begin: the previous shift of this map has not been ended (ws_shift_end)");
   // only new_map's WINDOW moves here, which is right iff it holds (tau, 0) everywhere -- not between ws_tsdf_scatter_dev and
   // ws_tsdf_integrate, nor for a map created from non-default host data that has not been integrated yet
@@ -664,6 +682,7 @@ int64_t ws_map_n_voxels(const ws_map *m) { return m ? m->n_vox : 0; }
 // ------------------------------------------------------------------ TSDF update
 int ws_tsdf_set_integrate(ws_map *m, int mode)
 {
+  if (m) WS_SETTLE(m);
   if (!m || (mode != WS_INTEGRATE_SPARSE && mode != WS_INTEGRATE_DENSE && mode != WS_INTEGRATE_SPARSE_SEPARATE))
     return invalid("ws_tsdf_set_integrate: bad argument");
   m->integrate_mode = mode;
@@ -673,6 +692,7 @@ int ws_tsdf_set_integrate(ws_map *m, int mode)
 int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 {
   if (!m) return invalid("ws_tsdf_set_capacity: map is NULL");
+  WS_SETTLE(m);
   WS_HIP(hipStreamSynchronize(m->ctx->stream));
   return map_alloc_records(m, (records + SUB_RECS - 1) / SUB_RECS);
 }
@@ -680,6 +700,7 @@ int ws_tsdf_set_capacity(ws_map *m, uint64_t records)
 int ws_debug_tsdf_chunk_policy(ws_map *m, uint64_t budget_bytes, uint32_t est_shift)
 {
   if (!m) return invalid("ws_debug_tsdf_chunk_policy: map is NULL");
+  WS_SETTLE(m);
   m->chunk_budget_bytes = budget_bytes;
   m->est_shift = est_shift;
   return WS_OK;
@@ -706,6 +727,8 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 int ws_tsdf_integrate(ws_map *m)
 {
   if (!m) return invalid("ws_tsdf_integrate: map is NULL");
+  const int rc0 = settle_tsdf(m);
+  if (rc0 != WS_OK) return rc0;
   return launch_tsdf_integrate(m);
 }
 
@@ -719,6 +742,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
   prof_begin(m->ctx, WS_K_UPDATE);
   rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
   if (rc == WS_OK) rc = launch_tsdf_integrate(m);
+  if (m->pending.active) m->pending.integrate_after = true; // (what a repeat of this scan has to be followed by)
   prof_end(m->ctx, WS_K_UPDATE);
   return rc;
 }
@@ -739,6 +763,8 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
 {
   if (!m || !out) return invalid("ws_tsdf_stats: NULL argument");
   {
+    const int rcs = settle_tsdf(m);
+    if (rcs != WS_OK) return rcs;
     const int rc0 = launch_tsdf_stats(m);
     if (rc0 != WS_OK) return rc0;
   }
@@ -856,6 +882,7 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
                    int32_t *e, int32_t *c)
 {
   if (!r || !m || !T || !h || !g || !e || !c) return invalid("ws_reg_iterate: NULL argument");
+  WS_SETTLE(m);
   if (res < 1) return invalid("ws_reg_iterate: map_resolution must be positive");
   hipStream_t s = r->ctx->stream;
   WS_HIP(hipMemcpyAsync(r->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, s)); // registration.cu:351
@@ -895,6 +922,7 @@ int ws_reg_begin(ws_reg *r, const float T_in[16], int32_t max_iterations, float 
 int ws_reg_accumulate_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev)
 {
   if (!r || !m || !sums_dev) return invalid("ws_reg_accumulate_dev: NULL argument");
+  WS_SETTLE(m);
   return launch_reg_accumulate(r, m, nullptr, res, flags, first, count, sums_dev);
 }
 
@@ -902,6 +930,7 @@ int ws_reg_iterate_shard_dev(ws_reg *r, const ws_map *m, int32_t res, uint32_t f
                              int32_t apply_previous)
 {
   if (!r || !m || !sums_dev) return invalid("ws_reg_iterate_shard_dev: NULL argument");
+  WS_SETTLE(m);
   return launch_reg_shard(r, m, res, flags, first, count, sums_dev, apply_previous);
 }
 
@@ -945,6 +974,7 @@ int ws_register_cloud(ws_reg *r, const ws_map *m, const float T_in[16], int32_t 
                       float epsilon, int32_t res, uint32_t flags, float T_out[16], int32_t *iterations)
 {
   if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud: NULL argument");
+  WS_SETTLE(m);
   if (res < 1) return invalid("ws_register_cloud: map_resolution must be positive");
   if (r->loop_mode == WS_REG_LOOP_RESIDENT && r->loop_supported)
   {
@@ -1122,6 +1152,7 @@ int ws_register_cloud_peers(ws_reg *r, const ws_map *m, size_t first, size_t cou
                             float it_weight_gradient, float epsilon, int32_t res, uint32_t flags, float T_out[16], int32_t *iterations)
 {
   if (!r || !m || !T_in || !T_out) return invalid("ws_register_cloud_peers: NULL argument");
+  WS_SETTLE(m);
   if (!r->peer_world) return invalid("ws_register_cloud_peers: ws_reg_peer_connect first");
   // An exchange that was given up leaves partial additions in the mailboxes and no saved snapshot: a rank's stale addition
   // plus its next one would reach count == world and pass for the all-rank total.  Nothing runs until the mailboxes are fresh.
@@ -1166,6 +1197,7 @@ int ws_reg_set_loop(ws_reg *r, int mode)
 int ws_debug_block_stats(ws_map *m, uint32_t *out, size_t words)
 {
   if (!m || !out) return invalid("ws_debug_block_stats: NULL argument");
+  WS_SETTLE(m);
   if (words > WS_BLOCK_STATS) words = WS_BLOCK_STATS;
   WS_HIP(hipMemcpyAsync(out, m->block_stats, words * sizeof(uint32_t), hipMemcpyDeviceToHost, m->ctx->stream));
   WS_HIP(hipStreamSynchronize(m->ctx->stream));

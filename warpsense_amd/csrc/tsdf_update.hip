@@ -2525,21 +2525,11 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res)
 
 uint64_t subs_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points) { return subs_needed(need_records, m->est_shift, n_points); }
 
-int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
+// one attempt of the scatter: every kernel enqueued, nothing waited for
+static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused, uint32_t *seq_out)
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
-  m->fused_done = false;
-  m->tail_blocks = 0;
-  if (n == 0)
-  {
-    m->resolve_blocks = 0;
-    // nothing listed: a following integrate pass has nothing to do
-    WS_HIP(hipMemsetAsync(&m->counters->n_listed, 0, sizeof(uint32_t), s));
-    WS_HIP(hipMemsetAsync(&m->counters->n_appended, 0, sizeof(uint32_t), s));
-    return WS_OK;
-  }
-
   const bool s0 = !m->new_is_default;
   // the (tile, entry) hash keeps the keys of released tiles: empty it before it fills up
   if (m->status_host[10] > m->big_slots / 4) m->prepped = false;
@@ -2592,10 +2582,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   const dim3 grid_tail((unsigned)((n + 63) / 64) * TAIL_SPLIT);
   const dim3 grid_free((unsigned)((n + 256 / FREE_LANES - 1) / (256 / FREE_LANES)));
   m->tail_blocks = grid_tail.x;
-
   const bool fuse = fused && !s0;
-  for (int attempt = 0;; ++attempt)
-  {
   prof_begin(ctx, WS_K_SETUP);
   // normally the kernels of the previous update have left their scratch zero / empty on their way (m->prepped)
   if (!m->prepped)
@@ -2653,61 +2640,114 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   else
     hipLaunchKernelGGL((tile_resolve_kernel<false, false>), dim3(RESOLVE_GRID), block, 0, s, ra);
   prof_end(ctx, WS_K_TILE_RESOLVE);
-  // The pool of sub-chunks is sized by estimate (subs_needed): a scan that exhausts it raises the abort flag, the resolve
-  // -- which is enqueued already -- then only puts the scratch back and writes nothing to the maps, and this call repeats the
-  // scan with a larger pool: never an inexact map.  The verdict is there when the resolve starts, ~0.4 ms into the update
-  // (host-mapped memory: the flag, then the sequence number the host spins on); the resolve itself runs while the caller
-  // enqueues what comes next.  (Everything above was enqueued without waiting for anything: the device runs the update back
-  // to back.)
+  m->fused_done = fuse;
+  m->prepped = true; // every kernel above has put back what it consumed
+  *seq_out = sa.scan_seq;
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+// The pool of sub-chunks is sized by estimate (subs_needed): a scan that exhausts it raises the abort flag, the resolve --
+// which is enqueued already -- then only puts the scratch back and writes nothing to the maps, and the scan is repeated with
+// a larger pool: never an inexact map.  The verdict is in host-mapped memory when the resolve starts, ~0.35 ms after the
+// launches (the flag, then the sequence number).  Round 4 waited for it inside ws_tsdf_update*; now the update returns after
+// the launches -- like the reference's (update_tsdf.cu:165) -- and whoever takes the map next looks first: ws_register_cloud,
+// ws_reg_iterate, ws_sync, the downloads, the next update.  By then the word is there; an aborted scan is repeated from the
+// arguments kept in ws_map::pending before the caller's own work is enqueued.  (Paced at the sensor's 10 Hz the round-4 wait
+// cost the callback 1.3 ms of its 3.5: the GPU runs the marches at idle clocks there.)
+int settle_tsdf(ws_map *m)
+{
+  if (!m || !m->pending.active) return WS_OK;
+  ws_context *ctx = m->ctx;
+  hipStream_t s = ctx->stream;
+  volatile uint32_t *st = m->status_host;
+  for (;;)
   {
-    volatile uint32_t *st = m->status_host;
-    auto wait_word = [&](int word, const char *what) -> int {
-      const auto t0 = std::chrono::steady_clock::now();
-      uint32_t spins = 0;
-      while (st[word] != sa.scan_seq)
+    const uint32_t seq = m->pending.seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (st[8] != seq)
+    {
+      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
       {
-        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50))
+        WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
+        if (st[8] != seq)
         {
-          WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
-          if (st[word] != sa.scan_seq)
-          {
-            set_error(what);
-            return WS_ERR_INTERNAL;
-          }
+          m->pending.active = false;
+          set_error("TSDF update: the resolve did not report the end of the marches");
+          return WS_ERR_INTERNAL;
         }
       }
-      std::atomic_thread_fence(std::memory_order_acquire);
-      return WS_OK;
-    };
-    int rc = wait_word(8, "TSDF update: the resolve did not report the end of the marches");
-    if (rc != WS_OK) return rc;
-    if (st[9] == 0) break; // the normal case
-    if (attempt >= 8)
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (st[9] == 0)
     {
+      m->pending.active = false; // the normal case
+      return WS_OK;
+    }
+    if (++m->pending.attempts > 8)
+    {
+      m->pending.active = false;
       set_error("TSDF update: the scan did not fit the record pool it had just been given");
       return WS_ERR_INTERNAL;
     }
     const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4) & ((1ull << 48) - 1ull);
-    uint64_t grow_to = subs_for_scan(m, need, n);
+    uint64_t grow_to = subs_for_scan(m, need, m->pending.n);
     if (grow_to < (uint64_t)m->sub_cap * 2) grow_to = (uint64_t)m->sub_cap * 2;
     if (grow_to > SUB_ID_LIMIT)
     {
+      m->pending.active = false;
       set_error("TSDF update: the scan needs more than 2^27 record sub-chunks");
       return WS_ERR_CAPACITY;
     }
-    rc = resize_records(m, grow_to); // (waits for the stream: the aborted update has drained and put its scratch back)
-    if (rc != WS_OK) return rc;
-    sa.rec = m->rec;
-    sa.sub_cap = m->sub_cap;
-    sa.big_keys = m->big_keys;
-    sa.big_mask = m->big_slots - 1;
-    sa.scan_seq = ++m->scan_seq;
-    // (resize_records leaves prepped == false: the new hash is filled by the preparation pass; the tile tables are zero already)
+    // (waits for the stream: the aborted update has drained and put its scratch back; leaves prepped == false: the new hash is
+    // filled by the preparation pass, the tile tables are zero already)
+    int rc = resize_records(m, grow_to);
+    if (rc == WS_OK) rc = enqueue_scatter(m, m->pending.xyz, m->pending.n, m->pending.pos, m->pending.up, m->pending.fused, &m->pending.seq);
+    if (rc == WS_OK && m->pending.integrate_after) rc = launch_tsdf_integrate(m);
+    if (rc != WS_OK)
+    {
+      m->pending.active = false;
+      return rc;
+    }
   }
-  } // attempts
-  m->fused_done = fuse;
-  m->prepped = true; // every kernel above has put back what it consumed
-  WS_HIP(hipGetLastError());
+}
+
+int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused)
+{
+  // (one scan in flight per map: its pool and its verdict words are the map's)
+  int rc = settle_tsdf(m);
+  if (rc != WS_OK) return rc;
+  ws_context *ctx = m->ctx;
+  hipStream_t s = ctx->stream;
+  m->fused_done = false;
+  m->tail_blocks = 0;
+  if (n == 0)
+  {
+    m->resolve_blocks = 0;
+    // nothing listed: a following integrate pass has nothing to do
+    WS_HIP(hipMemsetAsync(&m->counters->n_listed, 0, sizeof(uint32_t), s));
+    WS_HIP(hipMemsetAsync(&m->counters->n_appended, 0, sizeof(uint32_t), s));
+    return WS_OK;
+  }
+  uint32_t seq = 0;
+  rc = enqueue_scatter(m, xyz_dev, n, scanner_pos, up, fused, &seq);
+  if (rc != WS_OK) return rc;
+  m->pending.active = true;
+  m->pending.seq = seq;
+  m->pending.xyz = xyz_dev;
+  m->pending.n = n;
+  for (int k = 0; k < 3; ++k)
+  {
+    m->pending.pos[k] = scanner_pos[k];
+    m->pending.up[k] = up[k];
+  }
+  m->pending.fused = fused;
+  m->pending.integrate_after = false;
+  m->pending.attempts = 0;
+  // A scan into a NON-default new_map (the first update after a map came from the host, update_tsdf.cu:135-136) is settled here:
+  // the dense integrate that follows consumes new_map's stored entries, and must not run on the leftovers of an aborted scan.
+  if (!m->new_is_default) return settle_tsdf(m);
   return WS_OK;
 }
 

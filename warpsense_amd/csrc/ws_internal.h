@@ -210,6 +210,20 @@ struct ws_map
   uint32_t *box_stage = nullptr; // device staging for ws_map_extract_box / ws_map_insert_box
   size_t box_stage_cap = 0;
   uint32_t last_error_bits = 0;  // device error bits already taken from status_host, not yet shown by ws_tsdf_stats
+  // The scan whose verdict (did its records fit the pool?) has not been looked at yet: ws_tsdf_update* return after the
+  // launches, like the reference's update_tsdf (update_tsdf.cu:165); the next call that takes this map settles it first
+  // (settle_tsdf: the verdict is in host-mapped memory ~0.35 ms after the launches) and repeats the scan if it was aborted.
+  struct PendingScan
+  {
+    bool active = false;
+    uint32_t seq = 0;
+    const int32_t *xyz = nullptr; // must stay unchanged until the scan is settled (ws_tsdf_update copies host scans into scan_dev)
+    size_t n = 0;
+    int32_t pos[3] = {0, 0, 0}, up[3] = {0, 0, 0};
+    bool fused = false;
+    bool integrate_after = false; // ws_tsdf_update*: an integrate pass follows the scatter
+    int attempts = 0;
+  } pending;
   hipStream_t shift_stream = nullptr; // second stream for asynchronous slab transfers (map shift off the scan path)
   hipEvent_t shift_event = nullptr;
   uint32_t *shift_stage_dev = nullptr;  // packed leaving slabs
@@ -301,6 +315,7 @@ void prof_end(ws_context *ctx, int cls);
 // launchers implemented in the .hip files
 void fill_fan_steps(int32_t *fan_steps, int32_t res);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
+int settle_tsdf(ws_map *m); // the verdict of the scan in flight (repeats an aborted scan); every entry point that takes a map calls it first
 size_t ray_setup_bytes();
 int launch_scatter_prep(ws_map *m);
 int resize_records(ws_map *m, uint64_t sub_chunks); // api.hip: (re)allocate the pool (waits for the stream)
