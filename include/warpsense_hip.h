@@ -49,8 +49,9 @@ typedef enum
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
   WS_ERR_CAPACITY = -4,    /* returned at once by ws_tsdf_update* for a scan that needs more than 2^27 record sub-chunks (the record
                               pool itself cannot overflow: a scan that exhausts it is repeated with a larger one) */
-  WS_ERR_RANGE = -5,       /* ray of more than 8192 steps or 31 fan steps: outside the record's fields; the
-                              ray was dropped (sticky)                                                                */
+  WS_ERR_RANGE = -5,       /* a ray with more ray steps / fan steps than the record's key holds for a scan of that many points: 65 536
+                              steps and 255 fan steps up to 2^14 points, 32 768 / 63 for the reference's 131 072-point scans, 8192 / 31
+                              for the 1 000 000-point maximum; the ray was dropped (sticky)                 */
   WS_ERR_TIMEOUT = -6,     /* ws_register_cloud_peers: a peer rank did not deliver (ws_register_cloud itself retries with one
                               launch per iteration instead of returning this) */
   WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
@@ -146,7 +147,10 @@ int64_t ws_map_n_voxels(const ws_map *map);
  * xyz_host: n x 3 int32 (rmagine::Pointi AoS); scanner_pos in voxel units, up scaled by 32768.
  * Returns after enqueueing, like the reference (no device sync). */
 int ws_tsdf_update(ws_map *map, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
-/* same with the scan already resident in HBM (no H2D copy) */
+/* same with the scan already resident in HBM (no H2D copy).  Asynchronous like a stream copy: xyz_dev must stay unchanged until
+ * the next call that takes this map -- ws_register_cloud, ws_reg_iterate, ws_sync, a download, the next update -- has returned
+ * (that call looks at the scan's verdict first and repeats the scan with a larger record pool in the rare case that it did
+ * not fit: never an inexact map).  ws_tsdf_update copies host scans into a buffer of the map, so it has no such condition. */
 int ws_tsdf_update_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
 /* only the scatter (cu_min_tsdf_krnl, update_tsdf.cu:45-128): fills new_map, no integrate. For parity tests. */
 int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);

@@ -423,15 +423,33 @@ def test_a_scan_that_runs_out_of_chunks_is_aborted_and_repeated():
     assert st["records"] > cap0 // 2
 
 
+def test_long_rays_with_wide_fans_take_the_scans_own_key_split():
+    """until round 5 a ray of more than 8 192 steps or 31 fan steps was dropped (WS_ERR_RANGE) -- the reference
+    marches it (update_tsdf.cu:67,107-125).  The record's 38 key bits are now shared out per scan (rec_format, ws_internal.h): a
+    scan of a few rays admits 65 536 steps and 255 fan steps.  Rays of 23 000 steps at res 2 mm (1 mm per step) with fans up to
+    71 wide, sensor 20 m outside the window: bit-exact against the oracle, no error."""
+    torch = _torch()
+    tau, res, mw = 3000, 2, 640
+    view, t, oa, on = _pair_at((64, 64, 64), tau, res, mw, (0, 0, 0), (32, 32, 32))
+    pts = np.array([[60, 0, 0], [0, 61, 3], [-40, 10, -20], [33, -47, 9]], dtype=np.int32)
+    O.update_tsdf(oa, on, pts, (-10000, 0, 0), (0, 0, 32768), tau, mw, res)
+    t.update_tsdf(torch.from_numpy(pts).cuda(), (-10000, 0, 0), (0, 0, 32768))
+    t.ctx.sync()
+    got = _download_view(t, view, 0)
+    assert np.array_equal(got, oa.data)
+    assert int(np.count_nonzero(got != O.pack(tau, 0))) > 1000
+    assert t.stats()["error_flags"] == 0
+
+
 def test_ray_beyond_the_key_range_is_reported():
-    """a ray of more than 8 192 steps cannot be ordered by the 13-bit step field of the record: it is dropped and the map's
-    next synchronising call says so (WS_ERR_RANGE), instead of returning a map that silently lacks it"""
+    """a ray of more than 65 536 steps cannot be ordered by the step field of the record even in a scan of two points: it is
+    dropped and the map's next synchronising call says so (WS_ERR_RANGE), instead of returning a map that silently lacks it"""
     torch = _torch()
     import warpsense_amd as W
     tau, res, mw = 32000, 2, 640  # 1 mm steps; distance 40 m + tau = 72 000 steps
     view, t, oa, on = _pair_at((64, 64, 64), tau, res, mw, (0, 0, 0), (32, 32, 32))
     pts = np.array([[60, 0, 0], [0, 61, 3]], dtype=np.int32)
     t.update_tsdf(torch.from_numpy(pts).cuda(), (-20000, 0, 0), (0, 0, 32768))
-    with pytest.raises(W.WsError, match="8192 steps"):
+    with pytest.raises(W.WsError, match="outside the range of the record"):
         t.ctx.sync()
     assert np.all(_download_view(t, view, 0) == O.pack(tau, 0))

@@ -268,7 +268,8 @@ static int map_take_error(ws_map *m)
     set_error("TSDF update: record capacity exceeded, a TSDF update since the last check is not exact");
     return WS_ERR_CAPACITY;
   }
-  set_error("TSDF update: a ray needs more than 8192 steps or 31 fan steps (outside the range of the record fields) and was dropped");
+  set_error("TSDF update: a ray needs more ray steps or fan steps than the key of a scan of this many points holds (outside the range of the record fields: "
+            "65 536 steps / 255 fan steps for small scans, 32 768 / 63 for 131 072 points, 8192 / 31 for a million) and was dropped");
   return WS_ERR_RANGE;
 }
 

@@ -73,7 +73,7 @@ struct ScatterArgs
   uint32_t scan_seq;  // sequence number of this scatter
   unsigned long long *big_keys; // (tile, entry number) -> entry + 1 beyond TILE_DIRECT: keys, then uint32 values (big_mask + 1 slots)
   uint32_t big_mask;
-  uint32_t pad0;
+  uint32_t rec_fmt;   // the scan's split of the record's key bits: S | F << 8 (rec_format, ws_internal.h)
   uint32_t *tail_stats; // records / (flush, tile) groups per workgroup of the tail march
   TsdfCounters *counters;
   uint32_t *status; // host-mapped: [0] sticky error bits, [4..5] record bound of the scan in flight, [6] its sequence number, [8] / [9] see ws_map::status_host
@@ -287,9 +287,9 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
         const int64_t steps = div_trunc_i64(len_end - 1, half) + 1;
         const int64_t max_delta_z = (int64_t)DZ_PER_DISTANCE * len_end / MATRIX_RESOLUTION;
         const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
-        if (steps > REC_MAX_STEPS || (max_delta_z * 2) / res + 1 > REC_MAX_FAN || !small_iv)
+        if (steps > (int64_t)(1 << (a.rec_fmt & 0xffu)) || (max_delta_z * 2) / res + 1 > (int64_t)((1 << (a.rec_fmt >> 8)) - 1) || !small_iv)
         {
-          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the record's step / fan fields
+          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the record's step / fan fields for a scan of this many points
         }
         else
         {
@@ -906,7 +906,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     // records -- the kernel takes 462 instead of 183 us)
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), local = local_of(sx, sy, sz);
     if (mark) a.vstate[((size_t)tile << 10) + vbrick(local)] = VOX_KEYED;
-    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local));
+    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local, (int32_t)(a.rec_fmt & 0xffu), (int32_t)(a.rec_fmt >> 8)));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
@@ -1213,7 +1213,7 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
     {
       const uint32_t id = first == SUB_LOST ? SUB_LOST : first + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
       // (the answer of the atomic in there picked up one emit phase later, under the next batch's voxel bytes: no gain, measured)
-      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local));
+      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local, (int32_t)(a.rec_fmt & 0xffu), (int32_t)(a.rec_fmt >> 8)));
       n_keyed += 1;
     }
   }
@@ -1552,6 +1552,7 @@ struct ResolveArgs
   uint32_t big_mask;
   uint32_t scan_seq;
   uint32_t sub_cap;
+  uint32_t fan_mask, fan_mid; // the fan field of this scan's records (rec_format): the weight is negated iff fan != fan_mid
   uint32_t *new_data;
   uint32_t *avg_data;
   uint8_t *vstate;
@@ -1973,7 +1974,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       // scan A: the negatives that come before the current positive candidate and can block it
       auto scan_a = [&]() {
         scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
-          if (!rec_negative(rec)) return;
+          if (!rec_negative(rec, a.fan_mask, a.fan_mid)) return;
           const uint32_t m = mstate[l];
           if (m == M_IDLE || (uint32_t)av >= m) return;
           const unsigned long long P = kpos[l];
@@ -1991,7 +1992,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
       // ---- pass 1: earliest positive, smallest negative per voxel
       scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
-        if (rec_negative(rec))
+        if (rec_negative(rec, a.fan_mask, a.fan_mid))
           atomicMin(&kneg[l], (unsigned long long)neg_key(rec, av, value));
         else
           atomicMin(&kpos[l], (unsigned long long)rec);
@@ -2067,7 +2068,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         {
           // B: the next positive candidate that can still be accepted
           scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
-            if (rec_negative(rec)) return;
+            if (rec_negative(rec, a.fan_mask, a.fan_mid)) return;
             const uint32_t m = mstate[l];
             if (m == M_IDLE || (uint32_t)av > m) return;
             if (rec > klast[l]) atomicMin(&kpos[l], (unsigned long long)rec);
@@ -2572,7 +2573,10 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   sa.scan_seq = ++m->scan_seq;
   sa.big_keys = m->big_keys;
   sa.big_mask = m->big_slots - 1;
-  sa.pad0 = 0;
+  {
+    const RecFormat rf = rec_format(n);
+    sa.rec_fmt = (uint32_t)rf.S | ((uint32_t)rf.F << 8);
+  }
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;
   sa.status = m->status_dev;
@@ -2614,6 +2618,8 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   ra.big_keys = m->big_keys;
   ra.big_mask = m->big_slots - 1;
   ra.scan_seq = sa.scan_seq;
+  ra.fan_mask = (1u << (sa.rec_fmt >> 8)) - 1u;
+  ra.fan_mid = rec_fan_mid((int32_t)(sa.rec_fmt >> 8));
   ra.new_data = m->data[WS_MAP_NEW];
   ra.avg_data = m->data[WS_MAP_AVG];
   ra.vstate = m->vstate;

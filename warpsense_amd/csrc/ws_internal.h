@@ -59,22 +59,48 @@ struct MapParams
 
 // ---- candidate records ---------------------------------------------------------------------
 // One scatter target of a ray tail (a write_tsdf_min call, update_tsdf.cu:107-125) is ONE 64-bit word:
-//   point(20) | ray step(13) | fan(5) | value(16) | voxel in tile(10)
-// `fan` = fan step - mid + 15 (mid: the on-ray fan step, update_tsdf.cu:104): ascending like the fan step itself, and the
-// weight is negated iff fan != 15 (update_tsdf.cu:118-121) -- no separate sign-of-weight bit.  The top 38 bits
-// t = point | step | fan are unique per candidate, so ascending records == canonical serial order (the low bits never decide).
-constexpr int REC_VOX_BITS = 10, REC_VALUE_SHIFT = 10, REC_T_SHIFT = 26, REC_FAN_MID = 15;
+//   t = point | ray step | fan (38 bits) | value(16) | voxel in tile(10)
+// `fan` = fan step - mid + MID (mid: the on-ray fan step, update_tsdf.cu:104; MID = 2^(F-1) - 1): ascending like the fan step
+// itself, and the weight is negated iff fan != MID (update_tsdf.cu:118-121) -- no separate sign-of-weight bit.  The top 38 bits
+// are unique per candidate, so ascending records == canonical serial order (the low bits never decide).
+// The 38 bits are shared out PER SCAN (round 5; 20 | 13 | 5 for every scan before -- a ray of more than 8192 steps or 31 fan
+// steps was dropped with WS_ERR_RANGE, which the reference has no counterpart of): a scan of n points needs P = ceil(log2 n) bits
+// for the point, the rest goes to the step (up to 16 bits: 65 536 steps) and the fan (5 to 8 bits: 31 to 255 fan steps).  The
+// reference's own 131 072-point scans admit 32 768 steps and 63 fan steps (40 m rays at 5 mm); a million points 8192 / 31 as
+// before.  rec_format() is the one place that decides; the kernels get S and F as scalars.
+constexpr int REC_VOX_BITS = 10, REC_VALUE_SHIFT = 10, REC_T_SHIFT = 26;
 constexpr int T_BITS = 38;
 constexpr uint64_t T_MASK = (1ull << T_BITS) - 1;
-constexpr int32_t REC_MAX_STEPS = 8192, REC_MAX_FAN = 31; // what the fields hold: more is WS_ERR_RANGE
-__host__ __device__ inline uint64_t make_rec(uint32_t point, int32_t step, int32_t fan_minus_mid, int32_t value, uint32_t local)
+struct RecFormat
 {
-  return ((uint64_t)point << 44) | ((uint64_t)(uint32_t)step << 31) | ((uint64_t)(uint32_t)(fan_minus_mid + REC_FAN_MID) << REC_T_SHIFT) |
-         ((uint64_t)((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT) | (uint64_t)local;
+  int32_t S, F; // bits of the ray step and of the fan field
+};
+__host__ __device__ inline RecFormat rec_format(uint64_t n_points)
+{
+  int P = 1;
+  while ((1ull << P) < n_points) ++P; // point < n <= 2^P
+  const int R = T_BITS - P;            // >= 18 for n <= 2^20 (MAX_SCAN_POINTS)
+  RecFormat f;
+  f.F = 5 + (R - 18) / 3;
+  f.S = R - f.F;
+  if (f.S > 16) // (the marches carry a step in 16 bits next to the lane)
+  {
+    f.S = 16;
+    f.F = R - 16 > 8 ? 8 : R - 16;
+  }
+  return f;
+}
+__host__ __device__ inline int32_t rec_max_steps(const RecFormat &f) { return 1 << f.S; }
+__host__ __device__ inline int32_t rec_max_fan(const RecFormat &f) { return (1 << f.F) - 1; } // iter_steps the fan field holds
+__host__ __device__ inline uint32_t rec_fan_mid(int32_t F) { return (1u << (F - 1)) - 1u; }
+__host__ __device__ inline uint64_t make_rec(uint32_t point, int32_t step, int32_t fan_minus_mid, int32_t value, uint32_t local, int32_t S, int32_t F)
+{
+  return ((uint64_t)point << (REC_T_SHIFT + S + F)) | ((uint64_t)(uint32_t)step << (REC_T_SHIFT + F)) |
+         ((uint64_t)((uint32_t)fan_minus_mid + rec_fan_mid(F)) << REC_T_SHIFT) | ((uint64_t)((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT) | (uint64_t)local;
 }
 __host__ __device__ inline int32_t rec_value(uint64_t rec) { return (int32_t)(int16_t)(uint16_t)(rec >> REC_VALUE_SHIFT); }
 __host__ __device__ inline uint32_t rec_local(uint64_t rec) { return (uint32_t)rec & ((1u << REC_VOX_BITS) - 1u); }
-__host__ __device__ inline bool rec_negative(uint64_t rec) { return (((uint32_t)(rec >> REC_T_SHIFT)) & 31u) != (uint32_t)REC_FAN_MID; }
+__host__ __device__ inline bool rec_negative(uint64_t rec, uint32_t fan_mask, uint32_t fan_mid) { return (((uint32_t)(rec >> REC_T_SHIFT)) & fan_mask) != fan_mid; }
 
 // Records live in SUB-CHUNKS of 32 (256 bytes) that belong to one tile each.  A wave of the tail march owns a run of
 // sub-chunk ids (its share of the block its workgroup took from the pool, refilled 32 at a time); the first record a wave
