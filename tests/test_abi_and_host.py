@@ -221,3 +221,60 @@ def test_a_group_whose_device_side_exchange_keeps_timing_out_leaves_that_route_t
     for rank, exact, calls, resets, drops, peers, limit in sorted(q.get(timeout=10) for _ in range(2)):
         assert all(exact) and len(exact) == limit + 2, (rank, exact)
         assert calls == limit and resets == limit - 1 and drops == 1 and peers is None, (rank, calls, resets, drops, peers)
+
+
+class FailingPeerBackend(FlakyPeerBackend):
+    """the device-side route RAISES on rank 1 (a sticky map error surfacing there), works on rank 0"""
+
+    def register_peers(self, first, count, T_in, max_iterations, it_weight_gradient, epsilon):
+        self.calls += 1
+        if self.rank == 1:
+            raise ValueError("rank 1: the map is not exact")
+        return np.full((4, 4), 7.0, dtype=np.float32), 1
+
+
+def _failing_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from warpsense_amd import synthetic as S
+    from warpsense_amd.dist import sharded_register_cloud
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tau, res, mw, size = 1000, 50, 640, (64, 64, 32)
+        pts = S.os1_128_scan(rings=8, azimuths=64, half_extents_mm=(1200.0, 1000.0, 500.0), seed=5)
+        avg = O.OracleMap(size, tau, 0)
+        new = avg.copy()
+        O.update_tsdf(avg, new, pts, (0, 0, 0), (0, 0, 32768), tau, mw, res)
+        backend = FailingPeerBackend(avg, pts, res, rank, world)
+        try:
+            sharded_register_cloud(backend, pts.shape[0], np.eye(4, dtype=np.float32), 20, 0.1, 0.03, batch=7)
+            q.put((rank, "returned", backend.resets))
+        except ValueError as exc:
+            q.put((rank, "own:" + str(exc), backend.resets))
+        except RuntimeError as exc:
+            q.put((rank, "peer:" + str(exc)[:40], backend.resets))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_an_error_on_one_rank_ends_the_call_on_every_rank():
+    """when the device-side route raises on one rank, the others must not walk into the all-reduce route alone (they
+    blocked there until the backend's time-out).  The vote has three values: every rank leaves the call together -- the failing
+    rank with its own exception, the others with one that says a peer failed."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = dict((r, (what, resets)) for r, what, resets in (q.get(timeout=10) for _ in range(2)))
+    assert got[1][0].startswith("own:rank 1") and got[0][0].startswith("peer:"), got
+    assert got[0][1] == 1 and got[1][1] == 1

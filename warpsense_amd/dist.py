@@ -287,13 +287,27 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
         except Exception as exc:  # noqa: BLE001 - re-raised below, after the collective
             res, failure = None, exc
         ok = res is not None
-        if world > 1:  # a time-out is seen by every rank, but agree before anyone takes the other route
+        # the ranks agree on ONE of three verdicts before anyone takes another route: 2 = the exchange worked, 1 = it timed out
+        # (every rank sees that), 0 = a rank failed with an ERROR (with a two-valued vote the other ranks went on
+        # into the all-reduce route and blocked in collectives the failed rank, which re-raised, never joined)
+        verdict = 2 if ok else (0 if failure is not None else 1)
+        if world > 1:
             import torch
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            flag = torch.tensor([verdict], dtype=torch.int32)
             if dist.get_backend(group) != "gloo":
                 flag = flag.cuda()
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            ok = bool(int(flag.item()))
+            verdict = int(flag.item())
+            ok = verdict == 2
+        if verdict == 0:
+            # every rank leaves the call here, together: the failing rank with its own exception, the others with this one
+            backend.reset_peers()
+            if world > 1:
+                dist.barrier(group=group)
+            if failure is not None:
+                raise failure
+            raise RuntimeError("sharded_register_cloud: a peer rank failed in the device-side registration (its own exception says why); "
+                               "no rank took the all-reduce route")
         if ok:
             backend.peer_timeouts = 0
             backend.last_route = "device_mailboxes"
@@ -311,8 +325,6 @@ def sharded_register_cloud(backend, n_points: int, T_in, max_iterations: int, it
             backend.reset_peers()
         if world > 1:
             dist.barrier(group=group)
-        if failure is not None:
-            raise failure
     backend.last_route = "all_reduce"
     runner = None
     if graphs is not None:
