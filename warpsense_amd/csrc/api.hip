@@ -3,6 +3,7 @@
 #include <cmath>
 #include <chrono>
 #include <atomic>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -364,9 +365,15 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipHostMalloc((void **)&m->status_host, 64, hipHostMallocMapped));
   std::memset(m->status_host, 0, 64);
   TRY(hipHostGetDevicePointer((void **)&m->status_dev, m->status_host, 0));
-  // the pool of the ray tails' records: what a 131 072-point scan can need on this map (its record bound is ~75 M at 50 mm);
-  // a scan that needs more is aborted and repeated with a larger pool, ws_tsdf_set_capacity() reserves up front
-  rc = map_alloc_records(m, subs_for_scan(m, 80ull << 20, 131072));
+  // the pool of the ray tails' records: what a 131 072-point scan can need on a map of the reference's size (its record bound is
+  // ~75 M at 50 mm) -- scaled down for small maps (1.1 GB for a 64^3 map): 32 records per voxel, scans of 16 384
+  // points.  Only a first guess: a scan that needs more is aborted and repeated with a larger pool (settle_tsdf),
+  // ws_tsdf_set_capacity() reserves up front.
+  {
+    const bool small_map = m->n_vox < (16ll << 20);
+    const unsigned long long need0 = small_map ? std::max<unsigned long long>(1ull << 20, 32ull * (unsigned long long)m->n_vox) : (80ull << 20);
+    rc = map_alloc_records(m, subs_for_scan(m, std::min<unsigned long long>(need0, 80ull << 20), small_map ? 16384 : 131072));
+  }
   if (rc != WS_OK)
   {
     map_free(m);
