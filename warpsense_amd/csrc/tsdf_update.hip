@@ -94,6 +94,11 @@ constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
 #endif
+#ifndef WS_TAIL_DDA
+#define WS_TAIL_DDA 0 // 1: the tail march walks from column change to column change too (ws_dda.h).  Measured and NOT kept: 149 us against 133 --
+                      // a part of a tail is ~11 samples, the walk's state and per-ray constants cost 96 registers with 11 spilled, and its
+                      // iterations run 82 % full (tools/lane_model.py) where the stepped samples fill their batches to 94 %
+#endif
 #ifndef WS_FREE_DDA
 #define WS_FREE_DDA 1 // 1: the free pass walks from column change to column change (ws_dda.h); 0: rounds 3-4's sample phase + LDS queue
 #endif
@@ -918,7 +923,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     if (tile != listed_tile) a.tile_dirty[tile] = 1;
   };
 
-  const bool general = !__all(!work || (r.pad & RAY_SIMPLE));
+  const bool general = !__all(!work || ((r.pad & RAY_SIMPLE) && r.distance >= 2)); // (>= 2: the 32-bit multiplier of ws_dda.h)
   if (general)
   {
     // a ray of this wave wraps in int32 or leaves the window: the general walk with all its tests, record by record.  (The
@@ -951,6 +956,50 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     uint32_t cap_left = 0; // records the wave may put before it looks at its bookkeeping again (uniform)
     const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
     const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
+#if WS_TAIL_DDA
+    // The lane walks from one column change of its part of the tail to the next (ws_dda.h) instead of stepping every sample:
+    // a part is ~11 samples and ~6 column changes, the iterations of the wave drop from 235 k to 158 k per scan and an
+    // iteration loses the three stepped axes.  What a column change queues is what the stepped walk queued: the sample's
+    // position and its step.
+    const uint32_t adx = (uint32_t)(r.dx < 0 ? -r.dx : r.dx), ady = (uint32_t)(r.dy < 0 ? -r.dy : r.dy), adz = (uint32_t)(r.dz < 0 ? -r.dz : r.dz);
+    const int32_t smx = r.dx < 0 ? -1 : 0, smy = r.dy < 0 ? -1 : 0, smz = r.dz < 0 ? -1 : 0;
+    const int32_t sposx = (f.posx ^ smx) - smx, sposy = (f.posy ^ smy) - smy, sposz = (f.posz ^ smz) - smz;
+    DdaRay R;
+    R.M32 = (uint32_t)r.div_m;
+    R.sh = r.div_k - 32;
+    DdaAxis wx, wy;
+    wx.K = wy.K = wx.Ksp = wy.Ksp = DDA_NEVER;
+    wx.rho = wy.rho = wx.wq = wy.wq = wx.wr = wy.wr = 0;
+    wx.D = wy.D = 1;
+    uint32_t kk = DDA_NEVER; // the lane's next column change (ray step)
+    if (work)
+    {
+      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
+      const int32_t len0 = 1 + kinit * half;
+      const uint32_t qx = dda_q(adx, len0, R), qy = dda_q(ady, len0, R);
+      dda_axis_init(wx, adx, sposx, qx, dist, res, half);
+      dda_axis_init(wy, ady, sposy, qy, dist, res, half);
+      kk = min(wx.K, wy.K);
+      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71): a column change of its own in front
+      if (k0 == 0 && (div_res(sposx + (int32_t)qx, f) != 0 || div_res(sposy + (int32_t)qy, f) != 0)) kk = 0;
+    }
+    auto push_at = [&](bool cand, uint32_t ks) {
+      const unsigned long long mask = __ballot(cand);
+      if (cand)
+      {
+        const int32_t len = 1 + (int32_t)ks * half;
+        const int32_t ax = sposx + (int32_t)dda_q(adx, len, R), ay = sposy + (int32_t)dda_q(ady, len, R), az = sposz + (int32_t)dda_q(adz, len, R);
+        u32x4 e;
+        e.x = (uint32_t)((ax ^ smx) - smx);
+        e.y = (uint32_t)((ay ^ smy) - smy);
+        e.z = (uint32_t)((az ^ smz) - smz);
+        e.w = ks | ((uint32_t)lane << 16);
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
+      }
+      qtail += (uint32_t)__popcll(mask);
+    };
+#else
     AxisRun ix0, iy0, iz0;
     ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
     ix0.gap = 0x3fffffff;
@@ -992,6 +1041,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     int32_t todo = work ? k1 - k : 0;
     for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
     const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
+#endif
     // emit phase: up to 64 queued samples, one per lane
     auto emit_batch = [&]() {
       const uint32_t cnt = qtail - qhead;
@@ -1082,6 +1132,35 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         }
       }
     };
+#if WS_TAIL_DDA
+    auto walk = [&](auto special) {
+      while (__any(kk < (uint32_t)k1))
+      {
+        const bool active = kk < (uint32_t)k1;
+        push_at(active, kk);
+        const bool cx = active && wx.K == kk, cy = active && wy.K == kk;
+        if (cx)
+        {
+          const bool sp = decltype(special)::value && wx.Ksp == kk;
+          dda_axis_advance(wx);
+          if (decltype(special)::value && sp) dda_axis_after_zero_cell(wx, adx, sposx, dist, res);
+        }
+        if (cy)
+        {
+          const bool sp = decltype(special)::value && wy.Ksp == kk;
+          dda_axis_advance(wy);
+          if (decltype(special)::value && sp) dda_axis_after_zero_cell(wy, ady, sposy, dist, res);
+        }
+        if (active) kk = min(wx.K, wy.K);
+        // ---- emit phase: 64 queued samples, one per lane
+        if (qtail - qhead >= 64) emit_batch();
+      }
+    };
+    if (__any(work && (wx.Ksp != DDA_NEVER || wy.Ksp != DDA_NEVER)))
+      walk(std::true_type{});
+    else
+      walk(std::false_type{});
+#else
     for (int32_t it = 0; it < n_iter; ++it)
     {
       // ---- sample phase
@@ -1092,6 +1171,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // ---- emit phase: 64 queued samples, one per lane
       if (qtail - qhead >= 64) emit_batch();
     }
+#endif
     while (qtail != qhead) emit_batch();
   }
 #ifdef WS_TAIL_TIMING
@@ -1242,7 +1322,7 @@ __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame
   free_finish<false>(a, p, n_keyed, none);
 }
 
-constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
+[[maybe_unused]] constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
 #ifndef WS_FREE_LANES
 #define WS_FREE_LANES 4
 #endif
@@ -1332,10 +1412,12 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     wx.rho = wy.rho = wx.wq = wy.wq = wx.wr = wy.wr = 0;
     wx.D = wy.D = 1;
     uint32_t k = DDA_NEVER; // the lane's next candidate (ray step)
+#if WS_FREE_STATIC
     uint32_t last_tile = 0xffffffffu; // the tile this lane has marked last
     // (16 bytes of slack behind the voxel bytes of plane 0 and behind the tile bytes of plane 0: always zero)
     const int64_t dummy_vox = (int64_t)a.ntx * a.nty * a.ntz * 1024;
     const uint32_t dummy_tile = (uint32_t)(a.ntx * a.nty * a.ntz);
+#endif
     if (work)
     {
       const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
