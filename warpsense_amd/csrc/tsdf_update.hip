@@ -1336,7 +1336,8 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // a free pass of 195-230 instead of 123 us whatever the lane layout: out there neighbouring rays are more than a voxel
 // apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
 #ifndef WS_FREE_WGS
-#define WS_FREE_WGS 7 // workgroups per CU the register budget is set for (5 / 6 / 7 / 8: 121 / 120 / 117 / 147 us; seven: 72 VGPRs, 11 spilled outside the loop)
+#define WS_FREE_WGS 6 // workgroups per CU the register budget is set for (round 5's walk over column changes, 5 / 6 / 7 / 8: 105 / 103 / 102 / 120 us;
+                      // six: 80 VGPRs, one spilled outside the loops; seven: 72 with 15 spilled; round 4's stepped walk: 121 / 120 / 117 / 147)
 #endif
 __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
 {
