@@ -474,7 +474,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 tj = json.load(fh)
-                traffic_source = "profiles/pmc_traffic.json@" + str(tj.get("git_sha", "unknown")) + " (PMC passes of tools/profile_r04.sh, not measured in this run)"
+                traffic_source = "profiles/pmc_traffic.json@" + str(tj.get("git_sha", "unknown")) + " (PMC passes of tools/profile_r05.sh, not measured in this run)"
                 mode_key = "dense" if args.integrate == "dense" else "sparse"
                 # HBM bytes of the whole kernel group the achieved figure is computed over (PMC passes, tools/make_traffic.py)
                 traffic = tj.get(f"integrate:{mode_key}") if dom == "integrate" else tj.get(f"scatter_total:{mode_key}")

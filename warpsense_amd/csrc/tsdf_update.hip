@@ -81,6 +81,13 @@ struct ScatterArgs
 // 264 bytes of kernel arguments instead of 256 cost reg_loop_kernel 30 % (registration.hip); the same bound here
 static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of kernel arguments");
 
+#ifdef WS_REC_CONST // (timing experiment: the round-4 split 20 | 13 | 5 as compile-time constants)
+#define REC_S(a) 13
+#define REC_F(a) 5
+#else
+#define REC_S(a) ((int32_t)((a).rec_fmt & 0xffu))
+#define REC_F(a) ((int32_t)((a).rec_fmt >> 8))
+#endif
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
@@ -911,7 +918,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     // records -- the kernel takes 462 instead of 183 us)
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), local = local_of(sx, sy, sz);
     if (mark) a.vstate[((size_t)tile << 10) + vbrick(local)] = VOX_KEYED;
-    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local, (int32_t)(a.rec_fmt & 0xffu), (int32_t)(a.rec_fmt >> 8)));
+    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local, REC_S(a), REC_F(a)));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
@@ -1293,7 +1300,7 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
     {
       const uint32_t id = first == SUB_LOST ? SUB_LOST : first + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
       // (the answer of the atomic in there picked up one emit phase later, under the next batch's voxel bytes: no gain, measured)
-      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local, (int32_t)(a.rec_fmt & 0xffu), (int32_t)(a.rec_fmt >> 8)));
+      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local, REC_S(a), REC_F(a)));
       n_keyed += 1;
     }
   }
@@ -2659,6 +2666,9 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   {
     const RecFormat rf = rec_format(n);
     sa.rec_fmt = (uint32_t)rf.S | ((uint32_t)rf.F << 8);
+#ifdef WS_REC_CONST
+    sa.rec_fmt = 13u | (5u << 8);
+#endif
   }
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;

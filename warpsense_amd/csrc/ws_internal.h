@@ -95,8 +95,12 @@ __host__ __device__ inline int32_t rec_max_fan(const RecFormat &f) { return (1 <
 __host__ __device__ inline uint32_t rec_fan_mid(int32_t F) { return (1u << (F - 1)) - 1u; }
 __host__ __device__ inline uint64_t make_rec(uint32_t point, int32_t step, int32_t fan_minus_mid, int32_t value, uint32_t local, int32_t S, int32_t F)
 {
-  return ((uint64_t)point << (REC_T_SHIFT + S + F)) | ((uint64_t)(uint32_t)step << (REC_T_SHIFT + F)) |
-         ((uint64_t)((uint32_t)fan_minus_mid + rec_fan_mid(F)) << REC_T_SHIFT) | ((uint64_t)((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT) | (uint64_t)local;
+  // built as two 32-bit halves (the shifts are scan constants in scalar registers; 64-bit shifts by a variable are three
+  // instructions each on gfx950): u = step | fan is below 2^24, t = point | u is 38 bits, the record's high word is t >> 6
+  const uint32_t u = ((uint32_t)step << F) | ((uint32_t)fan_minus_mid + rec_fan_mid(F));
+  const uint32_t hi = (point << (S + F - 6)) | (u >> 6);                                                                  // S + F >= 18
+  const uint32_t lo = (u << REC_T_SHIFT) | (((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT) | local;                      // (the top bits of u leave the word)
+  return ((uint64_t)hi << 32) | lo;
 }
 __host__ __device__ inline int32_t rec_value(uint64_t rec) { return (int32_t)(int16_t)(uint16_t)(rec >> REC_VALUE_SHIFT); }
 __host__ __device__ inline uint32_t rec_local(uint64_t rec) { return (uint32_t)rec & ((1u << REC_VOX_BITS) - 1u); }
