@@ -226,8 +226,11 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
 {
   __shared__ unsigned long long ub_wave[4];
   __shared__ uint32_t s_bkey[512], s_bcnt[512]; // bins of this workgroup's rays: key, count (then: first rank)
+  __shared__ int32_t s_fan[256];                // fan_steps (tail_bound walks it entry by entry: a chain of dependent loads from memory otherwise)
   s_bkey[threadIdx.x] = s_bkey[threadIdx.x + 256] = 0xffffffffu;
   s_bcnt[threadIdx.x] = s_bcnt[threadIdx.x + 256] = 0;
+  s_fan[threadIdx.x] = a.fan_steps[threadIdx.x];
+  __syncthreads();
   uint32_t my_bin = 0;
   const uint32_t ix = blockIdx.x * 256u + threadIdx.x;
   if (ix == 0)
@@ -359,7 +362,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
           r.kfirst = kfirst;
           // records this ray can make: the scatter targets of its tail + one per free-space step (a free-space candidate that
           // lands on a voxel with records joins them)
-          const unsigned long long ub = tail_bound(kfirst, steps, len_end, a.fan_steps) + (unsigned long long)kfirst;
+          const unsigned long long ub = tail_bound(kfirst, steps, len_end, s_fan) + (unsigned long long)kfirst;
           r.ub = ub > 0xffffffffull ? 0xffffffffu : (uint32_t)ub;
         }
       }
