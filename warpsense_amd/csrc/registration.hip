@@ -1216,7 +1216,7 @@ constexpr uint64_t REG_COUNT_ONE = 1ull << 56;
 constexpr uint64_t REG_SUM_MASK = REG_COUNT_ONE - 1;
 static_assert(REG_WORDS == 64 && REG_BLOCKS % REG_GROUPS == 0 && REG_BLOCKS / REG_GROUPS < 256, "counted exchange");
 #ifndef WS_REG_FIRST_POLL_SLEEP
-#define WS_REG_FIRST_POLL_SLEEP 28
+#define WS_REG_FIRST_POLL_SLEEP 26 // (round 5, after the shorter solve: 16 / 22 / 25 / 26 / 28 / 30 / 34: 4.97 / 4.47 / 4.40 / 4.40 / 4.42 / 4.46 / 4.58 us per iteration)
 #endif
 constexpr int REG_FIRST_POLL_SLEEP = WS_REG_FIRST_POLL_SLEEP; // x 64 clocks before the first poll
 constexpr int REG_POLL_SLEEP = 2;        // between polls
