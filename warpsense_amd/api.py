@@ -541,6 +541,9 @@ class TSDFCuda:
         n = int(scan_points.shape[0])
         sp, u = _i3c(scanner_pos), _i3c(up)
         if _is_device(scan_points):
+            # ws_tsdf_update_dev returns after its launches and may have to repeat the scan when the NEXT call on this map looks at
+            # its verdict (warpsense_hip.h): the tensor must not go back to torch's allocator before that -- keep it until the next update
+            self._scan_in_flight = scan_points
             rc = self._L.ws_tsdf_update_dev(self.handle, _ptr(scan_points), n, _ptr(sp), _ptr(u))
         else:
             pts = np.ascontiguousarray(scan_points, dtype=np.int32)
@@ -558,6 +561,7 @@ class TSDFCuda:
 
     def scatter(self, scan_points_dev, scanner_pos, up):
         """cu_min_tsdf_krnl alone (parity tests): leaves the resolved scan in new_map."""
+        self._scan_in_flight = scan_points_dev  # (see update_tsdf)
         check(self._L.ws_tsdf_scatter_dev(self.handle, _ptr(scan_points_dev), int(scan_points_dev.shape[0]),
                                           _ptr(_i3c(scanner_pos)), _ptr(_i3c(up))), "ws_tsdf_scatter_dev")
 
