@@ -641,13 +641,17 @@ class RegistrationCuda:
         return h.reshape(6, 6).T.copy(), g, e.value, c.value
 
     def register_cloud(self, map_dev, pretransform, max_iterations, it_weight_gradient, epsilon, map_resolution):
-        T = _colmajor(pretransform)
-        out = np.empty(16, dtype=np.float32)
-        it = C.c_int32(0)
-        check(self._L.ws_register_cloud(self.handle, map_dev, _ptr(T), int(max_iterations), C.c_float(it_weight_gradient),
-                                        C.c_float(epsilon), int(map_resolution), self.flags, _ptr(out), C.byref(it)),
+        # (two ctypes buffers kept for the life of the object: numpy's .ctypes costs 3 us per array, and this call sits in the gap
+        # between the end of one registration and the first kernel of the next update)
+        buf = getattr(self, "_rc_buf", None)
+        if buf is None:
+            buf = self._rc_buf = ((C.c_float * 16)(), (C.c_float * 16)(), C.c_int32(0))
+        T_c, out_c, it = buf
+        T_c[:] = np.asarray(pretransform, dtype=np.float32).reshape(4, 4).T.reshape(16).tolist()
+        check(self._L.ws_register_cloud(self.handle, map_dev, T_c, int(max_iterations), C.c_float(it_weight_gradient),
+                                        C.c_float(epsilon), int(map_resolution), self.flags, out_c, C.byref(it)),
               "ws_register_cloud")
-        return out.reshape(4, 4).T.copy(), it.value
+        return np.array(out_c, dtype=np.float32).reshape(4, 4).T.copy(), it.value
 
     def last_sums(self):
         """(h 6x6 int64, g[6], e, c) the last Gauss-Newton update of the last register_cloud was made from (test entry)"""
