@@ -801,11 +801,11 @@ int ws_reg_destroy(ws_reg *r)
   if (r->points) (void)hipFree(r->points);
   if (r->partials) (void)hipFree(r->partials);
   if (r->state) (void)hipFree(r->state);
-  if (r->T_dev) (void)hipFree(r->T_dev);
   if (r->sums_dev) (void)hipFree(r->sums_dev);
   if (r->state_host) (void)hipHostFree(r->state_host);
   if (r->host_flag) (void)hipHostFree(r->host_flag);
   if (r->result_host) (void)hipHostFree(r->result_host);
+  if (r->iter_host) (void)hipHostFree(r->iter_host);
   if (r->grid_bar) (void)hipFree(r->grid_bar);
   if (r->shard_arrived) (void)hipFree(r->shard_arrived);
   (void)ws_reg_peer_disconnect(r);
@@ -838,13 +838,15 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   hipError_t e = hipSuccess;
   if (rc == WS_OK) e = hipMalloc((void **)&r->partials, reg_partials_bytes());
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->state, 2 * sizeof(GnState));
-  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->T_dev, 16 * sizeof(float));
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->sums_dev, 44 * sizeof(int64_t));
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->state_host, sizeof(GnState), hipHostMallocDefault);
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->host_flag, 64, hipHostMallocMapped);
   if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->host_flag_dev, r->host_flag, 0);
   if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->result_host, sizeof(GnState), hipHostMallocMapped);
   if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->result_host_dev, r->result_host, 0);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->iter_host, 64 * sizeof(int64_t), hipHostMallocMapped);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->iter_host_dev, r->iter_host, 0);
+  if (rc == WS_OK && e == hipSuccess) std::memset(r->iter_host, 0, 64 * sizeof(int64_t));
   if (rc == WS_OK && e == hipSuccess) e = hipMemsetAsync(r->state, 0, 2 * sizeof(GnState), ctx->stream);
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->grid_bar, reg_barrier_bytes());
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->shard_arrived, 256);
@@ -892,13 +894,34 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
   if (!r || !m || !T || !h || !g || !e || !c) return invalid("ws_reg_iterate: NULL argument");
   WS_SETTLE(m);
   if (res < 1) return invalid("ws_reg_iterate: map_resolution must be positive");
-  hipStream_t s = r->ctx->stream;
-  WS_HIP(hipMemcpyAsync(r->T_dev, T, 16 * sizeof(float), hipMemcpyHostToDevice, s)); // registration.cu:351
-  int rc = launch_reg_accumulate(r, m, r->T_dev, res, flags, 0, r->n, r->sums_dev);
+  // One launch, nothing copied by the runtime: the pose travels in the kernel arguments (registration.cu:351 copies it), the
+  // sums come back through host-mapped memory with the call's sequence number behind them (registration.cu:356-365 copies
+  // four results and adds 32 partials up on the host).  The caller cannot go on without them, so the wait is a spin on that
+  // word -- bounded: after 20 ms the stream is synchronised the ordinary way, and a kernel that never ends is the runtime's to report.
+  const uint32_t seq = ++r->iter_seq ? r->iter_seq : ++r->iter_seq; // (never 0: the block starts zeroed)
+  int rc = launch_reg_host_iter(r, m, T, res, flags, seq);
   if (rc != WS_OK) return rc;
+  {
+    const volatile int64_t *done = r->iter_host + 44;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while ((uint32_t)*done != seq)
+    {
+      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      {
+        WS_HIP(hipStreamSynchronize(r->ctx->stream));
+        if ((uint32_t)*done != seq)
+        {
+          set_error("ws_reg_iterate: the launch ended without its result");
+          return WS_ERR_INTERNAL;
+        }
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   int64_t sums[44];
-  WS_HIP(hipMemcpyAsync(sums, r->sums_dev, sizeof sums, hipMemcpyDeviceToHost, s));
-  WS_HIP(hipStreamSynchronize(s));
+  std::memcpy(sums, r->iter_host, sizeof sums);
   std::memcpy(h, sums, 36 * sizeof(int64_t));
   std::memcpy(g, sums + 36, 6 * sizeof(int64_t));
   *e = (int32_t)sums[42];

@@ -1758,6 +1758,53 @@ __global__ __launch_bounds__(REG_THREADS) void reg_shard_kernel(ShardArgs a)
   if (threadIdx.x == 0) __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- perform_registration for a HOST loop (registration.cu:347-368 as the reference's callers use it) in one launch ----
+// tsdf_registration.cpp:55-92 calls perform_registration once per Gauss-Newton iteration and needs h, g, e, c on the host
+// before it can go on: the call is a latency chain, and until round 5 it was a 64-byte copy to the device, two launches, a
+// 352-byte copy back into pageable memory and a stream synchronisation -- 34 us per iteration, 178 of them per scan.  Here the
+// pose travels in the kernel arguments, the last workgroup to arrive adds the partials up and writes the 44 sums and, behind
+// them, the call's sequence number into host-mapped memory; the host spins on that word (ws_reg_iterate).
+struct HostIterArgs
+{
+  PointArgs pts;
+  float T[16];        // column-major
+  int64_t *partials;  // [REG_BLOCKS][REG_SLOTS]
+  uint32_t *arrived;  // zero between launches
+  int64_t *sums_host; // host-mapped: 44 sums, then (at [44]) the sequence number
+  uint32_t seq;
+};
+
+__global__ __launch_bounds__(REG_THREADS) void reg_host_iter_kernel(HostIterArgs a)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  __shared__ int last_sh;
+  int64_t acc[REG_SLOTS];
+#pragma unroll
+  for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = a.T[i];
+  accumulate_points(a.pts, T, prefetch_points(a.pts), acc);
+  block_reduce32(acc, wave_part, red);
+  if (threadIdx.x < REG_SLOTS) publish_i64(&a.partials[(size_t)blockIdx.x * REG_SLOTS + threadIdx.x], red[threadIdx.x]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the write-through stores above have been acknowledged ...
+  __syncthreads();                                  // ... for all 32 lanes that made them
+  if (threadIdx.x == 0) last_sh = __hip_atomic_fetch_add(a.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!last_sh) return;
+  sum_partials<true>(a.partials, wave_part, red);
+  if (threadIdx.x == 0)
+  {
+    int64_t sums[44];
+    expand_sums(red, sums);
+#pragma unroll
+    for (int k = 0; k < 44; ++k) __hip_atomic_store(&a.sums_host[k], sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.sums_host[44], (int64_t)a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // test entry: the wave solver alone, one wave per system (A row-major 6x6, b) -> x, status
 __global__ __launch_bounds__(64) void solve6_test_kernel(const double *A, const double *b, double *x, int32_t *status)
 {
@@ -1822,6 +1869,23 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_accumulate_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   hipLaunchKernelGGL(reg_sum_kernel, dim3(1), dim3(REG_THREADS), 0, ctx->stream, (const int64_t *)r->partials, a.state, sums_dev);
+  prof_end(ctx, WS_K_REG);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+int launch_reg_host_iter(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, uint32_t seq)
+{
+  ws_context *ctx = r->ctx;
+  HostIterArgs a;
+  a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  for (int i = 0; i < 16; ++i) a.T[i] = T[i];
+  a.partials = r->partials;
+  a.arrived = r->shard_arrived + 16; // (a word of its own, a cache line away from reg_shard_kernel's)
+  a.sums_host = r->iter_host_dev;
+  a.seq = seq;
+  prof_begin(ctx, WS_K_REG);
+  hipLaunchKernelGGL(reg_host_iter_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;

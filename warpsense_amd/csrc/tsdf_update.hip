@@ -657,6 +657,26 @@ typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate 
 // an id waiting.  All of it modulo 256: flushed, rounded down to 32, and covered are never more than 256 apart.
 constexpr int WT_BITS = 8, WT_SLOTS = 1 << WT_BITS;
 constexpr uint32_t WT_SLOT_LIMIT = 224; // tiles in the table before the wave publishes and starts over
+#if WS_TAIL_RUNS
+// Round 5: a (wave, tile) pair takes its sub-chunks in RUNS of four (128 records) instead of one at a time: the record of rank
+// 0 mod 128 opens a run of four consecutive local numbers and leaves the run's POOL id in the tile's slot (two places: one round
+// of puts spans two runs at most), every other record reads that one word: probe, counter, run -- three LDS operations per
+// record instead of five (sub_of -> blk), and the branch that opens something runs in one round of four.  A pair with 10
+// records holds four sub-chunks and publishes one: the pool has the room (0.6 M of 3.4 M sub-chunks used per benchmark scan).
+constexpr uint32_t WT_RING = 1024;        // local numbers in the ring (a round can open 64 runs = 256 of them)
+constexpr uint32_t WT_LOCAL_LIMIT = 640;  // local numbers in flight before the wave publishes
+struct WaveTab
+{
+  uint32_t key[WT_SLOTS];
+  uint32_t cnt[WT_SLOTS];
+  uint32_t run[WT_SLOTS][2];          // pool id of the first sub-chunk of the tile's run rank >> 7, modulo 2 (wave_flush: [0] = first entry number)
+  uint16_t owner[WT_RING / 4];        // run (local number >> 2) -> slot | (rank >> 7) << 8: what the flush publishes
+  uint32_t blk[WT_RING / 32];
+  uint32_t n_local, n_slots, flushed, covered;
+  uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
+};
+#else
+constexpr uint32_t WT_RING = 256;
 constexpr uint32_t WT_LOCAL_LIMIT = 160; // sub-chunks in flight before it does
 struct WaveTab
 {
@@ -668,6 +688,7 @@ struct WaveTab
   uint32_t n_local, n_slots, flushed, covered;
   uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
 };
+#endif
 
 __device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile, bool &fresh)
 {
@@ -730,7 +751,11 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
         if (c[u])
         {
           if (j0[u] >= (1u << 19) - 256u) raise_error(a.counters, a.status, ERR_INTERNAL); // (half a million entries of one tile: never)
+#if WS_TAIL_RUNS
+          wt.run[s][0] = j0[u]; // (the run ids have done their work: the sub-chunks below are found through owner / blk)
+#else
           wt.cnt[s] = c[u] | (j0[u] << 13);
+#endif
         }
       }
       // (a lane's place among the firsts travels in seven bits: a flush of more than 127 new tiles takes the list places one by one)
@@ -760,15 +785,24 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
     const uint32_t nl = n_local - flushed;
     for (uint32_t q = lr; q < nl; q += na)
     {
-      const uint32_t gl = (flushed + q) & 255u;
+      const uint32_t gl = (flushed + q) & (WT_RING - 1u);
+#if WS_TAIL_RUNS
+      const uint32_t o = wt.owner[gl >> 2];
+      const uint32_t s = o & 255u, sub = ((o >> 8) << 2) + (gl & 3u);
+#else
       const uint32_t o = wt.owner[gl];
       const uint32_t s = o & 255u, sub = o >> 8;
+#endif
+#if WS_TAIL_RUNS
+      const uint32_t c = wt.cnt[s], j0 = wt.run[s][0];
+#else
       const uint32_t cj = wt.cnt[s];
       const uint32_t c = cj & 8191u, j0 = cj >> 13;
+#endif
       const uint32_t ns = (c + (uint32_t)SUB_RECS - 1u) >> SUB_BITS;
       const uint32_t fill = sub + 1u == ns ? c - (sub << SUB_BITS) : (uint32_t)SUB_RECS;
-      const uint32_t base = wt.blk[(gl >> 5) & 7u];
-      if (base != SUB_LOST) entry_publish(a, wt.key[s], j0 + sub, make_entry(base + (gl & 31u), fill));
+      const uint32_t base = wt.blk[(gl >> 5) & (WT_RING / 32u - 1u)];
+      if (sub < ns && base != SUB_LOST) entry_publish(a, wt.key[s], j0 + sub, make_entry(base + (gl & 31u), fill)); // (sub >= ns: the unused rest of a run)
     }
     asm volatile("" ::: "memory");
   }
@@ -795,26 +829,28 @@ __device__ __forceinline__ uint32_t wave_room(const ScatterArgs &a, WaveTab &wt)
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll((long long)act) - 1;
   uint32_t nl = wt.n_local, ns = wt.n_slots, fl = wt.flushed, cov = wt.covered;
-  if (nl - fl + 64u > WT_LOCAL_LIMIT || ns + 64u > WT_SLOT_LIMIT || (cov - nl < 64u && cov + SUB_REFILL - (fl & ~31u) > 256u))
+  constexpr uint32_t PER_PUT = WS_TAIL_RUNS ? 4u : 1u; // local numbers a put can open
+  constexpr uint32_t NEED = 64u * PER_PUT;             // ... a round of 64 puts
+  if (nl - fl + NEED > WT_LOCAL_LIMIT || ns + 64u > WT_SLOT_LIMIT || (cov - nl < NEED && cov + NEED - (fl & ~31u) > WT_RING))
   {
     wave_flush(a, wt);
     fl = nl;
     ns = 0;
   }
-  while (cov - nl < 64u)
+  while (cov - nl < NEED)
   {
-    // (flushed above if the ring of eight runs had no place for another)
+    // (flushed above if the ring of blocks had no place for more)
     uint32_t b = 0;
     if (lane == leader)
     {
       b = pool_grab(a, SUB_REFILL);
-      wt.blk[(cov >> 5) & 7u] = b;
+      for (uint32_t i = 0; i < SUB_REFILL; i += 32u) wt.blk[((cov + i) >> 5) & (WT_RING / 32u - 1u)] = b == SUB_LOST ? SUB_LOST : b + i;
       wt.covered = cov + SUB_REFILL;
     }
     cov += SUB_REFILL;
   }
   asm volatile("" ::: "memory");
-  const uint32_t r0 = WT_LOCAL_LIMIT - (nl - fl), r1 = WT_SLOT_LIMIT - ns, r2 = cov - nl;
+  const uint32_t r0 = (WT_LOCAL_LIMIT - (nl - fl)) / PER_PUT, r1 = WT_SLOT_LIMIT - ns, r2 = (cov - nl) / PER_PUT;
   return min(r0, min(r1, r2));
 }
 
@@ -832,6 +868,23 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
   // (the lanes of a wave mostly hit ONE counter, and the LDS takes such atomics one lane at a time: the old value is used for
   // everything -- no second atomic on the word)
   const uint32_t rank = atomicAdd(&wt.cnt[s], 1u);
+#if WS_TAIL_RUNS
+  const uint32_t rno = rank >> 7; // the tile's run of four sub-chunks this record belongs to
+  const bool opens = (rank & 127u) == 0;
+  if (opens)
+  {
+    const uint32_t g = atomicAdd(&wt.n_local, 4u); // (a multiple of four: a run never straddles a block of 32 ids)
+    const uint32_t base = wt.blk[(g >> 5) & (WT_RING / 32u - 1u)];
+    wt.run[s][rno & 1u] = base == SUB_LOST ? SUB_LOST : base + (g & 31u);
+    wt.owner[(g & (WT_RING - 1u)) >> 2] = (uint16_t)((uint32_t)s | (rno << 8));
+  }
+  // (the other lanes' words: read AFTER the branch above has run for the lanes that took it -- without the fence the compiler
+  // forwards the stored value within the lane and is free to let the lanes that only read go first)
+  asm volatile("" ::: "memory");
+  const uint32_t pid = wt.run[s][rno & 1u];
+  if (pid != SUB_LOST) a.rec[((size_t)(pid + ((rank >> SUB_BITS) & 3u)) << SUB_BITS) + (rank & (uint32_t)(SUB_RECS - 1))] = rec;
+  return (opens ? 1u : 0u) | (fresh ? 2u : 0u);
+#else
   const uint32_t sub = rank >> SUB_BITS, pos = rank & (uint32_t)(SUB_RECS - 1);
   if (pos == 0)
   {
@@ -839,10 +892,12 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
     wt.sub_of[s][sub & 3u] = (uint8_t)g;
     wt.owner[g & 255u] = (uint16_t)((uint32_t)s | (sub << 8));
   }
+  asm volatile("" ::: "memory");
   const uint32_t gl = wt.sub_of[s][sub & 3u];
   const uint32_t base = wt.blk[(gl >> 5) & 7u];
   if (base != SUB_LOST) a.rec[((size_t)(base + (gl & 31u)) << SUB_BITS) + pos] = rec;
   return (pos == 0 ? 1u : 0u) | (fresh ? 2u : 0u);
+#endif
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter

@@ -114,9 +114,20 @@ __host__ __device__ inline bool rec_negative(uint64_t rec, uint32_t fan_mask, ui
 // places in the tile's entry table, tile_ent[tile][j] = id << 5 | (records - 1).  Entries beyond TILE_DIRECT go through a
 // hash (tile, j) -> entry + 1.  Nobody ever waits for anybody: the resolve -- a later kernel -- reads what is there.
 constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 128;
-constexpr uint32_t SUB_WAVE_FIRST = 128;            // sub-chunks a wave of the tail march starts with
+#ifndef WS_TAIL_RUNS
+#define WS_TAIL_RUNS 0 // 1: a (wave, tile) pair of the tail march takes its sub-chunks in runs of four (WaveTab, tsdf_update.hip): 133 against 135 us for a static pool four times the size -- measured, not kept
+#endif
+#if WS_TAIL_RUNS
+#ifndef WS_TAIL_FIRST
+#define WS_TAIL_FIRST 512
+#endif
+constexpr uint32_t SUB_WAVE_FIRST = WS_TAIL_FIRST;  // sub-chunks a wave of the tail march starts with (a round of 64 records can open 64 runs)
+constexpr uint32_t SUB_REFILL = 256;                // and what a wave asks for when it runs low
+#else
+constexpr uint32_t SUB_WAVE_FIRST = 128;
+constexpr uint32_t SUB_REFILL = 32;
+#endif
 constexpr uint32_t SUB_WG_BLOCK = 4 * SUB_WAVE_FIRST; // ... taken from the pool by its workgroup in one request
-constexpr uint32_t SUB_REFILL = 32;                 // and what a wave asks for when it runs low
 constexpr uint32_t SUB_ID_LIMIT = (1u << 27) - 2u;  // an entry is id << 5 | fill - 1, + 1 in the hash
 // per-tile bytes, two planes in one allocation (tile_flag_plane_bytes apart): [0] "the free pass / an off-ray mark touched the
 // tile" (plain idempotent byte stores), [1] "the tile is on the scan's list" (it has records).  The resolve visits the listed
@@ -285,10 +296,12 @@ struct ws_reg
   int32_t *host_flag = nullptr;      // pinned + mapped: the device sets it when the loop has finished
   int32_t *host_flag_dev = nullptr;  // device view of host_flag
   int latest = 0;                    // state buffer holding the newest state
-  float *T_dev = nullptr;            // transform for ws_reg_iterate
   int64_t *sums_dev = nullptr;       // 44
   uint32_t *grid_bar = nullptr;      // two sets of {abort flag, counted group accumulators} of reg_loop_kernel (alternate launches)
-  uint32_t *shard_arrived = nullptr;  // arrival counter of reg_shard_kernel (zero between launches)
+  uint32_t *shard_arrived = nullptr;  // arrival counter of reg_shard_kernel (zero between launches); [16]: reg_host_iter_kernel's
+  int64_t *iter_host = nullptr;       // pinned + mapped: the 44 sums of ws_reg_iterate, then the call's sequence number
+  int64_t *iter_host_dev = nullptr;   // device view of iter_host
+  uint32_t iter_seq = 0;
   uint32_t loop_launches = 0;
   bool loop_sets_clear = false;
   int loop_mode = 0;                 // WS_REG_LOOP_*
@@ -362,6 +375,7 @@ int launch_reg_accumulate(ws_reg *r, const ws_map *m, const float *T_dev_or_null
 int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, int32_t k);
 int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev, int apply);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
+int launch_reg_host_iter(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, uint32_t seq);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init, bool peers = false, size_t first = 0, size_t count = 0);
