@@ -150,8 +150,22 @@ int run(const char *name, int xcds, int first_sleep)
   return 0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+  if (argc > 1 && argv[1][0] == 'g')
+  {
+    // the number of group accumulators for all 256 workgroups: fewer adds per word against more lines to poll
+    for (int sl : {14, 28})
+    {
+      printf("first poll after %d x 64 clocks, 8 XCDs, coherent level\n", sl);
+      if (run<0, 2>("2 groups of 128", 8, sl)) return 1;
+      if (run<0, 4>("4 groups of 64", 8, sl)) return 1;
+      if (run<0, 8>("8 groups of 32  [the loop today]", 8, sl)) return 1;
+      if (run<0, 16>("16 groups of 16", 8, sl)) return 1;
+      if (run<0, 32>("32 groups of 8", 8, sl)) return 1;
+    }
+    return 0;
+  }
   for (int sl : {0, 14, 28})
   {
     printf("first poll after %d x 64 clocks\n", sl);

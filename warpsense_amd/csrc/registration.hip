@@ -1210,7 +1210,10 @@ __global__ __launch_bounds__(REG_THREADS) void reg_iter_kernel(IterArgs a)
 // Safe against overtaking: a workgroup can only complete the poll of iteration i + 1 after every workgroup has added
 // for i + 1, i.e. after every workgroup has finished reading iteration i, so nobody adds into a parity buffer (i + 2)
 // that is still being read.
-constexpr int REG_GROUPS = 8;
+#ifndef WS_REG_GROUPS
+#define WS_REG_GROUPS 8 // (round 5, in the loop itself, first poll after 16 / 26 / 36 x 64 clocks: 4 groups 5.71 / 5.20 / 4.91 us per iteration, 8 groups - / 4.39 / -, 16 groups 6.82 / 5.97 / -)
+#endif
+constexpr int REG_GROUPS = WS_REG_GROUPS;
 constexpr int REG_WORDS = 2 * REG_SLOTS; // low halves, then high halves
 constexpr uint64_t REG_COUNT_ONE = 1ull << 56;
 constexpr uint64_t REG_SUM_MASK = REG_COUNT_ONE - 1;
