@@ -327,6 +327,8 @@ def main():
             # the resident loop is ONE launch for all iterations; per-iteration launches report one launch each
             kernels["reg_loop"] = {"avg_us": 1000.0 * ms / cnt, "launches": cnt, "iterations": reg_its,
                                    "us_per_iteration": 1000.0 * ms / max(reg_its, 1), "bytes_per_iteration": 40 * n,
+                                   "iterations_per_s": max(reg_its, 1) / (ms * 1e-3) if ms else None,
+                                   "achieved_GBps": 40 * n * max(reg_its, 1) / (ms * 1e-3) / 1e9 if ms else None,
                                    "note": "separate pass; latency-bound (SURVEY.md §8d: no roofline gate)"}
 
     # the multi-GPU code path (points sharded, RCCL all-reduce of the 44 sums each iteration, HIP-graph batches) on ONE
