@@ -1400,19 +1400,33 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // targets as marks in the second byte plane: 10.8 M records instead of 14.4 M and a tail march of 146 instead of 187 us, but
 // a free pass of 195-230 instead of 123 us whatever the lane layout: out there neighbouring rays are more than a voxel
 // apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
+#ifndef WS_FREE_SORTED
+#define WS_FREE_SORTED 0 // 1: the rays in the tail march's order, far cells first (a shorter end of the launch, but 109 against 103 us: rays sorted by where they END are not neighbours on the way there)
+#endif
 #ifndef WS_FREE_WGS
 #define WS_FREE_WGS 6 // workgroups per CU the register budget is set for (round 5's walk over column changes, 5 / 6 / 7 / 8: 105 / 103 / 102 / 120 us;
                       // six: 80 VGPRs, one spilled outside the loops; seven: 72 with 15 spilled; round 4's stepped walk: 121 / 120 / 117 / 147)
 #endif
 __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
 {
+#ifdef WS_FREE_TIMING
+  const long long t_free_begin = wall_clock64();
+#endif
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
 #if !WS_FREE_DDA
   __shared__ u32x4 s_queue[4 * FREE_QCAP];
 #endif
   __shared__ uint32_t s_keyed[4];
-  // (the workgroups in descending order of their rays' lengths instead of scan order: no change, measured -- this pass has no idle tail)
+#if WS_FREE_SORTED
+  // The rays in the tail march's order (sorted by where they end, the FAR cells first) instead of scan order: the free-space
+  // part of a ray is as long as the ray, a workgroup of far rays takes 95 us and one of near rays 36, and in scan order the
+  // launch spent its second half running empty -- 1536 resident workgroups until the 2048 were handed out at 60 us, 800 at
+  // 70 % of the span, 210 at 90 % (tools/free_timing.py).  Longest first, the ones that start last are the short ones.
+  const uint32_t slot = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
+  const uint32_t ix = slot < a.az_off[AZ_BINS] ? a.ray_order[slot] : 0xffffffffu; // (rays that are not in the order have no steps)
+#else
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
+#endif
   const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
   const int lane = threadIdx.x & 63;
   uint32_t n_keyed = 0;
@@ -1683,6 +1697,11 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
   {
     const uint32_t all = s_keyed[0] + s_keyed[1] + s_keyed[2] + s_keyed[3];
     if (all) atomicAdd(&a.counters->last_free_keyed, all);
+#ifdef WS_FREE_TIMING
+    // (instead of the tail march's statistics: 10 ns ticks this workgroup took, and when it started -- tools/free_timing.py)
+    a.tail_stats[blockIdx.x] = (uint32_t)(wall_clock64() - t_free_begin);
+    a.tail_stats[WS_TAIL_STATS + blockIdx.x] = (uint32_t)t_free_begin;
+#endif
   }
 }
 
@@ -1795,6 +1814,9 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
 
 #ifndef WS_RESOLVE_BRANCHFREE
 #define WS_RESOLVE_BRANCHFREE 1 // pass 1 of the fold without a branch per record (111.8 -> 110.6 us)
+#endif
+#ifndef WS_RESOLVE_PRIO
+#define WS_RESOLVE_PRIO 2
 #endif
 #ifndef WS_RES_MAXR
 #define WS_RES_MAXR 8
@@ -2021,18 +2043,21 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   }
   // The tiles with records: the scan's tile list (the marches appended every tile at its first reservation), dealt out
   // evenly: workgroup b takes the entries b, b + G, ...
-  const uint32_t e0 = blockIdx.x;
+  const uint32_t e0 = blockIdx.x, e_end = n_list, ES = G;
   uint32_t n_mine = 0; // tiles this workgroup has folded
-  if (e0 < n_list)
+#ifdef WS_RESOLVE_TIMING
+  uint32_t fill_sum = 0;
+#endif
+  if (e0 < e_end)
   {
-  const uint32_t last = n_list - 1;
+  const uint32_t last = e_end - 1;
   // pipeline: tile i is processed while the voxel bytes / entry table of tiles i+1 and i+2, the list entries up to i+3
   // and (from the middle of the iteration on) the records of tile i+1 are in flight
-  TileEntry te_n2 = a.tile_list[min(e0 + 2 * G, last)], te_n3 = te_n2;
+  TileEntry te_n2 = a.tile_list[min(e0 + 2 * ES, last)], te_n3 = te_n2;
   uint32_t tile_cur, tile_n1;
   TilePre p_cur, p_n1, p_n2;
   {
-    const TileEntry t0 = a.tile_list[e0], t1 = a.tile_list[min(e0 + G, last)];
+    const TileEntry t0 = a.tile_list[e0], t1 = a.tile_list[min(e0 + ES, last)];
     request(t0, p_cur);
     request(t1, p_n1);
     tile_cur = t0.tile;
@@ -2041,7 +2066,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   bool cached = fetch_records(p_cur), cached_next = false;
   u32x4 ex_cur = ex_next;
   auto issue_next = [&](uint32_t e) {
-    te_n3 = a.tile_list[min(e + 3 * G, last)];
+    te_n3 = a.tile_list[min(e + 3 * ES, last)];
     request(te_n2, p_n2);
     cached_next = fetch_records(p_n1);
   };
@@ -2054,9 +2079,34 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   init_lds();
   __syncthreads();
 
-  for (uint32_t e = e0; e < n_list; e += G)
+  for (uint32_t e = e0; e < e_end; e += ES)
   {
+#if WS_RESOLVE_PRIO
+    {
+      // The five workgroups of a compute unit start together with the same amount of work, and the SIMDs serve the OLDEST ready
+      // wave first: the workgroups finished one after the other (65 ... 115 us, tools/resolve_where.py: the spread is inside the
+      // compute units, not between them, and has nothing to do with the tiles a workgroup got), the compute unit ran its last
+      // 25 us with one or two workgroups.  Now the issue priority goes round: a workgroup changes its priority with every tile,
+      // the five of a compute unit (b, b + 256, ... in dispatch order) start at different places of the cycle -- spread inside a
+      // compute unit 9.7 -> 4.9 us, the launch 110 -> 104 us.  (Priority by progress -- a quarter of the tiles done, one level
+      // down: 105; time slices of 2.56 us on the shared clock: 106.)
+#if WS_RESOLVE_PRIO == 1
+      const uint32_t n_total = (e_end - e0 + ES - 1u) / ES;
+      const uint32_t q = min(3u, (n_mine * 4u) / max(n_total, 1u));
+      const uint32_t prio = 3u - q;
+#else
+      const uint32_t prio = (n_mine + blockIdx.x / 256u) & 3u;
+#endif
+      if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+      else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+      else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     n_mine += 1;
+#ifdef WS_RESOLVE_TIMING
+    fill_sum += p_cur.fill;
+#endif
     const TilePre p = p_cur;
     const uint32_t tile = tile_cur, nsub_real = p.fill, fill = aborted ? 0u : p.fill; // (an aborted scan: the entries may be anything)
     const int nz = p.nz;
@@ -2313,6 +2363,10 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   write_back(post);
   } // listed tiles
 
+#ifdef WS_RESOLVE_TIMING
+  const long long t_listed = wall_clock64();
+  uint32_t n_unlisted_mine = 0;
+#endif
   // ---- Tiles that are NOT on the list: no records, only marks of the free pass or of off-ray +tau candidates in the byte
   // planes -- (tau, +64) / (tau, -64) where a mark is, nothing to fold.  They are found by scanning the per-tile flag planes
   // (a byte per tile; the marches only ever STORE there: no atomic, no waiting in their loops), 16 tiles per thread and step,
@@ -2345,6 +2399,9 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       }
       __syncthreads();
       const uint32_t n_found = s_unres[0];
+#ifdef WS_RESOLVE_TIMING
+      n_unlisted_mine += n_found;
+#endif
       if (n_found && threadIdx.x == 0) atomicAdd(&a.counters->last_unlisted, n_found);
       for (uint32_t i = 0; i < n_found; ++i)
       {
@@ -2406,6 +2463,21 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     // (instead of the statistics: 10 ns ticks this workgroup was busy, and when it started)
     a.resolve_stats[2 * blockIdx.x + 0] = (uint32_t)(wall_clock64() - t_begin);
     a.resolve_stats[2 * blockIdx.x + 1] = (uint32_t)t_begin;
+#if WS_RESOLVE_TIMING == 4
+    {
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      a.resolve_stats[2 * blockIdx.x + 1] = ((xcc & 0xfu) << 16) | (hw & 0xffffu); // where the workgroup ran
+    }
+#endif
+#if WS_RESOLVE_TIMING == 3
+    a.resolve_stats[2 * blockIdx.x + 1] = (uint32_t)(t_listed - t_begin) | (min(n_unlisted_mine, 4095u) << 20); // ticks in the listed tiles | unlisted tiles found
+#endif
+#if WS_RESOLVE_TIMING == 2
+    // (what the workgroup's tiles were made of, for a fit of its busy time: sub-chunks << 16 | contested voxels)
+    a.resolve_stats[2 * blockIdx.x + 1] = (min(fill_sum, 65535u) << 16) | min(s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3], 65535u);
+#endif
 #endif
   }
 }
