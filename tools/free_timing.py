@@ -25,7 +25,7 @@ words = 3 * 65536 + 8192
 out = np.zeros(words, dtype=np.uint32)
 rc = t._L.ws_debug_block_stats(t.handle, out.ctypes.data_as(C.c_void_p), words)
 assert rc == 0
-n = 2048
+n = int(os.environ.get("WS_FREE_BLOCKS", "2048"))
 dur, start = out[:n].astype(np.int64), out[65536:65536 + n].astype(np.int64)
 start = (start - start.min()) & 0xffffffff
 end = start + dur
