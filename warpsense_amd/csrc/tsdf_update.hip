@@ -81,13 +81,8 @@ struct ScatterArgs
 // 264 bytes of kernel arguments instead of 256 cost reg_loop_kernel 30 % (registration.hip); the same bound here
 static_assert(sizeof(ScatterArgs) <= 256, "ScatterArgs: more than 256 bytes of kernel arguments");
 
-#ifdef WS_REC_CONST // (timing experiment: the round-4 split 20 | 13 | 5 as compile-time constants)
-#define REC_S(a) 13
-#define REC_F(a) 5
-#else
 #define REC_S(a) ((int32_t)((a).rec_fmt & 0xffu))
 #define REC_F(a) ((int32_t)((a).rec_fmt >> 8))
-#endif
 constexpr uint8_t VOX_KEYED = 1, VOX_TOUCHED = 2;
 constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second byte plane (stored there as 1)
 constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
@@ -101,35 +96,11 @@ constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 #ifndef WS_SORT_BLOCKS
 #define WS_SORT_BLOCKS 64
 #endif
-#ifndef WS_TAIL_DDA
-#define WS_TAIL_DDA 0 // 1: the tail march walks from column change to column change too (ws_dda.h).  Measured and NOT kept: 149 us against 133 --
-                      // a part of a tail is ~11 samples, the walk's state and per-ray constants cost 96 registers with 11 spilled, and its
-                      // iterations run 82 % full (tools/lane_model.py) where the stepped samples fill their batches to 94 %
-#endif
-#ifndef WS_FREE_DDA
-#define WS_FREE_DDA 1 // 1: the free pass walks from column change to column change (ws_dda.h); 0: rounds 3-4's sample phase + LDS queue
-#endif
-#ifndef WS_FREE_STATIC
-#define WS_FREE_STATIC 0 // 1: the free pass issues the same vector memory instructions in every step (two slots, stores into the slack)
-#endif
-#ifndef WS_FREE_KO
-#define WS_FREE_KO 0 // knock-out builds for timing (results wrong): 1 no tile byte, 2 no voxel store, 4 no voxel load
-#endif
-#ifndef WS_FREE_PIPE
-#define WS_FREE_PIPE 1 // 1: the voxel byte of a free-space candidate is requested one emit phase before it is used (126 -> 122 us)
-#endif
-#ifndef WS_EL_BINS
-#define WS_EL_BINS 8
-#endif
 #ifndef WS_SORT_RINGS
 #define WS_SORT_RINGS 16 // (tail march at 4 / 8 / 16 / 32 / 64 rings: 146 / 146 / 146 / 154 / 152 us, set-up pass 36 / 31 / 28 / 30 / 28)
 #endif
-#ifndef WS_SORT_CELLS
-#define WS_SORT_CELLS 3
-#endif
-constexpr int AZ_ONLY_BINS = 1024, EL_BINS = WS_EL_BINS;
-static_assert(AZ_ONLY_BINS * EL_BINS == 64 * 64 * 2, "the cell sort uses the same 8192 bins");
-constexpr int AZ_BINS = AZ_ONLY_BINS * EL_BINS; // direction bins: azimuth major, elevation minor
+constexpr int AZ_BINS = 8192; // sort bins of the rays: polar cells around the sensor (ray_setup_block); bin AZ_BINS = ray without steps
+static_assert(AZ_BINS == 2 * 4096, "WS_SORT_RINGS rings x 4096 / WS_SORT_RINGS sectors, above / below the sensor");
 
 size_t ray_setup_bytes() { return sizeof(RaySetup); }
 
@@ -379,12 +350,10 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
     uint32_t bin = AZ_BINS;
     if (r.steps > 0)
     {
-#if WS_SORT_CELLS
       const int32_t cwx = (a.map.size[0] + 63) / 64, cwy = (a.map.size[1] + 63) / 64;
       int bx = (hvx - a.map.pos[0] + a.map.size[0] / 2) / cwx, by = (hvy - a.map.pos[1] + a.map.size[1] / 2) / cwy;
       bx = bx < 0 ? 0 : (bx > 63 ? 63 : bx);
       by = by < 0 ? 0 : (by > 63 ? 63 : by);
-#if WS_SORT_CELLS == 3
       // polar cells around the sensor -- WS_SORT_RINGS rings x 4096 / WS_SORT_RINGS sectors, above / below -- the FAR rings first: rays that end far away
       // carry fans (up to three times the records), and work items in descending order of their length leave the shortest
       // for the end of the launch, when the compute units run empty
@@ -398,26 +367,6 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
       bin = (uint32_t)(((RINGS - 1 - ring) * 2 + (hvz >= a.scanner_pos[2] ? 1 : 0)) * SECTORS + sec);
       (void)bx;
       (void)by;
-#elif WS_SORT_CELLS == 2
-      // Morton order of the cells, above / below the sensor as the major key: where rays are sparse a wave's 64 rays span
-      // several bins, and consecutive bins should still be neighbours in space
-      uint32_t mx = (uint32_t)bx, my = (uint32_t)by;
-      mx = (mx | (mx << 4)) & 0x0f0fu; mx = (mx | (mx << 2)) & 0x3333u; mx = (mx | (mx << 1)) & 0x5555u;
-      my = (my | (my << 4)) & 0x0f0fu; my = (my | (my << 2)) & 0x3333u; my = (my | (my << 1)) & 0x5555u;
-      bin = (hvz >= a.scanner_pos[2] ? 4096u : 0u) + ((mx << 1) | my);
-#else
-      bin = (uint32_t)((bx * 64 + by) * 2 + (hvz >= a.scanner_pos[2] ? 1 : 0));
-#endif
-#else
-      const float az = atan2f((float)r.dy, (float)r.dx); // [-pi, pi]
-      int b = (int)((az + 3.14159265f) * ((float)AZ_ONLY_BINS / 6.2831853f));
-      b = b < 0 ? 0 : (b >= AZ_ONLY_BINS ? AZ_ONLY_BINS - 1 : b);
-      // elevation: sin(el) = dz / distance in [-1, 1]; LiDARs use the middle of that range: clamp +-0.5
-      float se = (float)r.dz / (float)r.distance;
-      int e = (int)((se + 0.5f) * (float)EL_BINS);
-      e = e < 0 ? 0 : (e >= EL_BINS ? EL_BINS - 1 : e);
-      bin = (uint32_t)(b * EL_BINS + e);
-#endif
     }
     r.pad |= (int32_t)(bin << 1); // bits 1 .. 14 (RAY_SIMPLE is bit 30)
     my_bin = bin;
@@ -545,9 +494,6 @@ __device__ __forceinline__ void raise_abort(const ScatterArgs &a)
 // under load (measured: 25 000 of them, one per free-space record, made the free pass 1.16 ms instead of 0.12), so the
 // shared counters are for the exceptions.
 constexpr uint32_t FREE_WAVE_FIRST = WS_FREE_FIRST; // (subs_needed() counts them)
-#ifndef WS_TAIL_SPLIT
-#define WS_TAIL_SPLIT 2
-#endif
 __device__ __forceinline__ uint32_t tail_static_subs(const ScatterArgs &a) { return ((a.n + 63u) / 64u) * (uint32_t)WS_TAIL_SPLIT * SUB_WG_BLOCK; }
 __device__ __forceinline__ uint32_t free_static_subs(const ScatterArgs &a) { return ((a.n + 63u) / 64u) * 4u * FREE_WAVE_FIRST; }
 __device__ __forceinline__ bool pool_holds_static(const ScatterArgs &a)
@@ -628,14 +574,8 @@ __device__ __forceinline__ void append_single(const ScatterArgs &a, uint32_t til
 // ---------------------------------------------------------------------------------------------------------
 // ray tails -> records, straight into sub-chunks of their tiles
 // ---------------------------------------------------------------------------------------------------------
-#ifndef WS_TAIL_SPLIT
-#define WS_TAIL_SPLIT 2
-#endif
 #ifndef WS_TAIL_WGS
 #define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (six: 80 VGPRs, 16 of them spilled, 234 instead of 187 us)
-#endif
-#ifndef WS_TAIL_BLIND
-#define WS_TAIL_BLIND 1 // off-ray candidates of value +tau as marks in the second byte plane instead of records (2.1 M of the benchmark scan's 14.4 M)
 #endif
 constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
@@ -657,25 +597,6 @@ typedef uint32_t __attribute__((aligned(1))) u32_a1; // four consecutive vstate 
 // an id waiting.  All of it modulo 256: flushed, rounded down to 32, and covered are never more than 256 apart.
 constexpr int WT_BITS = 8, WT_SLOTS = 1 << WT_BITS;
 constexpr uint32_t WT_SLOT_LIMIT = 224; // tiles in the table before the wave publishes and starts over
-#if WS_TAIL_RUNS
-// Round 5: a (wave, tile) pair takes its sub-chunks in RUNS of four (128 records) instead of one at a time: the record of rank
-// 0 mod 128 opens a run of four consecutive local numbers and leaves the run's POOL id in the tile's slot (two places: one round
-// of puts spans two runs at most), every other record reads that one word: probe, counter, run -- three LDS operations per
-// record instead of five (sub_of -> blk), and the branch that opens something runs in one round of four.  A pair with 10
-// records holds four sub-chunks and publishes one: the pool has the room (0.6 M of 3.4 M sub-chunks used per benchmark scan).
-constexpr uint32_t WT_RING = 1024;        // local numbers in the ring (a round can open 64 runs = 256 of them)
-constexpr uint32_t WT_LOCAL_LIMIT = 640;  // local numbers in flight before the wave publishes
-struct WaveTab
-{
-  uint32_t key[WT_SLOTS];
-  uint32_t cnt[WT_SLOTS];
-  uint32_t run[WT_SLOTS][2];          // pool id of the first sub-chunk of the tile's run rank >> 7, modulo 2 (wave_flush: [0] = first entry number)
-  uint16_t owner[WT_RING / 4];        // run (local number >> 2) -> slot | (rank >> 7) << 8: what the flush publishes
-  uint32_t blk[WT_RING / 32];
-  uint32_t n_local, n_slots, flushed, covered;
-  uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
-};
-#else
 constexpr uint32_t WT_RING = 256;
 constexpr uint32_t WT_LOCAL_LIMIT = 160; // sub-chunks in flight before it does
 struct WaveTab
@@ -688,7 +609,6 @@ struct WaveTab
   uint32_t n_local, n_slots, flushed, covered;
   uint32_t n_rec, n_groups; // statistics: records (general walk), (flush, tile) groups
 };
-#endif
 
 __device__ __forceinline__ int wt_insert(WaveTab &wt, uint32_t tile, bool &fresh)
 {
@@ -751,11 +671,7 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
         if (c[u])
         {
           if (j0[u] >= (1u << 19) - 256u) raise_error(a.counters, a.status, ERR_INTERNAL); // (half a million entries of one tile: never)
-#if WS_TAIL_RUNS
-          wt.run[s][0] = j0[u]; // (the run ids have done their work: the sub-chunks below are found through owner / blk)
-#else
           wt.cnt[s] = c[u] | (j0[u] << 13);
-#endif
         }
       }
       // (a lane's place among the firsts travels in seven bits: a flush of more than 127 new tiles takes the list places one by one)
@@ -786,19 +702,10 @@ __device__ __forceinline__ void wave_flush(const ScatterArgs &a, WaveTab &wt)
     for (uint32_t q = lr; q < nl; q += na)
     {
       const uint32_t gl = (flushed + q) & (WT_RING - 1u);
-#if WS_TAIL_RUNS
-      const uint32_t o = wt.owner[gl >> 2];
-      const uint32_t s = o & 255u, sub = ((o >> 8) << 2) + (gl & 3u);
-#else
       const uint32_t o = wt.owner[gl];
       const uint32_t s = o & 255u, sub = o >> 8;
-#endif
-#if WS_TAIL_RUNS
-      const uint32_t c = wt.cnt[s], j0 = wt.run[s][0];
-#else
       const uint32_t cj = wt.cnt[s];
       const uint32_t c = cj & 8191u, j0 = cj >> 13;
-#endif
       const uint32_t ns = (c + (uint32_t)SUB_RECS - 1u) >> SUB_BITS;
       const uint32_t fill = sub + 1u == ns ? c - (sub << SUB_BITS) : (uint32_t)SUB_RECS;
       const uint32_t base = wt.blk[(gl >> 5) & (WT_RING / 32u - 1u)];
@@ -829,7 +736,7 @@ __device__ __forceinline__ uint32_t wave_room(const ScatterArgs &a, WaveTab &wt)
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll((long long)act) - 1;
   uint32_t nl = wt.n_local, ns = wt.n_slots, fl = wt.flushed, cov = wt.covered;
-  constexpr uint32_t PER_PUT = WS_TAIL_RUNS ? 4u : 1u; // local numbers a put can open
+  constexpr uint32_t PER_PUT = 1u; // local numbers (sub-chunks) a put can open
   constexpr uint32_t NEED = 64u * PER_PUT;             // ... a round of 64 puts
   if (nl - fl + NEED > WT_LOCAL_LIMIT || ns + 64u > WT_SLOT_LIMIT || (cov - nl < NEED && cov + NEED - (fl & ~31u) > WT_RING))
   {
@@ -868,23 +775,6 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
   // (the lanes of a wave mostly hit ONE counter, and the LDS takes such atomics one lane at a time: the old value is used for
   // everything -- no second atomic on the word)
   const uint32_t rank = atomicAdd(&wt.cnt[s], 1u);
-#if WS_TAIL_RUNS
-  const uint32_t rno = rank >> 7; // the tile's run of four sub-chunks this record belongs to
-  const bool opens = (rank & 127u) == 0;
-  if (opens)
-  {
-    const uint32_t g = atomicAdd(&wt.n_local, 4u); // (a multiple of four: a run never straddles a block of 32 ids)
-    const uint32_t base = wt.blk[(g >> 5) & (WT_RING / 32u - 1u)];
-    wt.run[s][rno & 1u] = base == SUB_LOST ? SUB_LOST : base + (g & 31u);
-    wt.owner[(g & (WT_RING - 1u)) >> 2] = (uint16_t)((uint32_t)s | (rno << 8));
-  }
-  // (the other lanes' words: read AFTER the branch above has run for the lanes that took it -- without the fence the compiler
-  // forwards the stored value within the lane and is free to let the lanes that only read go first)
-  asm volatile("" ::: "memory");
-  const uint32_t pid = wt.run[s][rno & 1u];
-  if (pid != SUB_LOST) a.rec[((size_t)(pid + ((rank >> SUB_BITS) & 3u)) << SUB_BITS) + (rank & (uint32_t)(SUB_RECS - 1))] = rec;
-  return (opens ? 1u : 0u) | (fresh ? 2u : 0u);
-#else
   const uint32_t sub = rank >> SUB_BITS, pos = rank & (uint32_t)(SUB_RECS - 1);
   if (pos == 0)
   {
@@ -897,7 +787,6 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
   const uint32_t base = wt.blk[(gl >> 5) & 7u];
   if (base != SUB_LOST) a.rec[((size_t)(base + (gl & 31u)) << SUB_BITS) + pos] = rec;
   return (pos == 0 ? 1u : 0u) | (fresh ? 2u : 0u);
-#endif
 }
 
 // one work item: 64 direction-sorted rays x four of the 4 * TAIL_SPLIT parts of their tails (one part per wave): the scatter
@@ -998,7 +887,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       march_steps_direct(f, r, k0, k1, [&](int32_t kk, int32_t step, int32_t vx, int32_t vy, int32_t vz, int32_t value, bool positive) {
         const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
                       sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-        if (WS_TAIL_BLIND && mark && !positive && value == a.tau)
+        if (mark && !positive && value == a.tau)
         {
           mark_negative(sx, sy, sz, 0xffffffffu);
           return;
@@ -1021,50 +910,6 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     uint32_t cap_left = 0; // records the wave may put before it looks at its bookkeeping again (uniform)
     const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
     const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
-#if WS_TAIL_DDA
-    // The lane walks from one column change of its part of the tail to the next (ws_dda.h) instead of stepping every sample:
-    // a part is ~11 samples and ~6 column changes, the iterations of the wave drop from 235 k to 158 k per scan and an
-    // iteration loses the three stepped axes.  What a column change queues is what the stepped walk queued: the sample's
-    // position and its step.
-    const uint32_t adx = (uint32_t)(r.dx < 0 ? -r.dx : r.dx), ady = (uint32_t)(r.dy < 0 ? -r.dy : r.dy), adz = (uint32_t)(r.dz < 0 ? -r.dz : r.dz);
-    const int32_t smx = r.dx < 0 ? -1 : 0, smy = r.dy < 0 ? -1 : 0, smz = r.dz < 0 ? -1 : 0;
-    const int32_t sposx = (f.posx ^ smx) - smx, sposy = (f.posy ^ smy) - smy, sposz = (f.posz ^ smz) - smz;
-    DdaRay R;
-    R.M32 = (uint32_t)r.div_m;
-    R.sh = r.div_k - 32;
-    DdaAxis wx, wy;
-    wx.K = wy.K = wx.Ksp = wy.Ksp = DDA_NEVER;
-    wx.rho = wy.rho = wx.wq = wy.wq = wx.wr = wy.wr = 0;
-    wx.D = wy.D = 1;
-    uint32_t kk = DDA_NEVER; // the lane's next column change (ray step)
-    if (work)
-    {
-      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-      const int32_t len0 = 1 + kinit * half;
-      const uint32_t qx = dda_q(adx, len0, R), qy = dda_q(ady, len0, R);
-      dda_axis_init(wx, adx, sposx, qx, dist, res, half);
-      dda_axis_init(wy, ady, sposy, qy, dist, res, half);
-      kk = min(wx.K, wy.K);
-      // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71): a column change of its own in front
-      if (k0 == 0 && (div_res(sposx + (int32_t)qx, f) != 0 || div_res(sposy + (int32_t)qy, f) != 0)) kk = 0;
-    }
-    auto push_at = [&](bool cand, uint32_t ks) {
-      const unsigned long long mask = __ballot(cand);
-      if (cand)
-      {
-        const int32_t len = 1 + (int32_t)ks * half;
-        const int32_t ax = sposx + (int32_t)dda_q(adx, len, R), ay = sposy + (int32_t)dda_q(ady, len, R), az = sposz + (int32_t)dda_q(adz, len, R);
-        u32x4 e;
-        e.x = (uint32_t)((ax ^ smx) - smx);
-        e.y = (uint32_t)((ay ^ smy) - smy);
-        e.z = (uint32_t)((az ^ smz) - smz);
-        e.w = ks | ((uint32_t)lane << 16);
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        queue[(qtail + rank) & (TAIL_QCAP - 1)] = e;
-      }
-      qtail += (uint32_t)__popcll(mask);
-    };
-#else
     AxisRun ix0, iy0, iz0;
     ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
     ix0.gap = 0x3fffffff;
@@ -1106,7 +951,6 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     int32_t todo = work ? k1 - k : 0;
     for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
     const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
-#endif
     // emit phase: up to 64 queued samples, one per lane
     auto emit_batch = [&]() {
       const uint32_t cnt = qtail - qhead;
@@ -1144,7 +988,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       }
       if (!__any(iter_steps > 0)) return;
       // the off-ray targets of a sample of value +tau are marks, not records
-      const bool blind = WS_TAIL_BLIND && mark && value == tau;
+      const bool blind = mark && value == tau;
       const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
                     lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
       auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
@@ -1197,35 +1041,6 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
         }
       }
     };
-#if WS_TAIL_DDA
-    auto walk = [&](auto special) {
-      while (__any(kk < (uint32_t)k1))
-      {
-        const bool active = kk < (uint32_t)k1;
-        push_at(active, kk);
-        const bool cx = active && wx.K == kk, cy = active && wy.K == kk;
-        if (cx)
-        {
-          const bool sp = decltype(special)::value && wx.Ksp == kk;
-          dda_axis_advance(wx);
-          if (decltype(special)::value && sp) dda_axis_after_zero_cell(wx, adx, sposx, dist, res);
-        }
-        if (cy)
-        {
-          const bool sp = decltype(special)::value && wy.Ksp == kk;
-          dda_axis_advance(wy);
-          if (decltype(special)::value && sp) dda_axis_after_zero_cell(wy, ady, sposy, dist, res);
-        }
-        if (active) kk = min(wx.K, wy.K);
-        // ---- emit phase: 64 queued samples, one per lane
-        if (qtail - qhead >= 64) emit_batch();
-      }
-    };
-    if (__any(work && (wx.Ksp != DDA_NEVER || wy.Ksp != DDA_NEVER)))
-      walk(std::true_type{});
-    else
-      walk(std::false_type{});
-#else
     for (int32_t it = 0; it < n_iter; ++it)
     {
       // ---- sample phase
@@ -1236,7 +1051,6 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // ---- emit phase: 64 queued samples, one per lane
       if (qtail - qhead >= 64) emit_batch();
     }
-#endif
     while (qtail != qhead) emit_batch();
   }
 #ifdef WS_TAIL_TIMING
@@ -1302,11 +1116,7 @@ __device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFr
   p.idx = valid ? (int64_t)(((uint64_t)p.tile << 10) + vbrick(p.local)) : 0; // unconditional (clamped) load: nothing waits for it here
   p.ix = ix;
   p.k = k;
-#if WS_FREE_KO & 4
-  p.b = 0; // (knock-out build for timing: no load of the voxel byte)
-#else
   p.b = a.vstate[p.idx];
-#endif
 }
 // the sub-chunks of the records the free pass makes (one each): a wave of the compacting walk keeps the rest of the 64 it
 // took from the pool (fb_next, fb_left: uniform); the general walk -- lanes in varying company -- asks for what it needs
@@ -1319,11 +1129,7 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
 {
   const uint32_t b = p.b;
   const bool keyed = p.valid && (b & VOX_KEYED);
-#ifdef WS_FREE_NOKEY
-  const unsigned long long km = 0; // (knock-out build for timing: the free pass without its records, 106 instead of 120 us)
-#else
   const unsigned long long km = __ballot(keyed);
-#endif
   if (km)
   {
     // the voxel also has ordered candidates (from the tails): this one, (tau, +64) at its place in the order, joins the
@@ -1366,16 +1172,12 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
   {
     // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
     // whose loads both saw 0 both store: idempotent.)
-#if !(WS_FREE_KO & 2)
     a.vstate[p.idx] = VOX_TOUCHED;
-#endif
     // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured; an atomic
     // that puts the tile on the scan's list at its first mark: 123 -> 355 us -- the load sees stale zeros from the L1 of its
     // compute unit all through the kernel, harmless for a byte store, a blocking round trip for a returning atomic)
-#if !(WS_FREE_KO & 1)
     if (TILE_MARK)
       if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
-#endif
   }
 }
 // both halves at once (general walk)
@@ -1400,9 +1202,6 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 // targets as marks in the second byte plane: 10.8 M records instead of 14.4 M and a tail march of 146 instead of 187 us, but
 // a free pass of 195-230 instead of 123 us whatever the lane layout: out there neighbouring rays are more than a voxel
 // apart, every candidate is a cold cache line, and THIS pass waits for the byte it loads where the tail march only stores.)
-#ifndef WS_FREE_SORTED
-#define WS_FREE_SORTED 0 // 1: the rays in the tail march's order, far cells first (a shorter end of the launch, but 109 against 103 us: rays sorted by where they END are not neighbours on the way there)
-#endif
 #ifndef WS_FREE_WGS
 #define WS_FREE_WGS 6 // workgroups per CU the register budget is set for (round 5's walk over column changes, 5 / 6 / 7 / 8: 105 / 103 / 102 / 120 us;
                       // six: 80 VGPRs, one spilled outside the loops; seven: 72 with 15 spilled; round 4's stepped walk: 121 / 120 / 117 / 147)
@@ -1413,20 +1212,8 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
   const long long t_free_begin = wall_clock64();
 #endif
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
-#if !WS_FREE_DDA
-  __shared__ u32x4 s_queue[4 * FREE_QCAP];
-#endif
   __shared__ uint32_t s_keyed[4];
-#if WS_FREE_SORTED
-  // The rays in the tail march's order (sorted by where they end, the FAR cells first) instead of scan order: the free-space
-  // part of a ray is as long as the ray, a workgroup of far rays takes 95 us and one of near rays 36, and in scan order the
-  // launch spent its second half running empty -- 1536 resident workgroups until the 2048 were handed out at 60 us, 800 at
-  // 70 % of the span, 210 at 90 % (tools/free_timing.py).  Longest first, the ones that start last are the short ones.
-  const uint32_t slot = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
-  const uint32_t ix = slot < a.az_off[AZ_BINS] ? a.ray_order[slot] : 0xffffffffu; // (rays that are not in the order have no steps)
-#else
   const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
-#endif
   const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
   const int lane = threadIdx.x & 63;
   uint32_t n_keyed = 0;
@@ -1442,11 +1229,6 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
   const bool work = k0 < k1;
   const int32_t tau = a.tau;
   const MarchFrame f = make_march_frame(a.scanner_pos, a.res, tau, a.map);
-#if !WS_FREE_DDA
-  // wave-private ring buffer: LDS operations of one wave are performed in order, so no barrier between push and pop
-  u32x4 *queue = s_queue + (threadIdx.x >> 6) * FREE_QCAP;
-  uint32_t qhead = 0, qtail = 0;
-#endif
   const int32_t res = f.res, half = f.half, dist = r.distance;
   if (!__all(!work || ((r.pad & RAY_SIMPLE) && r.distance >= 2)))
   {
@@ -1462,7 +1244,6 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
         free_emit(a, f, ix, k, vx, vy, vz, n_keyed);
       });
   }
-#if WS_FREE_DDA
   else if (__any(work))
   {
     // One loop iteration per CANDIDATE (ws_dda.h): the lane walks from one column change of its part of the ray to the next --
@@ -1492,12 +1273,6 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     wx.rho = wy.rho = wx.wq = wy.wq = wx.wr = wy.wr = 0;
     wx.D = wy.D = 1;
     uint32_t k = DDA_NEVER; // the lane's next candidate (ray step)
-#if WS_FREE_STATIC
-    uint32_t last_tile = 0xffffffffu; // the tile this lane has marked last
-    // (16 bytes of slack behind the voxel bytes of plane 0 and behind the tile bytes of plane 0: always zero)
-    const int64_t dummy_vox = (int64_t)a.ntx * a.nty * a.ntz * 1024;
-    const uint32_t dummy_tile = (uint32_t)(a.ntx * a.nty * a.ntz);
-#endif
     if (work)
     {
       const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
@@ -1527,27 +1302,9 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
       const int32_t c0x = (int32_t)(((dz * aivx) >> 15) ^ (uint32_t)sivx) - sivx, c0y = (int32_t)(((dz * aivy) >> 15) ^ (uint32_t)sivy) - sivy,
                     c0z = (int32_t)(((dz * aivz) >> 15) ^ (uint32_t)sivz) - sivz;
       const int32_t ex = ((ax ^ smx) - smx) - c0x, ey = ((ay ^ smy) - smy) - c0y, ez = ((az ^ smz) - smz) - c0z;
-#if WS_FREE_STATIC
-      free_request(a, f, req, active, ix, (int32_t)k, div_res(ex, f), div_res(ey, f), div_res(ez, f));
-      // ---- the candidate of the step before
-      {
-        const uint32_t b = fin.b;
-        if (__ballot(fin.valid && (b & VOX_KEYED)))
-          free_finish<true, false, false>(a, fin, n_keyed, fblock); // (rare: the candidate joins the tile's records)
-        const bool fresh = fin.valid && b == 0;
-        a.vstate[fresh ? fin.idx : dummy_vox] = fresh ? VOX_TOUCHED : (uint8_t)0;
-        // the byte that tells the resolve about a tile WITHOUT records: a lane stays in a tile (4 x 4 columns) for several
-        // candidates and marks it when it enters it (marking a tile that turns out to be listed is harmless: the resolve's
-        // scan ignores listed tiles)
-        const bool mark = fin.valid && fin.tile != last_tile;
-        a.tile_dirty[mark ? fin.tile : dummy_tile] = mark ? (uint8_t)1 : (uint8_t)0;
-        last_tile = mark ? fin.tile : last_tile;
-      }
-#else
       // (one slot: finish the candidate whose byte the previous step requested, then request this one's)
       free_finish<true, true>(a, req, n_keyed, fblock);
       free_request(a, f, req, active, ix, (int32_t)k, div_res(ex, f), div_res(ey, f), div_res(ez, f));
-#endif
       // ---- on to the next column change
       const bool cx = active && wx.K == k, cy = active && wy.K == k;
       if (cx)
@@ -1568,12 +1325,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     auto walk = [&](auto special) {
       while (__any(k < (uint32_t)k1))
       {
-#if WS_FREE_STATIC
-        step(special, pend2, pend);
-        step(special, pend, pend2); // (a lane that is through takes part without a candidate)
-#else
         step(special, pend, pend2);
-#endif
       }
     };
     // (a ray that crosses the cell around zero -- the one cell that is 2 res - 1 wide -- needs a look at every crossing: a
@@ -1585,110 +1337,6 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     // (after a pair of steps only `pend` holds a candidate that is not finished)
     free_finish<true, true>(a, pend, n_keyed, fblock);
   }
-#else
-  else if (__any(work))
-  {
-    // 64 queued candidates, one per lane (fewer at the very end): finish the batch whose voxel bytes were requested by the
-    // previous emit phase, then pop the next batch and request its bytes
-    FreePending pend;
-    // (this wave's own few sub-chunks at the top of the pool)
-    FreeBlock fblock = {a.sub_cap - (blockIdx.x * 4u + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
-    pend.valid = false;
-    pend.idx = 0;
-    pend.tile = pend.local = pend.ix = pend.b = 0;
-    pend.k = 0;
-    auto emit = [&]() {
-#if WS_FREE_PIPE
-      free_finish<true>(a, pend, n_keyed, fblock);
-#endif
-      const uint32_t cnt = qtail - qhead;
-      const uint32_t n = cnt < 64 ? cnt : 64;
-      u32x4 e = {0, 0, 0, 0};
-      const bool has = (uint32_t)lane < n;
-      if (has) e = queue[(qhead + (uint32_t)lane) & (FREE_QCAP - 1)];
-      const uint32_t src_ix = (uint32_t)__shfl((int)ix, (int)(e.w >> 16), 64);
-      free_request(a, f, pend, has, src_ix, (int32_t)(e.w & 0xffffu), div_res((int32_t)e.x, f), div_res((int32_t)e.y, f), div_res((int32_t)e.z, f));
-#if !WS_FREE_PIPE
-      free_finish<true>(a, pend, n_keyed, fblock);
-      pend.valid = false;
-#endif
-      qhead += n;
-    };
-    AxisRun ix0, iy0, iz0;
-    ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
-    ix0.gap = 0x3fffffff;
-    iy0 = ix0;
-    iz0 = ix0;
-    int32_t k = k0; // the next sample of this lane
-    if (work)
-    {
-      const int32_t kinit = k0 > 0 ? k0 - 1 : 0;
-      run_init(ix0, f, r, r.dx, f.posx, kinit, true);
-      run_init(iy0, f, r, r.dy, f.posy, kinit, true);
-      run_init(iz0, f, r, r.dz, f.posz, kinit, false);
-    }
-    AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
-    int32_t last_dz = -1, c0x = 0, c0y = 0, c0z = 0;
-    // target of the single on-ray candidate of a free-space sample (update_tsdf.cu:103-112 with iter_steps == 1): the sample
-    // minus the fan base offset, which changes every 328 mm of ray
-    auto push = [&](bool cand, bool cx, bool cy, int32_t dzl) {
-      const unsigned long long mask = __ballot(cand);
-      if (mask == 0) return;
-      if (cand)
-      {
-        const int32_t px = fast_proj(wx, cx, res), py = fast_proj(wy, cy, res), pz = fast_proj(wz, false, res);
-        const int32_t delta_z = dzl >> 15; // (DZ_PER_DISTANCE * len) >> 15, len > 0; no fan in the free-space part: delta_z * 2 < res
-        if (delta_z != last_dz)
-        {
-          last_dz = delta_z;
-          c0x = trunc_shift15(delta_z * r.ivx);
-          c0y = trunc_shift15(delta_z * r.ivy);
-          c0z = trunc_shift15(delta_z * r.ivz);
-        }
-        u32x4 e;
-        e.x = (uint32_t)(px - c0x);
-        e.y = (uint32_t)(py - c0y);
-        e.z = (uint32_t)(pz - c0z);
-        e.w = (uint32_t)k | ((uint32_t)lane << 16);
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        queue[(qtail + rank) & (FREE_QCAP - 1)] = e;
-      }
-      qtail += (uint32_t)__popcll(mask);
-    };
-    // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71) and is where the walk was initialised:
-    // taken out of the loop, so that every iteration below is "step, then test"
-    {
-      bool first = false;
-      if (work && k0 == 0)
-      {
-        const int32_t px = fast_proj(wx, false, res), py = fast_proj(wy, false, res);
-        first = div_trunc(px, f.rM, f.rK, res) != 0 || div_trunc(py, f.rM, f.rK, res) != 0;
-      }
-      push(first, false, false, DZ_PER_DISTANCE); // len == 1
-      if (work && k0 == 0) k = 1;
-    }
-    // iterations of the wave: the longest lane (uniform: the loop itself is scalar)
-    int32_t todo = work ? k1 - k : 0;
-    for (int d = 32; d > 0; d >>= 1) todo = max(todo, __shfl_xor(todo, d, 64));
-    const int32_t n_iter = __builtin_amdgcn_readfirstlane(todo);
-    int32_t dzl = DZ_PER_DISTANCE * (1 + k * half); // DZ_PER_DISTANCE * len of the sample k, carried (no multiply per sample)
-    const int32_t dzl_step = DZ_PER_DISTANCE * half;
-    for (int32_t it = 0; it < n_iter; ++it)
-    {
-      // ---- sample phase: every lane steps (lanes that are through keep stepping; their samples are masked)
-      const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
-      fast_step_z(wz);
-      const bool cand = (cx || cy) && k < k1;
-      push(cand, cx, cy, dzl);
-      k += 1;
-      dzl += dzl_step;
-      // ---- emit phase
-      if (qtail - qhead >= 64) emit();
-    }
-    while (qtail != qhead) emit();
-    free_finish<true>(a, pend, n_keyed, fblock);
-  }
-#endif
   // statistics: free-space candidates that became records
   for (int d = 32; d > 0; d >>= 1) n_keyed += __shfl_down(n_keyed, d, 64);
   if (lane == 0) s_keyed[threadIdx.x >> 6] = n_keyed;
@@ -1812,12 +1460,6 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
   }
 }
 
-#ifndef WS_RESOLVE_BRANCHFREE
-#define WS_RESOLVE_BRANCHFREE 1 // pass 1 of the fold without a branch per record (111.8 -> 110.6 us)
-#endif
-#ifndef WS_RESOLVE_PRIO
-#define WS_RESOLVE_PRIO 2
-#endif
 #ifndef WS_RES_MAXR
 #define WS_RES_MAXR 8
 #endif
@@ -2045,9 +1687,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   // evenly: workgroup b takes the entries b, b + G, ...
   const uint32_t e0 = blockIdx.x, e_end = n_list, ES = G;
   uint32_t n_mine = 0; // tiles this workgroup has folded
-#ifdef WS_RESOLVE_TIMING
-  uint32_t fill_sum = 0;
-#endif
   if (e0 < e_end)
   {
   const uint32_t last = e_end - 1;
@@ -2081,32 +1720,21 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
   for (uint32_t e = e0; e < e_end; e += ES)
   {
-#if WS_RESOLVE_PRIO
     {
       // The five workgroups of a compute unit start together with the same amount of work, and the SIMDs serve the OLDEST ready
-      // wave first: the workgroups finished one after the other (65 ... 115 us, tools/resolve_where.py: the spread is inside the
+      // wave first: the workgroups finished one after the other (65 ... 115 us, a round-5 instrumented build: the spread is inside the
       // compute units, not between them, and has nothing to do with the tiles a workgroup got), the compute unit ran its last
       // 25 us with one or two workgroups.  Now the issue priority goes round: a workgroup changes its priority with every tile,
       // the five of a compute unit (b, b + 256, ... in dispatch order) start at different places of the cycle -- spread inside a
       // compute unit 9.7 -> 4.9 us, the launch 110 -> 104 us.  (Priority by progress -- a quarter of the tiles done, one level
       // down: 105; time slices of 2.56 us on the shared clock: 106.)
-#if WS_RESOLVE_PRIO == 1
-      const uint32_t n_total = (e_end - e0 + ES - 1u) / ES;
-      const uint32_t q = min(3u, (n_mine * 4u) / max(n_total, 1u));
-      const uint32_t prio = 3u - q;
-#else
       const uint32_t prio = (n_mine + blockIdx.x / 256u) & 3u;
-#endif
       if (prio == 3u) __builtin_amdgcn_s_setprio(3);
       else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
       else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-#endif
     n_mine += 1;
-#ifdef WS_RESOLVE_TIMING
-    fill_sum += p_cur.fill;
-#endif
     const TilePre p = p_cur;
     const uint32_t tile = tile_cur, nsub_real = p.fill, fill = aborted ? 0u : p.fill; // (an aborted scan: the entries may be anything)
     const int nz = p.nz;
@@ -2193,17 +1821,10 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
 
       // ---- pass 1: earliest positive, smallest negative per voxel
       scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
-#if WS_RESOLVE_BRANCHFREE
         // (one LDS atomic with a selected address and key instead of two exec-mask regions per record)
         const bool neg = rec_negative(rec, a.fan_mask, a.fan_mid);
         const unsigned long long key = neg ? (unsigned long long)neg_key(rec, av, value) : (unsigned long long)rec;
         atomicMin(neg ? &kneg[l] : &kpos[l], key);
-#else
-        if (rec_negative(rec, a.fan_mask, a.fan_mid))
-          atomicMin(&kneg[l], (unsigned long long)neg_key(rec, av, value));
-        else
-          atomicMin(&kpos[l], (unsigned long long)rec);
-#endif
       });
       __syncthreads();
       scan_a();
@@ -2363,10 +1984,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   write_back(post);
   } // listed tiles
 
-#ifdef WS_RESOLVE_TIMING
-  const long long t_listed = wall_clock64();
-  uint32_t n_unlisted_mine = 0;
-#endif
   // ---- Tiles that are NOT on the list: no records, only marks of the free pass or of off-ray +tau candidates in the byte
   // planes -- (tau, +64) / (tau, -64) where a mark is, nothing to fold.  They are found by scanning the per-tile flag planes
   // (a byte per tile; the marches only ever STORE there: no atomic, no waiting in their loops), 16 tiles per thread and step,
@@ -2399,9 +2016,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       }
       __syncthreads();
       const uint32_t n_found = s_unres[0];
-#ifdef WS_RESOLVE_TIMING
-      n_unlisted_mine += n_found;
-#endif
       if (n_found && threadIdx.x == 0) atomicAdd(&a.counters->last_unlisted, n_found);
       for (uint32_t i = 0; i < n_found; ++i)
       {
@@ -2463,21 +2077,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     // (instead of the statistics: 10 ns ticks this workgroup was busy, and when it started)
     a.resolve_stats[2 * blockIdx.x + 0] = (uint32_t)(wall_clock64() - t_begin);
     a.resolve_stats[2 * blockIdx.x + 1] = (uint32_t)t_begin;
-#if WS_RESOLVE_TIMING == 4
-    {
-      uint32_t hw, xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      a.resolve_stats[2 * blockIdx.x + 1] = ((xcc & 0xfu) << 16) | (hw & 0xffffu); // where the workgroup ran
-    }
-#endif
-#if WS_RESOLVE_TIMING == 3
-    a.resolve_stats[2 * blockIdx.x + 1] = (uint32_t)(t_listed - t_begin) | (min(n_unlisted_mine, 4095u) << 20); // ticks in the listed tiles | unlisted tiles found
-#endif
-#if WS_RESOLVE_TIMING == 2
-    // (what the workgroup's tiles were made of, for a fit of its busy time: sub-chunks << 16 | contested voxels)
-    a.resolve_stats[2 * blockIdx.x + 1] = (min(fill_sum, 65535u) << 16) | min(s_stat[0] + s_stat[1] + s_stat[2] + s_stat[3], 65535u);
-#endif
 #endif
   }
 }
@@ -2806,9 +2405,6 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   {
     const RecFormat rf = rec_format(n);
     sa.rec_fmt = (uint32_t)rf.S | ((uint32_t)rf.F << 8);
-#ifdef WS_REC_CONST
-    sa.rec_fmt = 13u | (5u << 8);
-#endif
   }
   sa.tail_stats = m->block_stats;
   sa.counters = m->counters;

@@ -114,19 +114,8 @@ __host__ __device__ inline bool rec_negative(uint64_t rec, uint32_t fan_mask, ui
 // places in the tile's entry table, tile_ent[tile][j] = id << 5 | (records - 1).  Entries beyond TILE_DIRECT go through a
 // hash (tile, j) -> entry + 1.  Nobody ever waits for anybody: the resolve -- a later kernel -- reads what is there.
 constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 128;
-#ifndef WS_TAIL_RUNS
-#define WS_TAIL_RUNS 0 // 1: a (wave, tile) pair of the tail march takes its sub-chunks in runs of four (WaveTab, tsdf_update.hip): 133 against 135 us for a static pool four times the size -- measured, not kept
-#endif
-#if WS_TAIL_RUNS
-#ifndef WS_TAIL_FIRST
-#define WS_TAIL_FIRST 512
-#endif
-constexpr uint32_t SUB_WAVE_FIRST = WS_TAIL_FIRST;  // sub-chunks a wave of the tail march starts with (a round of 64 records can open 64 runs)
-constexpr uint32_t SUB_REFILL = 256;                // and what a wave asks for when it runs low
-#else
-constexpr uint32_t SUB_WAVE_FIRST = 128;
-constexpr uint32_t SUB_REFILL = 32;
-#endif
+constexpr uint32_t SUB_WAVE_FIRST = 128; // sub-chunks a wave of the tail march starts with
+constexpr uint32_t SUB_REFILL = 32;      // and what it asks the pool for when it runs low
 constexpr uint32_t SUB_WG_BLOCK = 4 * SUB_WAVE_FIRST; // ... taken from the pool by its workgroup in one request
 constexpr uint32_t SUB_ID_LIMIT = (1u << 27) - 2u;  // an entry is id << 5 | fill - 1, + 1 in the hash
 // per-tile bytes, two planes in one allocation (tile_flag_plane_bytes apart): [0] "the free pass / an off-ray mark touched the

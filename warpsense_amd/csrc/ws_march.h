@@ -212,23 +212,6 @@ __device__ __forceinline__ int32_t axis_index_offset(const AxisWalk &w, int32_t 
 
 // FREE_SPACE: the caller guarantees that every step of [k0, k1) lies more than tau (+ the centre/fan slack) in front
 // of the hit point, so value == tau (weight 64, negated off the ray) without computing it (no squares, no sqrt).
-// the same for |e| < res (one wrap at most)
-__device__ __forceinline__ int32_t axis_index_offset_small(const AxisWalk &w, int32_t e, int32_t res)
-{
-  int32_t rem = w.rem + e, fi = w.fi;
-  if (rem >= res)
-  {
-    rem -= res;
-    fi += 1;
-  }
-  else if (rem < 0)
-  {
-    rem += res;
-    fi -= 1;
-  }
-  return fi + ((w.proj + e < 0 && rem != 0) ? 1 : 0);
-}
-
 template <bool FREE_SPACE, class Emit>
 __device__ __forceinline__ void march_steps_fast(const MarchFrame &f, const RaySetup &r, int32_t k0, int32_t k1, Emit &&emit)
 {
@@ -379,41 +362,6 @@ __device__ __forceinline__ void run_init(AxisRun &w, const MarchFrame &f, const 
       w.gap = m >= 1 ? rem + 1 : f.res - a;
   }
 }
-// one sample; returns true if the truncated voxel index of this axis changed (x, y)
-__device__ __forceinline__ bool run_step(AxisRun &w, int32_t dist, int32_t res)
-{
-  w.r += w.ar;
-  int32_t dq = w.aq;
-  if (w.r >= dist)
-  {
-    w.r -= dist;
-    dq += 1;
-  }
-  w.q += dq;
-  w.gap -= dq;
-  const bool crossed = w.gap <= 0;
-  if (crossed) w.gap += res;
-  return crossed;
-}
-__device__ __forceinline__ void run_step_z(AxisRun &w, int32_t dist)
-{
-  w.r += w.ar;
-  int32_t dq = w.aq;
-  if (w.r >= dist)
-  {
-    w.r -= dist;
-    dq += 1;
-  }
-  w.q += dq;
-}
-// position of the sample on this axis (update_tsdf.cu:69); `fix_gap`: the axis crossed into the cell around zero
-__device__ __forceinline__ int32_t run_proj(AxisRun &w, bool crossed, int32_t res)
-{
-  const int32_t a = w.spos + w.q;
-  if (crossed && (uint32_t)(a + res - 1) < (uint32_t)(res - 1)) w.gap += res - 1; // a in [-res+1, -1]
-  return (a ^ w.sm) - w.sm;
-}
-
 // ---- the same sample step with fewer instructions (the march kernels are bound by VALU issue) ---------------------------
 // The remainder is kept BIASED by 2^32 - dist, so that "r + ar >= dist" is the carry out of one 32-bit add, and the carry
 // feeds the quotient (add with carry) and the gap (subtract with borrow) directly: 8 vector instructions for an x / y axis,
