@@ -2,6 +2,7 @@
 """bench.py — scans/s of the warpsense hot path (TSDF update + Point-to-TSDF registration) on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts the N ranks itself, self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -121,8 +122,31 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
             "update_1_thread_scans_per_s": 1.0 / (one + best_reg[0])}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, the way the driver's
+    torch.distributed.run line does (one process per GPU, rendezvous on 127.0.0.1), and let rank 0's JSON line through.  Under a
+    launcher (WORLD_SIZE set) the world size must be the --gpus asked for."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    self_launch(args)
     # The driver reads ONE JSON line from stdout.  Libraries print there too (RCCL's version banner comes from C code):
     # keep a private handle on the real stdout for the result and send everything else that is written to fd 1 to stderr.
     sys.stdout.flush()

@@ -47,8 +47,9 @@ typedef enum
   WS_ERR_INVALID = -1,     /* bad argument                                             */
   WS_ERR_HIP = -2,         /* HIP runtime error (message in ws_last_error)              */
   WS_ERR_TOO_MANY_POINTS = -3, /* scan larger than the 1 000 000-point buffer (update_tsdf.h:33) */
-  WS_ERR_CAPACITY = -4,    /* returned at once by ws_tsdf_update* for a scan that needs more than 2^27 record sub-chunks (the record
-                              pool itself cannot overflow: a scan that exhausts it is repeated with a larger one) */
+  WS_ERR_CAPACITY = -4,    /* a scan that needs more than 2^27 record sub-chunks: returned by the NEXT call that takes the map (the one
+                              that looks at the scan's verdict; the record pool itself cannot overflow: a scan that exhausts it is
+                              repeated with a larger one) */
   WS_ERR_RANGE = -5,       /* a ray with more ray steps / fan steps than the record's key holds for a scan of that many points: 65 536
                               steps and 255 fan steps up to 2^14 points, 32 768 / 63 for the reference's 131 072-point scans, 8192 / 31
                               for the 1 000 000-point maximum; the ray was dropped (sticky)                 */
@@ -58,12 +59,13 @@ typedef enum
 } ws_status;
 
 /* Sticky device-side errors.  ws_tsdf_update* return after ENQUEUEING the kernels (like the reference,
- * update_tsdf.cu:165; before returning they wait for the marches' verdict on the record pool -- the reference blocks on its
- * cudaMemcpys in the same call, :152-154), so a problem found by the later kernels (WS_ERR_RANGE / INTERNAL: the
+ * update_tsdf.cu:165), so a problem found by the later kernels (WS_ERR_RANGE / INTERNAL: the
  * map is then not bit-exact) cannot come back from that call.  It is kept in host-visible memory and returned ONCE by the
  * first call on the same map that synchronises afterwards: ws_sync, ws_map_download, ws_register_cloud, ws_tsdf_stats.
  * compat.hpp turns it into the reference's print-and-exit (common.cuh:10-21).  Capacity is not among them: a scan that does
- * not fit the record pool is aborted without touching the maps and repeated with a larger pool inside the call. */
+ * not fit the record pool is aborted without touching the maps and repeated with a larger pool by the next call that takes the
+ * map, before that call's own work (every such entry point looks at the verdict first; two readers that get there at once -- the
+ * reference runs register_cloud and the shift thread's to_host under a SHARED lock -- are serialised inside the library). */
 
 #define WS_MAP_AVG 0 /* TSDFCuda::avg_map() */
 #define WS_MAP_NEW 1 /* TSDFCuda::new_map() */
@@ -148,9 +150,11 @@ int64_t ws_map_n_voxels(const ws_map *map);
  * Returns after enqueueing, like the reference (no device sync). */
 int ws_tsdf_update(ws_map *map, const int32_t *xyz_host, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
 /* same with the scan already resident in HBM (no H2D copy).  Asynchronous like a stream copy: xyz_dev must stay unchanged until
- * the next call that takes this map -- ws_register_cloud, ws_reg_iterate, ws_sync, a download, the next update -- has returned
- * (that call looks at the scan's verdict first and repeats the scan with a larger record pool in the rare case that it did
- * not fit: never an inexact map).  ws_tsdf_update copies host scans into a buffer of the map, so it has no such condition. */
+ * the kernels enqueued by this call have read it (stream order: anything enqueued later on the context's stream is safe, e.g.
+ * ws_scan_preprocess of the next frame).  The next call that takes this map -- ws_register_cloud, ws_reg_iterate, ws_sync, a
+ * download, the next update -- looks at the scan's verdict first and repeats the scan with a larger record pool in the rare case
+ * that it did not fit (never an inexact map); the repeat reads a copy of the scan that the first attempt left in a buffer of the
+ * map, not xyz_dev. */
 int ws_tsdf_update_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);
 /* only the scatter (cu_min_tsdf_krnl, update_tsdf.cu:45-128): fills new_map, no integrate. For parity tests. */
 int ws_tsdf_scatter_dev(ws_map *map, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3]);

@@ -278,3 +278,37 @@ def test_an_error_on_one_rank_ends_the_call_on_every_rank():
     got = dict((r, (what, resets)) for r, what, resets in (q.get(timeout=10) for _ in range(2)))
     assert got[1][0].startswith("own:rank 1") and got[0][0].startswith("peer:"), got
     assert got[0][1] == 1 and got[1][1] == 1
+
+
+def test_bench_gpus_flag_starts_the_ranks_or_checks_the_launcher(monkeypatch):
+    """bench.py --gpus N was parsed and never read.  Without a launcher N > 1 now re-executes under
+    torch.distributed.run with N ranks (rendezvous on 127.0.0.1, the caller's flags passed on); under a launcher the world size
+    must be the --gpus asked for."""
+    import argparse
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("ws_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(os, "execv", lambda exe, argv: calls.append((exe, list(argv))))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.self_launch(argparse.Namespace(gpus=4))
+    assert len(calls) == 1
+    argv = calls[0][1]
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and argv[argv.index("--nproc-per-node") + 1] == "4"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert os.path.basename(argv[-7]) == "bench.py"
+    # one GPU: nothing to launch
+    calls.clear()
+    bench.self_launch(argparse.Namespace(gpus=1))
+    assert not calls
+    # under a launcher: the world must match
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.self_launch(argparse.Namespace(gpus=4))
+    assert not calls
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        bench.self_launch(argparse.Namespace(gpus=4))

@@ -393,6 +393,24 @@ def test_bench_dry_run_two_ranks_share_the_gpu():
     assert out["replica_scans_per_s"] > 0
 
 
+def test_bench_gpus_two_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher ran on one GPU and printed n_gpus: 1.  It now starts its
+    N ranks itself (the same torch.distributed.run line); dry run with both ranks on cuda:0 over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WS_BENCH_SHARE_GPU="1", WS_BENCH_BACKEND="gloo", WS_REG_PEER_TIMEOUT_MS="250", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, cwd=root)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr.decode(errors="replace")[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["multi_gpu"]["iterations"] > 5
+
+
 def test_peer_mailbox_loop_eight_ranks_on_one_gpu():
     """world = 8, the size of a node: eight ranks x 32 resident workgroups share cuda:0 (tools/peer_bench.py in a process of its
     own with 16 hardware queues, so that all eight kernels are on the chip together), the benchmark cloud of 131 072 points on the

@@ -423,6 +423,132 @@ def test_a_scan_that_runs_out_of_chunks_is_aborted_and_repeated():
     assert st["records"] > cap0 // 2
 
 
+def _abort_prone_pair():
+    """a small map whose record pool is far too small for the scans below: every first attempt is aborted on the device"""
+    tau, res, mw, size = 600, 20, 640, (400, 400, 100)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    t.debug_chunk_policy(1, 9)
+    t.set_capacity(4096 * 256)
+    return (tau, res, mw), lm, t, oa, on
+
+
+def test_back_to_back_host_updates_with_an_aborted_scan_between_them():
+    """ws_tsdf_update copies a host scan into the map's scan buffer -- the buffer a repeat of the PREVIOUS scan
+    reads.  Two host-array updates back to back, the first one aborted for lack of pool (its verdict is only looked at by the
+    second call): the second call must settle the first scan BEFORE it overwrites the buffer.  (Before the fix the repeat ran on
+    the second scan's points with the first scan's count and pose.)"""
+    (tau, res, mw), lm, t, oa, on = _abort_prone_pair()
+    a = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    b = S.os1_128_scan(sensor_mm=(-90.0, 50.0, -30.0), rings=96, azimuths=384, half_extents_mm=(3000.0, 3300.0, 800.0), seed=12)
+    cap0 = t.stats()["record_capacity"]
+    t.update_tsdf(a, (6, -4, 2), (0, 0, 32768))   # numpy arrays: the reference's signature (host vector)
+    t.update_tsdf(b, (-4, 2, -1), (0, 0, 32768))  # no synchronising call in between
+    t.ctx.sync()
+    st = t.stats()
+    assert st["status"] == 0 and st["error_flags"] == 0
+    assert st["record_capacity"] > cap0, "the first scan must have outgrown the deliberately small pool"
+    O.update_tsdf(oa, on, a, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+    O.update_tsdf(oa, on, b, (-4, 2, -1), (0, 0, 32768), tau, mw, res)
+    got = download(t, lm, 0)
+    assert np.array_equal(got, oa.data), f"{np.count_nonzero(got != oa.data)} voxels differ"
+
+
+def test_a_repeat_does_not_read_the_callers_device_buffer():
+    """ws_tsdf_update_dev returns after its launches and the verdict on the record pool is looked at by the
+    next call that takes the map.  The repeat of an aborted scan reads the copy the first attempt left in the map's own buffer:
+    the caller may reuse its device buffer as soon as the kernels of the update have run (here: overwritten with another scan
+    after a device-wide synchronisation that the library knows nothing about)."""
+    torch = _torch()
+    (tau, res, mw), lm, t, oa, on = _abort_prone_pair()
+    a = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    x = torch.from_numpy(a).cuda()
+    cap0 = t.stats()["record_capacity"]
+    t.update_tsdf(x, (6, -4, 2), (0, 0, 32768))
+    torch.cuda.synchronize()  # (not a library call: nothing is settled)
+    x.copy_(torch.from_numpy(a[::-1].copy() + 17))  # the buffer now holds something else
+    torch.cuda.synchronize()
+    t.ctx.sync()  # settles: the aborted scan is repeated here
+    st = t.stats()
+    assert st["status"] == 0 and st["error_flags"] == 0 and st["record_capacity"] > cap0
+    O.update_tsdf(oa, on, a, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+    got = download(t, lm, 0)
+    assert np.array_equal(got, oa.data), f"{np.count_nonzero(got != oa.data)} voxels differ"
+
+
+def test_a_repeated_scatter_keeps_the_route_of_its_first_attempt():
+    """ws_tsdf_scatter_dev marks new_map as non-default once the scan is in it; the repeat of an aborted
+    scatter must still take the default-map route (free-space bytes), not turn every free-space candidate into a record."""
+    torch = _torch()
+    (tau, res, mw), lm, t, oa, on = _abort_prone_pair()
+    a = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=128, azimuths=512, half_extents_mm=(3800.0, 3600.0, 900.0), seed=11)
+    x = torch.from_numpy(a).cuda()
+    t.scatter(x, (6, -4, 2), (0, 0, 32768))
+    t.ctx.sync()
+    st = t.stats()
+    assert st["status"] == 0 and st["error_flags"] == 0
+    rec_repeated = st["records"]
+    O.update_min(on, a, (6, -4, 2), (0, 0, 32768), tau, res)
+    assert np.array_equal(download(t, lm, 1), on.data)
+    t.integrate()
+    # the same scan into a fresh map with room to spare: the same number of records
+    lm2, t2, _, _ = make_pair((400, 400, 100), tau, res, mw)
+    t2.scatter(x, (6, -4, 2), (0, 0, 32768))
+    t2.ctx.sync()
+    assert t2.stats()["records"] == rec_repeated
+
+
+def test_two_reader_threads_settle_an_aborted_scan_once():
+    """every reader entry point looks at the last scan's verdict first and, for an aborted scan, enlarges the
+    pool and runs the scan again.  The reference's caller has two readers under a SHARED lock -- register_cloud
+    (tsdf_registration.cpp:54) and the shift thread's avg_map().to_host (tsdf_mapping.cpp:115-117) -- so two host threads can
+    get there at once: the repeat must happen once, the other thread must wait for it.  50 aborted scans, each followed by a
+    registration and a download started together from two threads: the downloaded map is the oracle's every time."""
+    import threading
+    import warpsense_amd as W
+    torch = _torch()
+    tau, res, mw, size = 600, 20, 640, (400, 400, 100)
+    lm, t, oa, on = make_pair(size, tau, res, mw)
+    t.debug_chunk_policy(1, 9)
+    pts = S.os1_128_scan(sensor_mm=(130.0, -70.0, 40.0), rings=48, azimuths=256, half_extents_mm=(3800.0, 3600.0, 900.0), seed=13)
+    x = torch.from_numpy(pts).cuda()
+    reg = W.RegistrationCuda()
+    reg.prepare_registration(x)
+    n_aborted = 0
+    for rep in range(50):
+        t.set_capacity(4096 * 256)  # back to a pool the scan does not fit
+        cap0 = t.stats()["record_capacity"]
+        t.update_tsdf(x, (6, -4, 2), (0, 0, 32768))
+        O.update_tsdf(oa, on, pts, (6, -4, 2), (0, 0, 32768), tau, mw, res)
+        out, errs = {}, []
+        go = threading.Barrier(2)
+
+        def reader_registration():
+            try:
+                go.wait()
+                out["pose"] = reg.register_cloud(t.device_map(), np.eye(4, dtype=np.float32), 5, 0.1, 0.03, res)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def reader_download():
+            try:
+                go.wait()
+                out["map"] = download(t, lm, 0)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=reader_registration), threading.Thread(target=reader_download)]
+        for k in th:
+            k.start()
+        for k in th:
+            k.join()
+        assert not errs, errs
+        assert np.array_equal(out["map"], oa.data), f"repetition {rep}: {np.count_nonzero(out['map'] != oa.data)} voxels differ"
+        st = t.stats()
+        assert st["status"] == 0 and st["error_flags"] == 0
+        n_aborted += st["record_capacity"] > cap0
+    assert n_aborted == 50, "every scan was meant to outgrow its pool"
+
+
 def test_long_rays_with_wide_fans_take_the_scans_own_key_split():
     """until round 5 a ray of more than 8 192 steps or 31 fan steps was dropped (WS_ERR_RANGE) -- the reference
     marches it (update_tsdf.cu:67,107-125).  The record's 38 key bits are now shared out per scan (rec_format, ws_internal.h): a

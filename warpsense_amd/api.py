@@ -535,16 +535,19 @@ class TSDFCuda:
         self.handle = h
         self._avg = DeviceMapMemWrapper(self, WS_MAP_AVG)
         self._new = DeviceMapMemWrapper(self, WS_MAP_NEW)
+        self._scan_in_flight = None  # the device tensor of the last update (kept until the next one is enqueued behind it)
 
     # -- the three update_tsdf overloads of the reference (update_tsdf.cu:143-191)
     def update_tsdf(self, scan_points, scanner_pos, up, result: DeviceMap | None = None, latest_map: DeviceMap | None = None):
         n = int(scan_points.shape[0])
         sp, u = _i3c(scanner_pos), _i3c(up)
         if _is_device(scan_points):
-            # ws_tsdf_update_dev returns after its launches and may have to repeat the scan when the NEXT call on this map looks at
-            # its verdict (warpsense_hip.h): the tensor must not go back to torch's allocator before that -- keep it until the next update
-            self._scan_in_flight = scan_points
+            # ws_tsdf_update_dev returns after its launches: the tensor must not go back to torch's allocator before the kernels have
+            # read it (torch's allocator only knows torch's streams) -- keep it until the next update has been enqueued behind it
+            prev = self._scan_in_flight
             rc = self._L.ws_tsdf_update_dev(self.handle, _ptr(scan_points), n, _ptr(sp), _ptr(u))
+            self._scan_in_flight = scan_points
+            del prev
         else:
             pts = np.ascontiguousarray(scan_points, dtype=np.int32)
             rc = self._L.ws_tsdf_update(self.handle, _ptr(pts), n, _ptr(sp), _ptr(u))
@@ -561,9 +564,11 @@ class TSDFCuda:
 
     def scatter(self, scan_points_dev, scanner_pos, up):
         """cu_min_tsdf_krnl alone (parity tests): leaves the resolved scan in new_map."""
-        self._scan_in_flight = scan_points_dev  # (see update_tsdf)
+        prev = self._scan_in_flight  # (see update_tsdf)
         check(self._L.ws_tsdf_scatter_dev(self.handle, _ptr(scan_points_dev), int(scan_points_dev.shape[0]),
                                           _ptr(_i3c(scanner_pos)), _ptr(_i3c(up))), "ws_tsdf_scatter_dev")
+        self._scan_in_flight = scan_points_dev
+        del prev
 
     def integrate(self):
         check(self._L.ws_tsdf_integrate(self.handle), "ws_tsdf_integrate")

@@ -750,7 +750,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
   prof_begin(m->ctx, WS_K_UPDATE);
   rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, m->integrate_mode == WS_INTEGRATE_SPARSE);
   if (rc == WS_OK) rc = launch_tsdf_integrate(m);
-  if (m->pending.active) m->pending.integrate_after = true; // (what a repeat of this scan has to be followed by)
+  if (m->pending.active.load(std::memory_order_relaxed)) m->pending.integrate_after = true; // (what a repeat of this scan has to be followed by; the caller holds the map exclusively here)
   prof_end(m->ctx, WS_K_UPDATE);
   return rc;
 }
@@ -761,6 +761,8 @@ int ws_tsdf_update(ws_map *m, const int32_t *xyz_host, size_t n, const int32_t s
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
   if (n)
   {
+    // (scan_dev is what a repeat of the PREVIOUS scan would read -- its verdict first, then the new points)
+    WS_SETTLE(m);
     // pageable source: hipMemcpyAsync stages the data before it returns, like the reference's cudaMemcpy (update_tsdf.cu:152)
     WS_HIP(hipMemcpyAsync(m->scan_dev, xyz_host, n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, m->ctx->stream));
   }

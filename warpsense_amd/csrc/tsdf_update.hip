@@ -47,6 +47,7 @@ namespace ws
 struct ScatterArgs
 {
   const int32_t *xyz;
+  int32_t *xyz_keep; // the set-up pass copies the scan here (ws_map::scan_dev: what a repeat of an aborted scan reads); NULL: xyz is that buffer
   uint32_t n;
   int32_t scanner_pos[3];
   int32_t up[3];
@@ -232,6 +233,14 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
     px = a.xyz[3 * (size_t)ix + 0];
     py = a.xyz[3 * (size_t)ix + 1];
     pz = a.xyz[3 * (size_t)ix + 2];
+    if (a.xyz_keep)
+    {
+      // (the verdict on the record pool comes after ws_tsdf_update_dev has returned; a repeat must not depend on what
+      // the caller has done with its buffer since)
+      a.xyz_keep[3 * (size_t)ix + 0] = px;
+      a.xyz_keep[3 * (size_t)ix + 1] = py;
+      a.xyz_keep[3 * (size_t)ix + 2] = pz;
+    }
     // cu_to_map (cuda/util.h:111-114) + in_bounds_with_buffer_pos (update_tsdf.cu:55)
     const float fr = (float)res;
     const int32_t cx = (int32_t)floorf(__fdiv_rn((float)px, fr));
@@ -293,7 +302,10 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
           const int64_t ivmax = max(max(llabs(ivx), llabs(ivy)), llabs(ivz));
           // dmax <= distance: beyond ~46 m the reference's int sum of squares wraps and `distance` is not the length
           // of the ray any more — the walk's "less than one voxel per step" then fails
+          // (res * distance < 2^32: the column-change walk keeps W = res * dist in 32 bits, ws_dda.h -- ADVICE r5; only a map of
+          // metre-sized voxels gets near it)
           const bool fast = dmax <= distance && dmax * len_end < (1ll << 31) && pmax + dmax + 2 * (int64_t)res + tau < (1ll << 30) &&
+                            (int64_t)res * distance < (1ll << 32) &&
                             (2 * max_delta_z + res) * ivmax < (1ll << 31) &&
                             (len_end + 2 * (int64_t)res) * (len_end + 2 * (int64_t)res) < (1ll << 31);
           r.pad = fast ? RAY_FAST : 0;
@@ -2356,15 +2368,15 @@ void fill_fan_steps(int32_t *fan_steps, int32_t res)
 uint64_t subs_for_scan(const ws_map *m, uint64_t need_records, uint64_t n_points) { return subs_needed(need_records, m->est_shift, n_points); }
 
 // one attempt of the scatter: every kernel enqueued, nothing waited for
-static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused, uint32_t *seq_out)
+static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused, bool s0, uint32_t *seq_out)
 {
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
-  const bool s0 = !m->new_is_default;
   // the (tile, entry) hash keeps the keys of released tiles: empty it before it fills up
   if (m->status_host[10] > m->big_slots / 4) m->prepped = false;
   ScatterArgs sa;
   sa.xyz = xyz_dev;
+  sa.xyz_keep = xyz_dev == m->scan_dev ? nullptr : m->scan_dev;
   sa.n = (uint32_t)n;
   for (int k = 0; k < 3; ++k)
   {
@@ -2492,10 +2504,18 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
 // cost the callback 1.3 ms of its 3.5: the GPU runs the marches at idle clocks there.)
 int settle_tsdf(ws_map *m)
 {
-  if (!m || !m->pending.active) return WS_OK;
+  if (!m || !m->pending.active.load(std::memory_order_acquire)) return WS_OK; // (the fast path: no lock)
+  // Two readers of the reference's caller can get here at once (register_cloud and the shift thread's to_host, both under
+  // the SHARED lock): one of them settles the scan, the other waits here until the map is whole.
+  std::lock_guard<std::mutex> lock(m->settle_mu);
+  if (!m->pending.active.load(std::memory_order_acquire)) return WS_OK;
   ws_context *ctx = m->ctx;
   hipStream_t s = ctx->stream;
   volatile uint32_t *st = m->status_host;
+  auto done = [&](int rc) {
+    m->pending.active.store(false, std::memory_order_release);
+    return rc;
+  };
   for (;;)
   {
     const uint32_t seq = m->pending.seq;
@@ -2508,43 +2528,33 @@ int settle_tsdf(ws_map *m)
         WS_HIP(hipStreamSynchronize(s)); // (a stream busy with much earlier work; the word is there afterwards)
         if (st[8] != seq)
         {
-          m->pending.active = false;
           set_error("TSDF update: the resolve did not report the end of the marches");
-          return WS_ERR_INTERNAL;
+          return done(WS_ERR_INTERNAL);
         }
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (st[9] == 0)
-    {
-      m->pending.active = false; // the normal case
-      return WS_OK;
-    }
+    if (st[9] == 0) return done(WS_OK); // the normal case
     if (++m->pending.attempts > 8)
     {
-      m->pending.active = false;
       set_error("TSDF update: the scan did not fit the record pool it had just been given");
-      return WS_ERR_INTERNAL;
+      return done(WS_ERR_INTERNAL);
     }
     const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4) & ((1ull << 48) - 1ull);
     uint64_t grow_to = subs_for_scan(m, need, m->pending.n);
     if (grow_to < (uint64_t)m->sub_cap * 2) grow_to = (uint64_t)m->sub_cap * 2;
     if (grow_to > SUB_ID_LIMIT)
     {
-      m->pending.active = false;
       set_error("TSDF update: the scan needs more than 2^27 record sub-chunks");
-      return WS_ERR_CAPACITY;
+      return done(WS_ERR_CAPACITY);
     }
     // (waits for the stream: the aborted update has drained and put its scratch back; leaves prepped == false: the new hash is
-    // filled by the preparation pass, the tile tables are zero already)
+    // filled by the preparation pass, the tile tables are zero already).  The repeat reads the copy of the scan the set-up pass
+    // of the aborted attempt has left in scan_dev, and takes the route (default / non-default new_map) of the first attempt.
     int rc = resize_records(m, grow_to);
-    if (rc == WS_OK) rc = enqueue_scatter(m, m->pending.xyz, m->pending.n, m->pending.pos, m->pending.up, m->pending.fused, &m->pending.seq);
+    if (rc == WS_OK) rc = enqueue_scatter(m, m->scan_dev, m->pending.n, m->pending.pos, m->pending.up, m->pending.fused, m->pending.s0, &m->pending.seq);
     if (rc == WS_OK && m->pending.integrate_after) rc = launch_tsdf_integrate(m);
-    if (rc != WS_OK)
-    {
-      m->pending.active = false;
-      return rc;
-    }
+    if (rc != WS_OK) return done(rc);
   }
 }
 
@@ -2566,12 +2576,12 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
     return WS_OK;
   }
   uint32_t seq = 0;
-  rc = enqueue_scatter(m, xyz_dev, n, scanner_pos, up, fused, &seq);
+  const bool s0 = !m->new_is_default;
+  rc = enqueue_scatter(m, xyz_dev, n, scanner_pos, up, fused, s0, &seq);
   if (rc != WS_OK) return rc;
-  m->pending.active = true;
   m->pending.seq = seq;
-  m->pending.xyz = xyz_dev;
   m->pending.n = n;
+  m->pending.s0 = s0;
   for (int k = 0; k < 3; ++k)
   {
     m->pending.pos[k] = scanner_pos[k];
@@ -2580,6 +2590,7 @@ int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
   m->pending.fused = fused;
   m->pending.integrate_after = false;
   m->pending.attempts = 0;
+  m->pending.active.store(true, std::memory_order_release);
   // A scan into a NON-default new_map (the first update after a map came from the host, update_tsdf.cu:135-136) is settled here:
   // the dense integrate that follows consumes new_map's stored entries, and must not run on the leftovers of an aborted scan.
   if (!m->new_is_default) return settle_tsdf(m);

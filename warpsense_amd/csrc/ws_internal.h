@@ -3,8 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -243,17 +245,21 @@ struct ws_map
   // The scan whose verdict (did its records fit the pool?) has not been looked at yet: ws_tsdf_update* return after the
   // launches, like the reference's update_tsdf (update_tsdf.cu:165); the next call that takes this map settles it first
   // (settle_tsdf: the verdict is in host-mapped memory ~0.35 ms after the launches) and repeats the scan if it was aborted.
+  // The reference's caller runs "one writer or many readers" (tsdf_mapping.cpp:62-75,114-124, tsdf_registration.cpp:54), and
+  // every reader entry point settles: `active` is the lock-free fast path, `settle_mu` makes the slow path (wait for the
+  // verdict; for an aborted scan: new pool, the scan again) exclusive -- a second reader waits there until the map is whole.
   struct PendingScan
   {
-    bool active = false;
+    std::atomic<bool> active{false};
     uint32_t seq = 0;
-    const int32_t *xyz = nullptr; // must stay unchanged until the scan is settled (ws_tsdf_update copies host scans into scan_dev)
-    size_t n = 0;
+    size_t n = 0;  // the points are in ws_map::scan_dev (the set-up pass of the scan keeps a copy there: a repeat does not depend on the caller's buffer)
     int32_t pos[3] = {0, 0, 0}, up[3] = {0, 0, 0};
     bool fused = false;
+    bool s0 = false;              // the scan went into a non-default new_map (decided when it was first launched)
     bool integrate_after = false; // ws_tsdf_update*: an integrate pass follows the scatter
     int attempts = 0;
   } pending;
+  std::mutex settle_mu;
   hipStream_t shift_stream = nullptr; // second stream for asynchronous slab transfers (map shift off the scan path)
   hipEvent_t shift_event = nullptr;
   uint32_t *shift_stage_dev = nullptr;  // packed leaving slabs
