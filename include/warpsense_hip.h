@@ -262,6 +262,9 @@ int ws_debug_block_stats(ws_map *map, uint32_t *out, size_t words);
  * another kernel kept that workgroup off the chip: the exchange times out (5 ms) and ws_register_cloud repeats the
  * registration with one launch per iteration. *fallbacks (may be NULL) receives how often that has happened on `reg`. */
 int ws_debug_reg_stall(ws_reg *reg, int32_t stall_next, int32_t *fallbacks);
+/* test / tuning entry: the resident server behind ws_reg_iterate (enable: 1 / 0, -1 = leave as it is; idle_us > 0: how long it
+ * stays without a request, default 50); *launches = servers started so far on this handle */
+int ws_debug_reg_server(ws_reg *reg, int32_t enable, int32_t idle_us, int32_t *launches);
 
 /* Test entry: the 44 sums (h[36] column-major, g[6], e, c -- the out-parameters of perform_registration, registration.cu:347-368)
  * the LAST Gauss-Newton update of the last ws_register_cloud / ws_register_cloud_peers on `reg` was made from.  Synchronises. */

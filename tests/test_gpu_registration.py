@@ -294,3 +294,118 @@ def test_loop_sums_on_a_map_of_arbitrary_entries(n, res):
             assert np.array_equal(h, ho), (mode, max_it)
             assert np.array_equal(T, T_o.astype(np.float32)), (mode, max_it, np.abs(T - T_o).max())
     rc.close()
+
+
+def _server(reg_cuda, enable=-1, idle_us=0):
+    import ctypes as C
+    n = C.c_int32(0)
+    rc = reg_cuda._L.ws_debug_reg_server(reg_cuda.handle, int(enable), int(idle_us), C.byref(n))
+    assert rc == 0
+    return n.value
+
+
+def test_perform_registration_through_the_resident_server():
+    """the reference's caller is unchanged -- one perform_registration per Gauss-Newton iteration, the solve on the
+    host in between (tsdf_registration.cpp:55-92) -- and a launch per call cost 19.8 us.  ws_reg_iterate now talks to a kernel
+    that stays on the GPU across calls (reg_server_kernel): the pose goes out and the 44 sums come back through host-mapped
+    memory.  Bit-exact against the oracle for a sequence of poses, ONE launch for the whole sequence while the calls keep coming,
+    the same numbers with the server switched off, and a new server after the old one has gone idle."""
+    import time
+    reg, oa, pts, res = build_scene()
+    q = S.transform_points_mm(pts, S.perturbation(40, -30, 10, 2.0))
+    rc = reg.reg_
+    rc.prepare_registration(q)
+    poses = [np.eye(4, dtype=np.float32)] + [S.perturbation(3.0 * k - 20, 28 - k, -9 + 0.5 * k, 0.15 * k - 1.7) for k in range(24)]
+    want = [O.reg_iterate(oa, T, q, res, rc.flags) for T in poses]
+    base = _server(rc, enable=1, idle_us=200000)  # (a Python caller is slow: keep the server through the gaps)
+    got = [rc.perform_registration(reg.tsdf().device_map(), T, res) for T in poses]
+    assert _server(rc) - base == 1, "one server for the whole sequence"
+    for (h, g, e, c), (ho, go, eo, co) in zip(got, want):
+        assert c == co and e == eo and c > 1000 and np.array_equal(g, go) and np.array_equal(h, ho)
+    # the same calls with one launch each
+    _server(rc, enable=0)
+    for T, (ho, go, eo, co) in zip(poses[:5], want):
+        h, g, e, c = rc.perform_registration(reg.tsdf().device_map(), T, res)
+        assert c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)
+    # a short idle time: the server has left between two calls, the next call starts another
+    base = _server(rc, enable=1, idle_us=20)
+    for T, (ho, go, eo, co) in zip(poses[:6], want):
+        h, g, e, c = rc.perform_registration(reg.tsdf().device_map(), T, res)
+        time.sleep(0.002)
+        assert c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)
+    assert _server(rc) - base >= 5
+
+
+def test_the_resident_server_sees_what_happens_between_two_calls():
+    """A living server answers from the cloud it holds in registers and from the map as the stream ordered it: a new cloud
+    (prepare_registration), an update of the map, a download -- everything that enqueues work on the context's stream asks the
+    server to leave, and the next perform_registration starts a new one BEHIND that work.  Every answer is the oracle's for the
+    state the caller has built up."""
+    import torch
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    on = O.OracleMap(oa.size, 1000, 0)
+    rc = reg.reg_
+    _server(rc, enable=1, idle_us=200000)
+    T = S.perturbation(12, -7, 3, 0.8)
+    q1 = S.transform_points_mm(pts, S.perturbation(40, -30, 10, 2.0))
+    q2 = np.ascontiguousarray(S.transform_points_mm(pts, S.perturbation(-25, 14, -6, -1.1))[::-1][: len(pts) - 77])
+    pts2 = S.os1_128_scan(rings=32, azimuths=256, half_extents_mm=(2400.0, 2500.0, 900.0), seed=77)
+
+    def check(q):
+        h, g, e, c = rc.perform_registration(reg.tsdf().device_map(), T, res)
+        ho, go, eo, co = O.reg_iterate(oa, T, q, res, rc.flags)
+        assert c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)
+
+    rc.prepare_registration(q1)
+    check(q1)
+    check(q1)
+    rc.prepare_registration(torch.from_numpy(q2).cuda())  # another cloud
+    check(q2)
+    reg.update_tsdf(torch.from_numpy(pts2).cuda(), pose=np.eye(4, dtype=np.float32))  # the map changes
+    O.update_tsdf(oa, on, pts2, (0, 0, 0), (0, 0, 32768), 1000, 640, res)
+    check(q2)
+    check(q2)
+    reg.tsdf().ctx.sync()
+    check(q2)
+
+
+def test_a_reader_thread_beside_the_resident_server():
+    """the reference's shift thread reads the map (avg_map().to_host, tsdf_mapping.cpp:115-117) while the registration thread is
+    in its loop: a download from a second host thread asks the server to leave in the middle of a sequence of requests; no
+    request is lost or answered twice, every answer is exact"""
+    import threading
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    rc = reg.reg_
+    _server(rc, enable=1, idle_us=300)
+    q = S.transform_points_mm(pts, S.perturbation(40, -30, 10, 2.0))
+    rc.prepare_registration(q)
+    poses = [S.perturbation(2.0 * k - 20, 18 - k, -9 + 0.5 * k, 0.1 * k - 1.2) for k in range(40)]
+    want = [O.reg_iterate(oa, T, q, res, rc.flags) for T in poses]
+    stop = threading.Event()
+    errs = []
+    lm = W.LocalMap(*oa.size, 1000, 0)
+    n_reads = [0]
+
+    def reader():
+        try:
+            host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+            while not stop.is_set():
+                reg.tsdf().avg_map().to_host(host)
+                n_reads[0] += 1
+                assert np.array_equal(host.data_, oa.data)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=reader)
+    th.start()
+    try:
+        for rep in range(3):
+            for T, (ho, go, eo, co) in zip(poses, want):
+                h, g, e, c = rc.perform_registration(reg.tsdf().device_map(), T, res)
+                assert c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+    assert n_reads[0] > 0

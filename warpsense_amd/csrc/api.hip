@@ -99,10 +99,25 @@ static void copy3(int32_t dst[3], const int32_t src[3])
 size_t reg_partials_bytes();
 } // namespace ws
 static int ctx_take_errors(ws_context *ctx);
+// A resident server of ws_reg_iterate (reg_server_kernel) holds the context's stream until it has been idle for 50 us: whoever
+// enqueues other work there asks it to leave first (one store into host-mapped memory; the work is ordered behind the kernel
+// anyway).  The next ws_reg_iterate waits until that server is really gone and starts a new one -- behind the other work.
+static void servers_leave(ws_context *ctx)
+{
+  if (!ctx) return;
+  for (ws_reg *r : ctx->regs)
+  {
+    const uint32_t id = r->srv_launch.load(std::memory_order_acquire);
+    if (id == 0 || ws::reg_server_mail_exited(r->srv_mail) == id) continue;
+    ws::reg_server_mail_stop(r->srv_mail, id);
+    r->srv_stopping.store(true, std::memory_order_release);
+  }
+}
 // every entry point that takes a map looks at the verdict of the scan in flight first (settle_tsdf, tsdf_update.hip)
 #define WS_SETTLE(map_ptr)                                                   \
   do                                                                         \
   {                                                                          \
+    servers_leave((map_ptr)->ctx);                                           \
     const int rc_settle__ = ws::settle_tsdf(const_cast<ws_map *>(map_ptr));  \
     if (rc_settle__ != WS_OK) return rc_settle__;                            \
   } while (0)
@@ -159,6 +174,7 @@ int ws_ctx_destroy(ws_context *ctx)
 int ws_ctx_set_stream(ws_context *ctx, void *hip_stream)
 {
   if (!ctx) return invalid("ws_ctx_set_stream: ctx is NULL");
+  servers_leave(ctx);
   hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   // work already enqueued on the old stream finishes before anything goes to the new one -- unless one of them is
   // being captured into a graph (a synchronisation would invalidate the capture; the graph orders its own nodes)
@@ -173,6 +189,7 @@ int ws_ctx_set_stream(ws_context *ctx, void *hip_stream)
 int ws_sync(ws_context *ctx)
 {
   if (!ctx) return invalid("ws_sync: ctx is NULL");
+  servers_leave(ctx);
   for (ws_map *m : ctx->maps)
   {
     const int rc = settle_tsdf(m); // (an aborted scan is repeated before the stream is drained)
@@ -727,6 +744,7 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_scatter_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
+  servers_leave(m->ctx);
   int rc = launch_tsdf_scatter(m, xyz_dev, n, scanner_pos, up, false);
   if (rc == WS_OK && n) m->new_is_default = false; // new_map now carries the scan until it is integrated
   return rc;
@@ -735,6 +753,7 @@ int ws_tsdf_scatter_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32
 int ws_tsdf_integrate(ws_map *m)
 {
   if (!m) return invalid("ws_tsdf_integrate: map is NULL");
+  servers_leave(m->ctx);
   const int rc0 = settle_tsdf(m);
   if (rc0 != WS_OK) return rc0;
   return launch_tsdf_integrate(m);
@@ -744,6 +763,7 @@ int ws_tsdf_update_dev(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_
 {
   if (!m || (!xyz_dev && n) || !scanner_pos || !up) return invalid("ws_tsdf_update_dev: NULL argument");
   if (n > MAX_SCAN_POINTS) return too_many_points(n);
+  servers_leave(m->ctx);
   int rc;
   // with the default (sparse) integrate the tile resolve folds cu_avg_tsdf_krnl into its write-back (new_map stays
   // (tau, 0)); a non-default new_map is resolved on top of its entries and integrated by the dense pass
@@ -799,7 +819,20 @@ int ws_tsdf_stats(ws_map *m, ws_tsdf_stats_t *out)
 int ws_reg_destroy(ws_reg *r)
 {
   if (!r) return WS_OK;
+  if (r->ctx)
+  {
+    servers_leave(r->ctx);
+    auto &v = r->ctx->regs;
+    for (size_t i = 0; i < v.size(); ++i)
+      if (v[i] == r)
+      {
+        v.erase(v.begin() + (long)i);
+        break;
+      }
+  }
   (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->srv_mail) (void)hipHostFree(r->srv_mail);
+  if (r->srv_ctl) (void)hipFree(r->srv_ctl);
   if (r->points) (void)hipFree(r->points);
   if (r->partials) (void)hipFree(r->partials);
   if (r->state) (void)hipFree(r->state);
@@ -854,12 +887,23 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
   if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->shard_arrived, 256);
   if (rc == WS_OK && e == hipSuccess) e = hipMemset(r->shard_arrived, 0, 256);
   if (rc == WS_OK && e == hipSuccess) r->loop_supported = reg_loop_supported(ctx->device);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostMalloc((void **)&r->srv_mail, reg_server_mail_bytes(), hipHostMallocMapped);
+  if (rc == WS_OK && e == hipSuccess) e = hipHostGetDevicePointer((void **)&r->srv_mail_dev, r->srv_mail, 0);
+  if (rc == WS_OK && e == hipSuccess) std::memset(r->srv_mail, 0, reg_server_mail_bytes());
+  if (rc == WS_OK && e == hipSuccess) e = hipMalloc((void **)&r->srv_ctl, reg_server_ctl_bytes());
+  if (rc == WS_OK && e == hipSuccess) e = hipMemset(r->srv_ctl, 0, reg_server_ctl_bytes());
+  if (rc == WS_OK && e == hipSuccess)
+  {
+    if (const char *env = std::getenv("WS_REG_SERVER")) r->srv_enabled = std::atoi(env) != 0;
+    if (const char *env = std::getenv("WS_REG_SERVER_IDLE_US")) r->srv_idle_us = (uint32_t)std::max(1, std::atoi(env));
+  }
   if (rc != WS_OK || e != hipSuccess)
   {
     if (e != hipSuccess) rc = hip_fail(e, "ws_reg_create allocation", __FILE__, __LINE__);
     ws_reg_destroy(r);
     return rc;
   }
+  ctx->regs.push_back(r);
   *out = r;
   return WS_OK;
 }
@@ -867,6 +911,7 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
 int ws_reg_prepare(ws_reg *r, const int32_t *xyz_host, size_t n)
 {
   if (!r || (!xyz_host && n)) return invalid("ws_reg_prepare: NULL argument");
+  servers_leave(r->ctx); // (a resident server of ws_reg_iterate keeps the cloud in registers: the copy below is ordered behind it)
   int rc = reg_reserve(r, n);
   if (rc != WS_OK) return rc;
   r->n = n;
@@ -877,6 +922,7 @@ int ws_reg_prepare(ws_reg *r, const int32_t *xyz_host, size_t n)
 int ws_reg_prepare_dev(ws_reg *r, const int32_t *xyz_dev, size_t n)
 {
   if (!r || (!xyz_dev && n)) return invalid("ws_reg_prepare_dev: NULL argument");
+  servers_leave(r->ctx);
   int rc = reg_reserve(r, n);
   if (rc != WS_OK) return rc;
   r->n = n;
@@ -890,20 +936,111 @@ const int32_t *ws_reg_points_dev(const ws_reg *r, size_t *n)
   return r ? r->points : nullptr;
 }
 
+// ws_reg_iterate through the resident server (reg_server_kernel): see there.  Returns WS_OK with the 44 sums, or an error.
+static int reg_iterate_served(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, int64_t sums[44])
+{
+  auto exited = [&]() { return reg_server_mail_exited(r->srv_mail); };
+  auto wait_gone = [&](uint32_t id) -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (exited() != id)
+      if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+      {
+        WS_HIP(hipStreamSynchronize(r->ctx->stream));
+        if (exited() != id)
+        {
+          set_error("ws_reg_iterate: the resident server did not leave");
+          return WS_ERR_INTERNAL;
+        }
+      }
+    return WS_OK;
+  };
+  uint32_t id = r->srv_launch.load(std::memory_order_acquire);
+  bool alive = id != 0 && exited() != id;
+  const MapParams &par = m->par[WS_MAP_AVG];
+  const bool same = r->srv_sig.map == m && r->srv_sig.points == r->points && r->srv_sig.map_data == m->data[WS_MAP_AVG] && r->srv_sig.n == r->n &&
+                    r->srv_sig.res == res && r->srv_sig.flags == flags && std::memcmp(&r->srv_sig.par, &par, sizeof par) == 0;
+  if (alive && (!same || r->srv_stopping.load(std::memory_order_acquire)))
+  {
+    // somebody has enqueued other work behind that server (or the call is for another map / cloud): it must be gone before a
+    // request may be written -- it would answer from the state it was launched with
+    reg_server_mail_stop(r->srv_mail, id);
+    const int rc = wait_gone(id);
+    if (rc != WS_OK) return rc;
+    alive = false;
+  }
+  uint32_t seq = r->srv_seq + 1;
+  if (seq >= 0x7fffffffu) seq = 1;
+  r->srv_seq = seq;
+  reg_server_mail_write(r->srv_mail, T, seq);
+  auto launch = [&]() -> int {
+    id = ++r->srv_ids ? r->srv_ids : ++r->srv_ids;
+    r->srv_sig.map = m;
+    r->srv_sig.points = r->points;
+    r->srv_sig.map_data = m->data[WS_MAP_AVG];
+    r->srv_sig.n = r->n;
+    r->srv_sig.res = res;
+    r->srv_sig.flags = flags;
+    r->srv_sig.par = par;
+    r->srv_stopping.store(false, std::memory_order_release);
+    r->srv_launch.store(id, std::memory_order_release);
+    r->srv_launches += 1;
+    return launch_reg_server(r, m, res, flags, id, r->srv_served, r->srv_idle_us);
+  };
+  if (!alive)
+  {
+    const int rc = launch();
+    if (rc != WS_OK) return rc;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (reg_server_mail_done(r->srv_mail) != seq)
+  {
+    if (exited() == id)
+    {
+      // the server left (idle for too long, or asked to by another thread's call) without having seen this request
+      if (reg_server_mail_done(r->srv_mail) == seq) break;
+      const int rc = launch();
+      if (rc != WS_OK) return rc;
+    }
+    if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+    {
+      reg_server_mail_stop(r->srv_mail, id);
+      WS_HIP(hipStreamSynchronize(r->ctx->stream));
+      set_error("ws_reg_iterate: the resident server did not answer");
+      return WS_ERR_INTERNAL;
+    }
+  }
+  reg_server_mail_sums(r->srv_mail, sums);
+  r->srv_served = seq;
+  return WS_OK;
+}
+
 int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, int64_t h[36], int64_t g[6],
                    int32_t *e, int32_t *c)
 {
   if (!r || !m || !T || !h || !g || !e || !c) return invalid("ws_reg_iterate: NULL argument");
-  WS_SETTLE(m);
   if (res < 1) return invalid("ws_reg_iterate: map_resolution must be positive");
-  // One launch, nothing copied by the runtime: the pose travels in the kernel arguments (registration.cu:351 copies it), the
-  // sums come back through host-mapped memory with the call's sequence number behind them (registration.cu:356-365 copies
-  // four results and adds 32 partials up on the host).  The caller cannot go on without them, so the wait is a spin on that
-  // word -- bounded: after 20 ms the stream is synchronised the ordinary way, and a kernel that never ends is the runtime's to report.
-  const uint32_t seq = ++r->iter_seq ? r->iter_seq : ++r->iter_seq; // (never 0: the block starts zeroed)
-  int rc = launch_reg_host_iter(r, m, T, res, flags, seq);
-  if (rc != WS_OK) return rc;
+  int64_t sums[44];
+  if (r->srv_enabled && r->loop_supported)
   {
+    // (no WS_SETTLE here: that would ask the server to leave.  A scan whose verdict is open was enqueued by a call that has
+    // already done so, and is settled now; a living server implies a settled map)
+    const int rcs = ws::settle_tsdf(const_cast<ws_map *>(m));
+    if (rcs != WS_OK) return rcs;
+    const int rc = reg_iterate_served(r, m, T, res, flags, sums);
+    if (rc != WS_OK) return rc;
+  }
+  else
+  {
+    WS_SETTLE(m);
+    // One launch, nothing copied by the runtime: the pose travels in the kernel arguments (registration.cu:351 copies it), the
+    // sums come back through host-mapped memory with the call's sequence number behind them (registration.cu:356-365 copies
+    // four results and adds 32 partials up on the host).  The caller cannot go on without them, so the wait is a spin on that
+    // word -- bounded: after 20 ms the stream is synchronised the ordinary way, and a kernel that never ends is the runtime's to report.
+    const uint32_t seq = ++r->iter_seq ? r->iter_seq : ++r->iter_seq; // (never 0: the block starts zeroed)
+    int rc = launch_reg_host_iter(r, m, T, res, flags, seq);
+    if (rc != WS_OK) return rc;
     const volatile int64_t *done = r->iter_host + 44;
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
@@ -921,14 +1058,24 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    std::memcpy(sums, r->iter_host, sizeof sums);
   }
-  int64_t sums[44];
-  std::memcpy(sums, r->iter_host, sizeof sums);
   std::memcpy(h, sums, 36 * sizeof(int64_t));
   std::memcpy(g, sums + 36, 6 * sizeof(int64_t));
   *e = (int32_t)sums[42];
   *c = (int32_t)sums[43];
   return map_take_error(const_cast<ws_map *>(m));
+}
+
+// test / tuning entry: the resident server of ws_reg_iterate on or off, its idle time; returns the servers launched so far
+int ws_debug_reg_server(ws_reg *r, int32_t enable, int32_t idle_us, int32_t *launches)
+{
+  if (!r) return invalid("ws_debug_reg_server: reg is NULL");
+  servers_leave(r->ctx);
+  if (enable >= 0) r->srv_enabled = enable ? 1 : 0;
+  if (idle_us > 0) r->srv_idle_us = (uint32_t)idle_us;
+  if (launches) *launches = (int32_t)r->srv_launches;
+  return WS_OK;
 }
 
 int ws_reg_begin(ws_reg *r, const float T_in[16], int32_t max_iterations, float it_weight_gradient, float epsilon)

@@ -59,6 +59,11 @@ __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int mask)
 //   BIT 32, 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange exactly those halves of two registers
 //               (no select, no address): one VALU instruction per 32-bit register pair;
 //   BIT 8 .. 1: DPP lane permutations (row_ror:8, row_half_mirror + quad_perm, quad_perm).
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src_lane)
+{
+  const int lo = __shfl((int)(uint32_t)((uint64_t)v & 0xffffffffull), src_lane, 64), hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src_lane, 64);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
 __device__ __forceinline__ int64_t pack64(int lo, int hi) { return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); }
 
 template <int BIT>
@@ -1808,6 +1813,241 @@ __global__ __launch_bounds__(REG_THREADS) void reg_host_iter_kernel(HostIterArgs
   }
 }
 
+// ---- ... and WITHOUT a launch per call: a resident server (round 6) ----
+// The reference's caller is unchanged -- perform_registration once per Gauss-Newton iteration, the solve on the host between
+// two calls (tsdf_registration.cpp:55-92) -- and with one launch per call an iteration cost 19.8 us, of which the kernel is 3:
+// the rest is the launch.  This kernel stays on the GPU ACROSS calls.  ws_reg_iterate writes the pose and a request number into
+// one 64-byte line of host-mapped memory (ServerMail); workgroup 0 polls that line (one read gets request number and pose: only
+// twelve of the pose's sixteen floats are used, cu_to_int_mat / registration.cu:208, the other slots carry the number, a stop
+// word and a checksum of the snapshot), hands the pose to the other workgroups through device memory, every workgroup does its
+// share of calc_jacobis + the reduction (the scan's points stay in registers from call to call), the last one to arrive writes
+// the 44 sums and the request number back into host-mapped memory, where the host spins.  The server leaves when nothing has
+// been asked for `idle_ticks` (50 us), or at once when the host says so (any other entry point that enqueues work on the
+// stream: that work is ordered behind this kernel); ws_reg_iterate starts a new one when it finds none.  A request that
+// meets a leaving server is not lost: the number stays in the line, the host sees `exited` without `done` and launches again.
+struct ServerMail // host-mapped, 64-byte aligned
+{
+  uint32_t line[16];  // host -> device: pose words 0-2, 4-6, 8-10, 12-14 (column-major, rows 0-2); [3] request number (written
+                      // last), [7] id of the launch the host wants gone, [11] checksum of the pose words and the number
+  uint32_t pad[16];
+  int64_t sums[44];   // device -> host
+  int64_t done;       // device -> host: number of the request the sums belong to (written last)
+  int64_t exited;     // device -> host: id of the last launch that has left the GPU
+};
+static_assert(offsetof(ServerMail, sums) == 128, "ServerMail");
+size_t reg_server_mail_bytes() { return sizeof(ServerMail); }
+__host__ __device__ inline uint32_t server_checksum(const uint32_t *line)
+{
+  uint32_t c = 0x5bd1e995u ^ line[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c = (c << 5 | c >> 27) ^ line[j * 4 + i];
+  return c;
+}
+void reg_server_mail_write(void *mail, const float T[16], uint32_t seq)
+{
+  ServerMail *m = static_cast<ServerMail *>(mail);
+  uint32_t line[16] = {};
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 3; ++i) std::memcpy(&line[j * 4 + i], &T[j * 4 + i], 4);
+  line[3] = seq;
+  volatile uint32_t *dst = m->line;
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 3; ++i) dst[j * 4 + i] = line[j * 4 + i];
+  dst[11] = server_checksum(line);
+  std::atomic_thread_fence(std::memory_order_release);
+  dst[3] = seq; // the request is complete
+}
+void reg_server_mail_stop(void *mail, uint32_t launch_id)
+{
+  volatile uint32_t *dst = static_cast<ServerMail *>(mail)->line;
+  dst[7] = launch_id;
+}
+uint32_t reg_server_mail_done(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->done); }
+uint32_t reg_server_mail_exited(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->exited); }
+void reg_server_mail_sums(const void *mail, int64_t sums[44])
+{
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const volatile int64_t *src = static_cast<const ServerMail *>(mail)->sums;
+  for (int k = 0; k < 44; ++k) sums[k] = src[k];
+}
+
+// Device memory of the server (ws_reg::srv_ctl, zero at creation, never reset afterwards):
+//   lines[REG_GROUPS][16]   the host's line as workgroup 0 has copied it, once per group of 32 workgroups: what a workgroup
+//                           polls -- request number, stop word, checksum and pose in ONE 64-byte read, 32 pollers per line
+//   accum[REG_GROUPS][64]   counted accumulators (as in reg_loop_kernel): every workgroup ADDS its 32 sums, as low / high
+//                           halves whose top byte counts the additions; workgroup 0 polls them until every count has moved
+//                           by 32 -- no arrival counter (256 returning atomics on one address are 10 us: tools/doorbell_bench.hip,
+//                           12.5 us per round trip with them against 3.0 for the host <-> kernel hop alone), no partials, no second pass
+//   then[REG_GROUPS][64]    the accumulators as they stood after the last answered request (kept from launch to launch)
+struct ServerCtl
+{
+  uint32_t lines[REG_GROUPS][16];
+  uint64_t accum[REG_GROUPS][REG_WORDS];
+  uint64_t then[REG_GROUPS][REG_WORDS];
+};
+size_t reg_server_ctl_bytes() { return sizeof(ServerCtl); }
+struct ServerArgs
+{
+  PointArgs pts;
+  ServerCtl *ctl;
+  ServerMail *mail;  // device view
+  uint32_t launch_id;
+  uint32_t served;   // the last request number that was answered before this launch
+  uint32_t idle_ticks; // of the 100 MHz clock
+};
+
+// one poll of a 16-word line by lanes 0..15 of a wave: 0 = nothing new, 1 = a request (number in `seq`, pose in `w`), 2 = leave
+__device__ __forceinline__ int server_line_state(uint32_t w /* lane l < 16: word l */, uint32_t served, uint32_t launch_id, uint32_t &seq)
+{
+  seq = (uint32_t)__builtin_amdgcn_readlane((int)w, 3);
+  if ((uint32_t)__builtin_amdgcn_readlane((int)w, 7) == launch_id) return 2;
+  if (seq == served || seq == 0) return 0;
+  // a consistent snapshot?  (the writer stores the number last; a read that saw it and not all of the pose -- torn in two on the
+  // way -- fails the checksum and is simply repeated)
+  uint32_t c = 0x5bd1e995u ^ seq;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c = (c << 5 | c >> 27) ^ (uint32_t)__builtin_amdgcn_readlane((int)w, j * 4 + i);
+  return c == (uint32_t)__builtin_amdgcn_readlane((int)w, 11) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(REG_THREADS) void reg_server_kernel(ServerArgs a)
+{
+  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t red[REG_SLOTS];
+  __shared__ float T_sh[16];
+  __shared__ uint32_t bell_sh; // 0: leave
+  const Prefetched f = prefetch_points(a.pts); // the cloud does not change while a server lives (ws_reg_prepare* stops it)
+  constexpr uint32_t per_group = REG_BLOCKS / REG_GROUPS;
+  const int lane = threadIdx.x & 63;
+  const int group = (int)(blockIdx.x / per_group);
+  uint32_t served = a.served;
+  uint64_t then[REG_GROUPS];
+  if (blockIdx.x == 0 && threadIdx.x < 64)
+  {
+#pragma unroll
+    for (int g = 0; g < REG_GROUPS; ++g) then[g] = a.ctl->then[g][lane];
+  }
+  for (;;)
+  {
+    // ---- wave 0 waits for a request
+    if (threadIdx.x < 64)
+    {
+      uint32_t w = 0, seq = 0;
+      int state;
+      if (blockIdx.x == 0)
+      {
+        // the host's line: lanes 0..15 read one word each, in ONE instruction (a 64-byte read of host memory)
+        const long long t0 = wall_clock64();
+        for (;;)
+        {
+          if (lane < 16) w = __hip_atomic_load(&a.mail->line[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          state = server_line_state(w, served, a.launch_id, seq);
+          if (state != 0) break;
+          if (wall_clock64() - t0 > (long long)a.idle_ticks)
+          {
+            state = 2;
+            w = lane == 7 ? a.launch_id : 0u; // (a line that says "leave" to the other workgroups)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        // hand it to the other workgroups: one copy per group
+        if (lane < 16)
+        {
+#pragma unroll
+          for (int g = 0; g < REG_GROUPS; ++g) __hip_atomic_store(&a.ctl->lines[g][lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      else
+      {
+        for (;;)
+        {
+          if (lane < 16) w = __hip_atomic_load(&a.ctl->lines[group][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          state = server_line_state(w, served, a.launch_id, seq);
+          if (state != 0) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      if (lane < 16) T_sh[lane] = __uint_as_float(w);
+      if (lane == 0) bell_sh = state == 1 ? seq : 0u;
+    }
+    __syncthreads();
+    const uint32_t bell = bell_sh;
+    if (bell == 0) break;
+    // ---- perform_registration (registration.cu:347-368) for that pose
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+    int64_t acc[REG_SLOTS];
+#pragma unroll
+    for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+    accumulate_points(a.pts, T, f, acc);
+    block_reduce32(acc, wave_part, red); // (its barriers also keep T_sh / bell_sh from being rewritten while anybody reads them)
+    if (threadIdx.x < 64)
+    {
+      const uint64_t s = (uint64_t)red[lane & (REG_SLOTS - 1)];
+      const uint32_t half = lane < REG_SLOTS ? (uint32_t)(s & 0xffffffffull) : (uint32_t)(s >> 32);
+      __hip_atomic_fetch_add(&a.ctl->accum[group][lane], REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0)
+      {
+        // ---- all 256 additions, then the 44 words of the reference's h, g, e, c to the host
+        uint64_t wv[REG_GROUPS];
+        for (;;)
+        {
+          bool ok = true;
+#pragma unroll
+          for (int g = 0; g < REG_GROUPS; ++g)
+          {
+            wv[g] = __hip_atomic_load(&a.ctl->accum[g][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (((wv[g] - then[g]) >> 56) & 0xffu) == (uint64_t)per_group;
+          }
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        uint64_t sum = 0;
+#pragma unroll
+        for (int g = 0; g < REG_GROUPS; ++g)
+        {
+          sum += (wv[g] - then[g]) & REG_SUM_MASK;
+          then[g] = wv[g];
+        }
+        const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)sum, 32);
+        const int64_t total = (int64_t)(sum + (high << 32)); // lanes 0 .. 31: the total of slot `lane`
+        // expand_sums, one lane per word: lane k < 44 fetches the term it needs from the lane that holds it
+        int src = 0;
+        if (lane < 36)
+        {
+          const int i = lane % 6, j = lane / 6;
+          src = i <= j ? tri_index(i, j) : tri_index(j, i);
+        }
+        else if (lane < 42)
+          src = 21 + (lane - 36);
+        else if (lane < 44)
+          src = 27 + (lane - 42);
+        int64_t v = shfl_i64(total, src);
+        if (lane >= 42) v = (int64_t)(int32_t)v; // e and c are `int` in the reference (registration.cu:16-21)
+        if (lane < 44) __hip_atomic_store(&a.mail->sums[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&a.mail->done, (int64_t)bell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    served = bell;
+  }
+  // ---- workgroup 0 leaves the accumulators' state for the next launch and tells the host that this one is gone (the others
+  // have seen the same line and do nothing more; the next launch is ordered behind the end of this kernel)
+  if (blockIdx.x == 0 && threadIdx.x < 64)
+  {
+#pragma unroll
+    for (int g = 0; g < REG_GROUPS; ++g) a.ctl->then[g][lane] = then[g];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&a.mail->exited, (int64_t)a.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // test entry: the wave solver alone, one wave per system (A row-major 6x6, b) -> x, status
 __global__ __launch_bounds__(64) void solve6_test_kernel(const double *A, const double *b, double *x, int32_t *status)
 {
@@ -1889,6 +2129,23 @@ int launch_reg_host_iter(ws_reg *r, const ws_map *m, const float T[16], int32_t 
   a.seq = seq;
   prof_begin(ctx, WS_K_REG);
   hipLaunchKernelGGL(reg_host_iter_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  prof_end(ctx, WS_K_REG);
+  WS_HIP(hipGetLastError());
+  return WS_OK;
+}
+
+int launch_reg_server(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, uint32_t launch_id, uint32_t served, uint32_t idle_us)
+{
+  ws_context *ctx = r->ctx;
+  ServerArgs a;
+  a.pts = make_point_args(r, m, res, flags, 0, r->n);
+  a.ctl = reinterpret_cast<ServerCtl *>(r->srv_ctl);
+  a.mail = static_cast<ServerMail *>(r->srv_mail_dev);
+  a.launch_id = launch_id;
+  a.served = served;
+  a.idle_ticks = idle_us * 100u; // wall_clock64: 100 MHz
+  prof_begin(ctx, WS_K_REG);
+  hipLaunchKernelGGL(reg_server_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;

@@ -130,9 +130,37 @@ __device__ __forceinline__ uint32_t tile_of(int32_t nty, int32_t ntz, int32_t sx
   const uint32_t col = __umul24((uint32_t)(sx >> TILE_XB), (uint32_t)nty) + (uint32_t)(sy >> TILE_YB);
   return __umul24(col, (uint32_t)ntz) + (uint32_t)(sz >> TILE_ZB);
 }
+// The voxel inside its tile, twice, straight from the storage coordinates: `local` = lx | ly | lz, z fastest -- what a record
+// carries and the resolve's LDS arrays are indexed by (a column's 64 z spread over all banks; round 6 measured records in brick
+// order: the resolve 107 -> 116 us, a wall's records then fall on 8 banks) -- and `vox` = vbrick(local), its byte in the tile's
+// kilobyte of voxel bytes (ws_internal.h).
+static_assert(TILE_XB == 2 && TILE_YB == 2 && TILE_ZB == 6, "vox_of / vbrick: 4 x 4 x 8 bricks of a 4 x 4 x 64 tile");
+__device__ __forceinline__ uint32_t vox_of(int32_t sx, int32_t sy, int32_t sz)
+{
+  const uint32_t xy = (((uint32_t)sx & 3u) << 2) | ((uint32_t)sy & 3u);
+  return (((uint32_t)sz & 0x38u) << 4) | (xy << 3) | ((uint32_t)sz & 7u);
+}
 __device__ __forceinline__ uint32_t local_of(int32_t sx, int32_t sy, int32_t sz)
 {
-  return (uint32_t)(((sx & ((1 << TILE_XB) - 1)) << (TILE_YB + TILE_ZB)) | ((sy & ((1 << TILE_YB) - 1)) << TILE_ZB) | (sz & ((1 << TILE_ZB) - 1)));
+  const uint32_t xy = (((uint32_t)sx & 3u) << 2) | ((uint32_t)sy & 3u);
+  return (xy << TILE_ZB) | ((uint32_t)sz & 63u);
+}
+// vbrick backwards (the rare free-space candidate that becomes a record)
+__device__ __forceinline__ uint32_t local_of_vox(uint32_t vox) { return ((vox & 0x78u) << 3) | ((vox >> 4) & 0x38u) | (vox & 7u); }
+// Byte `vox` of tile `tile` in a plane of voxel bytes / record place `pos` of sub-chunk `id`.  SMALL: the planes and the pool are
+// below 4 GB (every map up to 1025^3; decided per launch): the offset is ONE 32-bit instruction next to a base address in scalar
+// registers, instead of a 64-bit shift and two 64-bit additions per access -- the marches are bound by vector-instruction issue.
+template <bool SMALL>
+__device__ __forceinline__ uint8_t *vox_ptr(uint8_t *plane, uint32_t tile, uint32_t vox)
+{
+  if (SMALL) return plane + (uint32_t)((tile << 10) | vox);
+  return plane + (((size_t)tile << 10) | vox);
+}
+template <bool SMALL>
+__device__ __forceinline__ unsigned long long *rec_ptr(unsigned long long *pool, uint32_t id, uint32_t pos)
+{
+  if (SMALL) return reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(pool) + (uint32_t)((((id << SUB_BITS) | pos)) << 3));
+  return pool + (((size_t)id << SUB_BITS) | pos);
 }
 
 // everything the scatter expects to be zero / empty, in ONE launch (after map creation and after the buffers were resized:
@@ -220,11 +248,13 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
   RaySetup r;
   r.dx = r.dy = r.dz = r.distance = r.ivx = r.ivy = r.ivz = r.steps = 0;
   r.div_m = 0;
+  r.spare = 0;
   r.div_k = 0;
   r.pad = 0;
   r.kfirst = 0;
   r.ub = 0;
   const int32_t res = a.res, tau = a.tau, half = res / 2;
+  const bool frame_biased_ok = make_march_frame(a.scanner_pos, res, tau, a.map).biased_ok;
   bool ok = false;
   int32_t px = 0, py = 0, pz = 0;
   int32_t hvx = 0, hvy = 0, hvz = 0; // voxel of the scan point
@@ -293,7 +323,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
           r.ivx = (int32_t)ivx; r.ivy = (int32_t)ivy; r.ivz = (int32_t)ivz;
           r.steps = (int32_t)steps;
           const FastDiv fd = make_fastdiv_dev(distance);
-          r.div_m = fd.M;
+          r.div_m = (uint32_t)fd.M; // (below 2^32: make_fastdiv)
           r.div_k = fd.k;
           // conditions of march_steps_fast (ws_march.h): no int32 wrap in d*len, pos + d, voxel centres,
           // delta_z*iv and step*res*iv, nor in the squared distance to the hit point (|p - centre| <= len_end + 2 res)
@@ -316,7 +346,7 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
             const int64_t endx = (int64_t)posx + div_trunc_i64((int64_t)dx * len_end, distance), endy = (int64_t)posy + div_trunc_i64((int64_t)dy * len_end, distance),
                           endz = (int64_t)posz + div_trunc_i64((int64_t)dz * len_end, distance);
             const int64_t ev[3] = {div_trunc_i64(endx, res), div_trunc_i64(endy, res), div_trunc_i64(endz, res)};
-            bool inside = fast;
+            bool inside = fast && frame_biased_ok; // (div_res_b / ring_b, ws_march.h: the window's coordinates fit their bias)
             for (int k = 0; k < 3; ++k)
             {
               const int64_t lim = (int64_t)(a.map.size[k] / 2) - margin;
@@ -586,6 +616,9 @@ __device__ __forceinline__ void append_single(const ScatterArgs &a, uint32_t til
 // ---------------------------------------------------------------------------------------------------------
 // ray tails -> records, straight into sub-chunks of their tiles
 // ---------------------------------------------------------------------------------------------------------
+#ifndef WS_TAIL_KO
+#define WS_TAIL_KO 0 // knock-out builds for timing (results wrong): 1 no voxel-byte stores, 2 no record store, 4 no table / record at all, 8 no rounds, 16 no publishing at the end
+#endif
 #ifndef WS_TAIL_WGS
 #define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (six: 80 VGPRs, 16 of them spilled, 234 instead of 187 us)
 #endif
@@ -775,6 +808,7 @@ __device__ __forceinline__ uint32_t wave_room(const ScatterArgs &a, WaveTab &wt)
 
 // one record of the wave: its tile's slot, its rank there, the sub-chunk (opened by the record of rank 0 mod 32), its place
 // Returns bit 0: the record opened a sub-chunk, bit 1: its tile is new in the table (what the caller's room shrinks by).
+template <bool SMALL>
 __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, uint32_t tile, unsigned long long rec)
 {
   bool fresh = false;
@@ -797,7 +831,11 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
   asm volatile("" ::: "memory");
   const uint32_t gl = wt.sub_of[s][sub & 3u];
   const uint32_t base = wt.blk[(gl >> 5) & 7u];
-  if (base != SUB_LOST) a.rec[((size_t)(base + (gl & 31u)) << SUB_BITS) + pos] = rec;
+#if WS_TAIL_KO & 2
+  if (base != SUB_LOST && rec == 0x12345ull) *rec_ptr<SMALL>(a.rec, base + (gl & 31u), pos) = rec; // (never)
+#else
+  if (base != SUB_LOST) *rec_ptr<SMALL>(a.rec, base + (gl & 31u), pos) = rec;
+#endif
   return (pos == 0 ? 1u : 0u) | (fresh ? 2u : 0u);
 }
 
@@ -807,6 +845,7 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
 // (Round 4 measured two other shapes first: the records through a slice of a raw buffer in HBM and a copy by the workgroup
 // into 2 KB chunks per tile -- 226-233 us, 66 of them the copy; and staged in LDS, flushed whenever the area filled up --
 // 243-258 us, it costs two workgroups per CU of occupancy.)
+template <bool SMALL>
 __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
   __shared__ WaveTab s_tab[4];
@@ -875,15 +914,15 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     // the free-space pass must know that this voxel takes part in the key order
     // (as a non-temporal store -- the marks push the half-filled sub-chunk lines out of the L2: 380 MB of writes for 98 MB of
     // records -- the kernel takes 462 instead of 183 us)
-    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), local = local_of(sx, sy, sz);
-    if (mark) a.vstate[((size_t)tile << 10) + vbrick(local)] = VOX_KEYED;
-    used = wave_put(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local, REC_S(a), REC_F(a)));
+    const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), vox = vox_of(sx, sy, sz);
+    if (mark) *vox_ptr<SMALL>(a.vstate, tile, vox) = VOX_KEYED;
+    used = wave_put<SMALL>(a, wt, tile, make_rec(rix, k, fan_minus_mid, value, local_of(sx, sy, sz), REC_S(a), REC_F(a)));
     return tile;
   };
   // an off-ray candidate of value +tau: (tau, -64) whoever makes it, never ordered (see ray_setup_block) -> a mark in the second plane
   auto mark_negative = [&](int32_t sx, int32_t sy, int32_t sz, uint32_t listed_tile) {
     const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-    vneg[((size_t)tile << 10) + vbrick(local_of(sx, sy, sz))] = 1;
+    *vox_ptr<SMALL>(vneg, tile, vox_of(sx, sy, sz)) = 1;
     // (the tile of the sample's on-ray record is on the list through that record -- nearly always this tile too; any other gets
     // the byte the resolve scans for.  A blind store: a load here would be a wait for everything the wave has in flight.)
     if (tile != listed_tile) a.tile_dirty[tile] = 1;
@@ -921,7 +960,9 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     uint32_t qhead = 0, qtail = 0;
     uint32_t cap_left = 0; // records the wave may put before it looks at its bookkeeping again (uniform)
     const int32_t res = f.res, half = f.half, tau = f.tau, dist = r.distance;
-    const int32_t hitx = f.posx + r.dx, hity = f.posy + r.dy, hitz = f.posz + r.dz; // the scan point (update_tsdf.cu:57)
+    // the scan point (update_tsdf.cu:57), shifted by divB - half: what the biased voxel index of div_res_b is subtracted from
+    const int32_t hshift = (int32_t)f.divB - half;
+    const int32_t hitbx = f.posx + r.dx + hshift, hitby = f.posy + r.dy + hshift, hitbz = f.posz + r.dz + hshift;
     AxisRun ix0, iy0, iz0;
     ix0.r = ix0.ar = ix0.aq = ix0.q = ix0.spos = ix0.sm = 0;
     ix0.gap = 0x3fffffff;
@@ -937,8 +978,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
     }
     // the branch-free sample step of ws_march.h (lanes that are through keep stepping, masked)
     AxisFast wx = fast_from(ix0, work ? dist : 1), wy = fast_from(iy0, work ? dist : 1), wz = fast_from(iz0, work ? dist : 1);
-    auto push = [&](bool cand, bool cx, bool cy) {
-      const unsigned long long mask = __ballot(cand);
+    auto push = [&](unsigned long long mask /* ballot of cand */, bool cand, bool cx, bool cy) {
       if (mask == 0) return;
       if (cand)
       {
@@ -957,7 +997,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // of the loop, so that every iteration is "step, then test"
       bool first = false;
       if (work && k0 == 0) first = div_res(fast_proj(wx, false, res), f) != 0 || div_res(fast_proj(wy, false, res), f) != 0;
-      push(first, false, false);
+      push(__ballot(first), first, false, false);
       if (work && k0 == 0) k = 1;
     }
     int32_t todo = work ? k1 - k : 0;
@@ -973,16 +1013,17 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       qhead += n;
       // constants of the ray the sample belongs to (a lane of this wave)
       const int src = (int)(e.w >> 16);
-      const int32_t s_hitx = __shfl(hitx, src, 64), s_hity = __shfl(hity, src, 64), s_hitz = __shfl(hitz, src, 64);
+      const int32_t s_hitx = __shfl(hitbx, src, 64), s_hity = __shfl(hitby, src, 64), s_hitz = __shfl(hitbz, src, 64);
       const int32_t s_ivx = __shfl(r.ivx, src, 64), s_ivy = __shfl(r.ivy, src, 64), s_ivz = __shfl(r.ivz, src, 64);
       const int32_t s_dist = __shfl(r.distance, src, 64);
       const uint32_t s_ix = (uint32_t)__shfl((int)ix, src, 64);
       const int32_t ek = (int32_t)(e.w & 0xffffu);
       const int32_t projx = (int32_t)e.x, projy = (int32_t)e.y, projz = (int32_t)e.z;
       const int32_t len = 1 + ek * half;
-      // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact)
-      const int32_t ddx = s_hitx - (__mul24(div_res(projx, f), res) + half), ddy = s_hity - (__mul24(div_res(projy, f), res) + half),
-                    ddz = s_hitz - (__mul24(div_res(projz, f), res) + half);
+      // update_tsdf.cu:81-98 (no int32 wrap for a RAY_SIMPLE ray: 24-bit multiplies are exact).  The voxel's index comes biased by
+      // divBq (div_res_b): centre = (q - divBq) res + half, and the hit point was shifted by divB - half once per ray
+      const int32_t ddx = s_hitx - (int32_t)__umul24(div_res_b(projx, f), (uint32_t)res), ddy = s_hity - (int32_t)__umul24(div_res_b(projy, f), (uint32_t)res),
+                    ddz = s_hitz - (int32_t)__umul24(div_res_b(projz, f), (uint32_t)res);
       int32_t value = (int32_t)sqrtf((float)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz)));
       value = value < tau ? value : tau;
       if (len > s_dist) value = -value;
@@ -1001,16 +1042,20 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       if (!__any(iter_steps > 0)) return;
       // the off-ray targets of a sample of value +tau are marks, not records
       const bool blind = mark && value == tau;
-      const int32_t lowx = projx - trunc_shift15(__mul24(delta_z, s_ivx)), lowy = projy - trunc_shift15(__mul24(delta_z, s_ivy)),
-                    lowz = projz - trunc_shift15(__mul24(delta_z, s_ivz));
-      auto target = [&](int32_t step, int32_t &sx, int32_t &sy, int32_t &sz) {
-        const int32_t sm = step * res;
-        const int32_t vx = div_res(lowx + trunc_shift15(__mul24(sm, s_ivx)), f), vy = div_res(lowy + trunc_shift15(__mul24(sm, s_ivy)), f),
-                      vz = div_res(lowz + trunc_shift15(__mul24(sm, s_ivz)), f);
-        sx = ring_fast(vx, f.ringK[0], a.map.size[0]);
-        sy = ring_fast(vy, f.ringK[1], a.map.size[1]);
-        sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
-      };
+      const unsigned long long m_blind = mark ? __ballot(value == tau) : 0ull;
+      // The fan (update_tsdf.cu:107-112): target j = (lowest + trunc(j res iv / 32768)) / res.  The products grow by res * iv
+      // from one fan step to the next and their sign is iv's: `acc` carries j res iv + (iv < 0 ? 32767 : 0), the truncating
+      // division by 32768 is its arithmetic shift -- one add and one shift per axis and round instead of multiply, sign, mask,
+      // add, shift (round 6; the three multiply-shift divisions by res and the ring buffer: div_res_b / ring_b, ws_march.h)
+      const int32_t bx = iv_bias(s_ivx), by = iv_bias(s_ivy), bz = iv_bias(s_ivz);
+      const int32_t lowx = projx - trunc15_biased(delta_z, s_ivx, bx), lowy = projy - trunc15_biased(delta_z, s_ivy, by),
+                    lowz = projz - trunc15_biased(delta_z, s_ivz, bz);
+      const int32_t incx = __mul24(res, s_ivx), incy = __mul24(res, s_ivy), incz = __mul24(res, s_ivz);
+      int32_t accx = bx, accy = by, accz = bz;
+      // the parts of the record that belong to the sample (make_rec, ws_internal.h): u = step << F | fan, fan = round - mid + MID
+      const int32_t recS = REC_S(a), recF = REC_F(a);
+      const uint32_t rec_hi0 = s_ix << (recS + recF - 6), rec_lo0 = ((uint32_t)value & 0xffffu) << REC_VALUE_SHIFT;
+      const uint32_t rec_u0 = ((uint32_t)ek << recF) + rec_fan_mid(recF) - (uint32_t)mid;
       // Rounds of at most one target per lane, fan step by fan step (update_tsdf.cu:107-125) IN THE FAN'S OWN ORDER: round j is
       // fan step j of every sample whose fan has more than j steps -- the on-ray target (always a record) where j == mid, an
       // off-ray one (a record, or a mark for a sample of value +tau) elsewhere.  The samples of a batch come from rays that
@@ -1019,30 +1064,55 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // sat out the round j == mid: 381 k rounds of 59 % instead of 244 k for the benchmark scan's 14.4 M targets.)  In front
       // of every round the wave makes sure its bookkeeping has room for the records of the round (a scalar compare, nearly always).
       uint32_t mid_tile = 0xffffffffu; // the tile of the sample's on-ray record, once that is made (it is on the list through it)
+#if WS_TAIL_KO & 8
+      if ((rec_hi0 ^ rec_u0 ^ (uint32_t)lowx ^ (uint32_t)lowy ^ (uint32_t)lowz ^ (uint32_t)incx ^ (uint32_t)incy ^ (uint32_t)incz ^ m_blind) == 0x12345u)
+#endif
       for (int32_t round = 0;; ++round)
       {
         // (the loop bound as a ballot per round: a maximum over the lanes by shuffles is six trips through the LDS pipe per emit phase)
-        if (!__any(round < iter_steps)) break;
+        const unsigned long long m_on = __ballot(round < iter_steps);
+        if (m_on == 0) break;
         const bool on = round < iter_steps;
         const bool onray = round == mid;
         const bool puts = on && (onray || !blind);
-        const uint32_t n_put = (uint32_t)__popcll(__ballot(puts));
+        const uint32_t n_put = (uint32_t)__popcll(m_on & (__ballot(onray) | ~m_blind)); // ballot(puts), from scalar masks
         if (n_put)
         {
           // (every record of the round could open a sub-chunk and bring a new tile: room for that, then count what they did)
           if (cap_left < n_put) cap_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_room(a, wt));
           n_written += n_put;
         }
+        // the target's storage coordinates (all lanes: the fan's state moves on in every round)
+        const int32_t sx = ring_b(div_res_b(lowx + (accx >> 15), f), f.ringB[0], a.map.size[0]),
+                      sy = ring_b(div_res_b(lowy + (accy >> 15), f), f.ringB[1], a.map.size[1]),
+                      sz = ring_b(div_res_b(lowz + (accz >> 15), f), f.ringB[2], a.map.size[2]);
+        accx += incx;
+        accy += incy;
+        accz += incz;
         uint32_t used = 0;
         if (on)
         {
-          int32_t sx, sy, sz;
-          target(round, sx, sy, sz);
+          const uint32_t tile = tile_of(a.nty, a.ntz, sx, sy, sz), vox = vox_of(sx, sy, sz);
           if (!puts)
-            mark_negative(sx, sy, sz, mid_tile);
+          {
+            // an off-ray candidate of value +tau: a mark in the second plane (mark_negative)
+#if !(WS_TAIL_KO & 1)
+            *vox_ptr<SMALL>(vneg, tile, vox) = 1;
+            if (tile != mid_tile) a.tile_dirty[tile] = 1;
+#endif
+          }
           else
           {
-            const uint32_t tile = put_record(s_ix, ek, round - mid, value, sx, sy, sz, used);
+#if !(WS_TAIL_KO & 1)
+            if (mark) *vox_ptr<SMALL>(a.vstate, tile, vox) = VOX_KEYED;
+#endif
+            const uint32_t u = rec_u0 + (uint32_t)round;
+            const uint32_t hi = rec_hi0 | (u >> 6), lo = (u << REC_T_SHIFT) | rec_lo0 | local_of(sx, sy, sz);
+#if WS_TAIL_KO & 4
+            if ((hi ^ lo ^ tile) == 0x12345u) used = wave_put<SMALL>(a, wt, tile, ((unsigned long long)hi << 32) | lo); // (never: keeps the arithmetic alive)
+#else
+            used = wave_put<SMALL>(a, wt, tile, ((unsigned long long)hi << 32) | lo);
+#endif
             if (onray) mid_tile = tile;
           }
         }
@@ -1058,7 +1128,8 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
       // ---- sample phase
       const bool cx = fast_step(wx, res), cy = fast_step(wy, res);
       fast_step_z(wz);
-      push((cx || cy) && k < k1, cx, cy);
+      // (ballots of the simple conditions, combined as scalars: the ballot of a conjunction costs two vector instructions more)
+      push((__ballot(cx) | __ballot(cy)) & __ballot(k < k1), (cx || cy) && k < k1, cx, cy);
       k += 1;
       // ---- emit phase: 64 queued samples, one per lane
       if (qtail - qhead >= 64) emit_batch();
@@ -1069,7 +1140,9 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   const long long t_mid = wall_clock64();
 #endif
   // ---- phase 2: the wave publishes what it has filled
+#if !(WS_TAIL_KO & 16)
   wave_flush<true>(a, wt);
+#endif
   if (lane == 0)
   {
     atomicAdd(&s_stat[0], n_written + wt.n_rec);
@@ -1092,12 +1165,13 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
 #endif
 }
 
+template <bool SMALL> // SMALL: 32-bit offsets into the voxel bytes and the record pool (vox_ptr)
 __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
 {
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
-  if (blockIdx.x < n_items) tail_item(a, blockIdx.x);
+  if (blockIdx.x < n_items) tail_item<SMALL>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1109,26 +1183,24 @@ __global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArg
 // path to 122 us; what remains is the scattered byte traffic itself (21 M byte loads, 9 M byte stores, one cache line each).
 struct FreePending
 {
-  int64_t idx;   // voxel (storage index)
   uint32_t tile;
-  uint32_t local; // voxel inside the tile
+  uint32_t vox;  // voxel inside the tile (brick order: vox_of)
   uint32_t ix;   // ray
   int32_t k;     // ray step
-  uint32_t b;    // the voxel's byte (in flight until the next emit phase)
+  uint32_t b;    // the voxel's byte (in flight until the next step)
   bool valid;
 };
-__device__ __forceinline__ void free_request(const ScatterArgs &a, const MarchFrame &f, FreePending &p, bool valid, uint32_t ix, int32_t k, int32_t vx, int32_t vy,
-                                             int32_t vz)
+// sx, sy, sz: storage coordinates of the candidate's voxel
+template <bool SMALL>
+__device__ __forceinline__ void free_request(const ScatterArgs &a, FreePending &p, bool valid, uint32_t ix, int32_t k, int32_t sx, int32_t sy, int32_t sz)
 {
-  const int32_t sx = ring_fast(vx, f.ringK[0], a.map.size[0]), sy = ring_fast(vy, f.ringK[1], a.map.size[1]),
-                sz = ring_fast(vz, f.ringK[2], a.map.size[2]);
   p.valid = valid;
-  p.tile = tile_of(a.nty, a.ntz, sx, sy, sz);
-  p.local = local_of(sx, sy, sz);
-  p.idx = valid ? (int64_t)(((uint64_t)p.tile << 10) + vbrick(p.local)) : 0; // unconditional (clamped) load: nothing waits for it here
+  // unconditional (clamped) load: nothing waits for it here
+  p.tile = valid ? tile_of(a.nty, a.ntz, sx, sy, sz) : 0u;
+  p.vox = valid ? vox_of(sx, sy, sz) : 0u;
   p.ix = ix;
   p.k = k;
-  p.b = a.vstate[p.idx];
+  p.b = *vox_ptr<SMALL>(a.vstate, p.tile, p.vox);
 }
 // the sub-chunks of the records the free pass makes (one each): a wave of the compacting walk keeps the rest of the 64 it
 // took from the pool (fb_next, fb_left: uniform); the general walk -- lanes in varying company -- asks for what it needs
@@ -1136,12 +1208,13 @@ struct FreeBlock
 {
   uint32_t next, left;
 };
-template <bool CACHED, bool TILE_MARK = true, bool STORE = true> // TILE_MARK false: the caller marks the candidate's tile itself; STORE false: the keyed half only
+template <bool CACHED, bool SMALL>
 __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePending &p, uint32_t &n_keyed, FreeBlock &fb)
 {
   const uint32_t b = p.b;
+  // (the ballot of a conjunction goes through a vector register and back -- v_cndmask + v_cmp; two ballots and a scalar AND do not)
+  const unsigned long long km = __ballot(p.valid) & __ballot((b & VOX_KEYED) != 0);
   const bool keyed = p.valid && (b & VOX_KEYED);
-  const unsigned long long km = __ballot(keyed);
   if (km)
   {
     // the voxel also has ordered candidates (from the tails): this one, (tau, +64) at its place in the order, joins the
@@ -1176,32 +1249,32 @@ __device__ __forceinline__ void free_finish(const ScatterArgs &a, const FreePend
     {
       const uint32_t id = first == SUB_LOST ? SUB_LOST : first + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
       // (the answer of the atomic in there picked up one emit phase later, under the next batch's voxel bytes: no gain, measured)
-      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, p.local, REC_S(a), REC_F(a)));
+      append_single(a, p.tile, id, make_rec(p.ix, p.k, 0, a.tau, local_of_vox(p.vox), REC_S(a), REC_F(a)));
       n_keyed += 1;
     }
   }
-  if (STORE && p.valid && b == 0)
+  if (p.valid && b == 0)
   {
     // free space only (the common case): the result will be (tau, 64) whoever comes first.  (Two candidates of one voxel
     // whose loads both saw 0 both store: idempotent.)
-    a.vstate[p.idx] = VOX_TOUCHED;
+    *vox_ptr<SMALL>(a.vstate, p.tile, p.vox) = VOX_TOUCHED;
     // (remembering the tiles a workgroup has marked in an LDS set instead of this load: 126 -> 140 us, measured; an atomic
     // that puts the tile on the scan's list at its first mark: 123 -> 355 us -- the load sees stale zeros from the L1 of its
     // compute unit all through the kernel, harmless for a byte store, a blocking round trip for a returning atomic)
-    if (TILE_MARK)
-      if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
+    if (a.tile_dirty[p.tile] == 0) a.tile_dirty[p.tile] = 1;
   }
 }
 // both halves at once (general walk)
+template <bool SMALL>
 __device__ __forceinline__ void free_emit(const ScatterArgs &a, const MarchFrame &f, uint32_t ix, int32_t k, int32_t vx, int32_t vy, int32_t vz, uint32_t &n_keyed)
 {
   FreePending p;
   FreeBlock none = {0, 0};
-  free_request(a, f, p, true, ix, k, vx, vy, vz);
-  free_finish<false>(a, p, n_keyed, none);
+  free_request<SMALL>(a, p, true, ix, k, ring_fast(vx, f.ringK[0], a.map.size[0]), ring_fast(vy, f.ringK[1], a.map.size[1]),
+                      ring_fast(vz, f.ringK[2], a.map.size[2]));
+  free_finish<false, SMALL>(a, p, n_keyed, none);
 }
 
-[[maybe_unused]] constexpr int FREE_QCAP = 128; // queue entries per wave (one sample phase adds at most 64)
 #ifndef WS_FREE_LANES
 #define WS_FREE_LANES 4
 #endif
@@ -1218,6 +1291,7 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
 #define WS_FREE_WGS 6 // workgroups per CU the register budget is set for (round 5's walk over column changes, 5 / 6 / 7 / 8: 105 / 103 / 102 / 120 us;
                       // six: 80 VGPRs, one spilled outside the loops; seven: 72 with 15 spilled; round 4's stepped walk: 121 / 120 / 117 / 147)
 #endif
+template <bool SMALL> // SMALL: 32-bit offsets into the voxel bytes (vox_ptr)
 __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
 {
 #ifdef WS_FREE_TIMING
@@ -1253,7 +1327,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
           raise_error(a.counters, a.status, ERR_FREE_BOUND); // impossible by the bound; never lose a candidate silently
           return;
         }
-        free_emit(a, f, ix, k, vx, vy, vz, n_keyed);
+        free_emit<SMALL>(a, f, ix, k, vx, vy, vz, n_keyed);
       });
   }
   else if (__any(work))
@@ -1267,18 +1341,25 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     FreePending pend;
     FreeBlock fblock = {a.sub_cap - (blockIdx.x * 4u + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
     pend.valid = false;
-    pend.idx = 0;
-    pend.tile = pend.local = pend.ix = pend.b = 0;
+    pend.tile = pend.vox = pend.ix = pend.b = 0;
     pend.k = 0;
     const uint32_t adx = (uint32_t)(r.dx < 0 ? -r.dx : r.dx), ady = (uint32_t)(r.dy < 0 ? -r.dy : r.dy), adz = (uint32_t)(r.dz < 0 ? -r.dz : r.dz);
     const int32_t smx = r.dx < 0 ? -1 : 0, smy = r.dy < 0 ? -1 : 0, smz = r.dz < 0 ? -1 : 0;
     const int32_t sposx = (f.posx ^ smx) - smx, sposy = (f.posy ^ smy) - smy, sposz = (f.posz ^ smz) - smz;
-    // the fan base offset c0 = trunc(delta_z * iv / 32768) (update_tsdf.cu:103-110 with one fan step): delta_z >= 0, so the
-    // sign is iv's
-    const uint32_t aivx = (uint32_t)(r.ivx < 0 ? -r.ivx : r.ivx), aivy = (uint32_t)(r.ivy < 0 ? -r.ivy : r.ivy), aivz = (uint32_t)(r.ivz < 0 ? -r.ivz : r.ivz);
-    const int32_t sivx = r.ivx < 0 ? -1 : 0, sivy = r.ivy < 0 ? -1 : 0, sivz = r.ivz < 0 ? -1 : 0;
+    // The walk lives in MIRRORED coordinates (every axis turned so that the ray travels in the positive direction: a = s pos + q),
+    // and so does the rest of the step: the fan base offset c0 = trunc(delta_z * iv / 32768) (update_tsdf.cu:103-110 with one fan
+    // step) with the mirrored s iv -- delta_z >= 0, so the product's sign is s iv's and the rounding toward zero a per-ray bias in
+    // front of an arithmetic shift (trunc15_biased) --, the truncating division by res (trunc is odd: trunc(e / res) = s trunc(s e /
+    // res)), and the sign comes back in the ONE instruction that adds the ring buffer's constant: x = s (qm - divBq) + offset - pos =
+    // (qm ^ sm) + Kc, Kc = ringB for s = +1 and ringB + 2 divBq + 1 for s = -1 (v_xad_u32).  Two instructions per axis less than
+    // un-mirroring the position first.
+    const int32_t ivmx = (r.ivx ^ smx) - smx, ivmy = (r.ivy ^ smy) - smy, ivmz = (r.ivz ^ smz) - smz;
+    const int32_t bvx = iv_bias(ivmx), bvy = iv_bias(ivmy), bvz = iv_bias(ivmz);
+    const uint32_t kcx = (uint32_t)f.ringB[0] + (smx ? 2u * (uint32_t)f.divBq + 1u : 0u), kcy = (uint32_t)f.ringB[1] + (smy ? 2u * (uint32_t)f.divBq + 1u : 0u),
+                   kcz = (uint32_t)f.ringB[2] + (smz ? 2u * (uint32_t)f.divBq + 1u : 0u);
+    const uint32_t hdx = adx * (uint32_t)half, hdy = ady * (uint32_t)half, hdz = adz * (uint32_t)half, dzh = (uint32_t)(DZ_PER_DISTANCE * half);
     DdaRay R;
-    R.M32 = (uint32_t)r.div_m;
+    R.M32 = r.div_m;
     R.sh = r.div_k - 32;
     DdaAxis wx, wy;
     wx.K = wy.K = wx.Ksp = wy.Ksp = DDA_NEVER;
@@ -1296,27 +1377,21 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
       // the sample k == 0 is compared with the voxel column (0, 0) (update_tsdf.cu:65,71): a candidate of its own in front
       if (k0 == 0 && (div_res(sposx + (int32_t)qx, f) != 0 || div_res(sposy + (int32_t)qy, f) != 0)) k = 0;
     }
-    // One step of the walk: request the voxel byte of the lane's next candidate into `req`, THEN finish the candidate in `fin`
-    // (requested one step earlier: its byte has had a whole step), then move on to the next column change.
-    // gfx950 retires loads and stores in order behind one counter, and the compiler can only wait for "all but the N youngest"
-    // when N is the same on every path: so every step issues exactly one load and two stores -- a lane with nothing to store
-    // stores a zero into the slack behind its plane -- and the wait for fin's byte leaves this step's load and the previous
-    // step's stores in flight.  (With the stores under branches every wait was a wait for everything: the voxel store's
-    // acknowledgement and the next byte's round trip, one after the other, every iteration -- 55 % of the waves' time by
-    // SQ_WAIT_ANY.)  The loop below runs the step twice per trip with the two slots exchanged, so that a byte in flight is
-    // never copied from one register to another (a copy is a use: the wait would come right behind the load).
-    auto step = [&](auto special, FreePending &req, FreePending &fin) {
+    // One step of the walk: finish the candidate whose voxel byte the PREVIOUS step requested (it has had a whole step to
+    // arrive), request the byte of the lane's next candidate, move on to the next column change.  (gfx950 retires loads and
+    // stores in order behind one counter and the stores here are under branches, so the wait for a byte is a wait for
+    // everything in flight; a variant that issued the same load and two stores in every step -- `vmcnt(3)` instead -- was no
+    // faster: DESIGN.md section 5.)
+    auto step = [&](auto special, FreePending &req) {
       const bool active = k < (uint32_t)k1;
       // ---- the sample's position (update_tsdf.cu:69) and its single on-ray target (:103-112 with iter_steps == 1)
-      const int32_t len = 1 + (int32_t)k * half;
-      const int32_t ax = sposx + (int32_t)dda_q(adx, len, R), ay = sposy + (int32_t)dda_q(ady, len, R), az = sposz + (int32_t)dda_q(adz, len, R);
-      const uint32_t dz = (uint32_t)(DZ_PER_DISTANCE * len) >> 15; // no fan in the free-space part: dz * 2 < res
-      const int32_t c0x = (int32_t)(((dz * aivx) >> 15) ^ (uint32_t)sivx) - sivx, c0y = (int32_t)(((dz * aivy) >> 15) ^ (uint32_t)sivy) - sivy,
-                    c0z = (int32_t)(((dz * aivz) >> 15) ^ (uint32_t)sivz) - sivz;
-      const int32_t ex = ((ax ^ smx) - smx) - c0x, ey = ((ay ^ smy) - smy) - c0y, ez = ((az ^ smz) - smz) - c0z;
-      // (one slot: finish the candidate whose byte the previous step requested, then request this one's)
-      free_finish<true, true>(a, req, n_keyed, fblock);
-      free_request(a, f, req, active, ix, (int32_t)k, div_res(ex, f), div_res(ey, f), div_res(ez, f));
+      // (|d| * len_k = (|d| half) k + |d|, 100 * len_k = (100 half) k + 100: one multiply-add each)
+      const int32_t ax = sposx + (int32_t)dda_qn(hdx * k + adx, R), ay = sposy + (int32_t)dda_qn(hdy * k + ady, R), az = sposz + (int32_t)dda_qn(hdz * k + adz, R);
+      const int32_t dz = (int32_t)(dzh * k + (uint32_t)DZ_PER_DISTANCE) >> 15; // (DZ_PER_DISTANCE * len) >> 15; no fan in the free-space part: dz * 2 < res
+      const int32_t ex = ax - trunc15_biased(dz, ivmx, bvx), ey = ay - trunc15_biased(dz, ivmy, bvy), ez = az - trunc15_biased(dz, ivmz, bvz);
+      free_finish<true, SMALL>(a, req, n_keyed, fblock);
+      free_request<SMALL>(a, req, active, ix, (int32_t)k, ring_m(div_res_b(ex, f), (uint32_t)smx, kcx, a.map.size[0]),
+                          ring_m(div_res_b(ey, f), (uint32_t)smy, kcy, a.map.size[1]), ring_m(div_res_b(ez, f), (uint32_t)smz, kcz, a.map.size[2]));
       // ---- on to the next column change
       const bool cx = active && wx.K == k, cy = active && wy.K == k;
       if (cx)
@@ -1333,12 +1408,8 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
       }
       if (active) k = min(wx.K, wy.K);
     };
-    FreePending pend2 = pend;
     auto walk = [&](auto special) {
-      while (__any(k < (uint32_t)k1))
-      {
-        step(special, pend, pend2);
-      }
+      while (__any(k < (uint32_t)k1)) step(special, pend);
     };
     // (a ray that crosses the cell around zero -- the one cell that is 2 res - 1 wide -- needs a look at every crossing: a
     // loop of its own for the waves that hold such a ray)
@@ -1346,8 +1417,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
       walk(std::true_type{});
     else
       walk(std::false_type{});
-    // (after a pair of steps only `pend` holds a candidate that is not finished)
-    free_finish<true, true>(a, pend, n_keyed, fblock);
+    free_finish<true, SMALL>(a, pend, n_keyed, fblock); // the last candidate
   }
   // statistics: free-space candidates that became records
   for (int d = 32; d > 0; d >>= 1) n_keyed += __shfl_down(n_keyed, d, 64);
@@ -1533,6 +1603,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
   __shared__ uint32_t s_unres[2];
+  __shared__ uint32_t s_negs; // the tile in work has negative-weight (off-ray) records
 #ifdef WS_RESOLVE_TIMING
   const long long t_begin = wall_clock64();
 #endif
@@ -1726,7 +1797,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   post.idx0 = 0;
   post.tile = 0;
   post.vs = post.touched = 0;
-  if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
+  if (threadIdx.x == 0) s_unres[0] = s_unres[1] = s_negs = 0;
   init_lds();
   __syncthreads();
 
@@ -1832,15 +1903,21 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       };
 
       // ---- pass 1: earliest positive, smallest negative per voxel
+      bool has_neg = false;
       scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
         // (one LDS atomic with a selected address and key instead of two exec-mask regions per record)
         const bool neg = rec_negative(rec, a.fan_mask, a.fan_mid);
+        has_neg = has_neg || neg;
         const unsigned long long key = neg ? (unsigned long long)neg_key(rec, av, value) : (unsigned long long)rec;
         atomicMin(neg ? &kneg[l] : &kpos[l], key);
       });
+      // Off-ray candidates exist only where the fan is more than one step wide (update_tsdf.cu:101-102: beyond 8.2 m at 50 mm): a
+      // tile without them has nothing that could block a positive candidate, and scan A -- a pass over all records -- is skipped
+      if (__any(has_neg) && lane == 0) s_negs = 1;
       __syncthreads();
-      scan_a();
+      if (s_negs != 0) scan_a();
       __syncthreads();
+      if (threadIdx.x == 0) s_negs = 0; // (read by everybody before the barrier above; written again after the decide's barrier)
       // this tile's records are not needed again (unless it needs ordered rounds, which stream): everything the next
       // iterations need is requested NOW and arrives under the decide phase, the barrier and the write-back
       from_regs = false;
@@ -2439,13 +2516,21 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   hipLaunchKernelGGL(ray_setup_kernel, grid_setup, block, 0, s, sa);
   hipLaunchKernelGGL(ray_sort_kernel, dim3(min(grid_setup.x, (unsigned)WS_SORT_BLOCKS)), block, 0, s, sa);
   prof_end(ctx, WS_K_SETUP);
+  // 32-bit offsets into the voxel bytes and the record pool where both are below 4 GB (vox_ptr / rec_ptr)
+  const bool small = 2ull * vstate_plane_bytes(m->n_tiles) < (1ull << 32) && (uint64_t)m->sub_cap * (SUB_RECS * 8ull) < (1ull << 32);
   prof_begin(ctx, WS_K_MARCH_TAILS);
-  hipLaunchKernelGGL(march_tail_kernel, grid_tail, block, 0, s, sa);
+  if (small)
+    hipLaunchKernelGGL(march_tail_kernel<true>, grid_tail, block, 0, s, sa);
+  else
+    hipLaunchKernelGGL(march_tail_kernel<false>, grid_tail, block, 0, s, sa);
   prof_end(ctx, WS_K_MARCH_TAILS);
   if (!s0)
   {
     prof_begin(ctx, WS_K_MARCH_FREE);
-    hipLaunchKernelGGL(march_free_kernel, grid_free, block, 0, s, sa);
+    if (small)
+      hipLaunchKernelGGL(march_free_kernel<true>, grid_free, block, 0, s, sa);
+    else
+      hipLaunchKernelGGL(march_free_kernel<false>, grid_free, block, 0, s, sa);
     prof_end(ctx, WS_K_MARCH_FREE);
   }
 

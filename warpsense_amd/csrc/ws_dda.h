@@ -51,6 +51,8 @@ struct DdaRay
   int32_t sh; // div_k - 32 >= 0
 };
 WS_DDA_FN uint32_t dda_q(uint32_t ad, int32_t len, const DdaRay &r) { return dda_mulhi(ad * (uint32_t)len, r.M32) >> r.sh; }
+// ... from the product n = |d| * len_k = (|d| * half) * k + |d| itself (one multiply-add per axis and step in the walk's loop)
+WS_DDA_FN uint32_t dda_qn(uint32_t n, const DdaRay &r) { return dda_mulhi(n, r.M32) >> r.sh; }
 
 struct DdaAxis
 {

@@ -193,6 +193,7 @@ struct ws_context
   std::vector<Span> spans;       // recorded, not yet resolved
   std::vector<hipEvent_t> pool;  // free events
   std::vector<struct ws_map *> maps; // maps of this context (sticky device-side errors are reported at ws_sync)
+  std::vector<struct ws_reg *> regs; // registrations of this context (a resident server of ws_reg_iterate is asked to leave by whoever enqueues other work)
   double prof_ms[WS_K_COUNT] = {};
   int64_t prof_n[WS_K_COUNT] = {};
 };
@@ -297,6 +298,27 @@ struct ws_reg
   int64_t *iter_host = nullptr;       // pinned + mapped: the 44 sums of ws_reg_iterate, then the call's sequence number
   int64_t *iter_host_dev = nullptr;   // device view of iter_host
   uint32_t iter_seq = 0;
+  // the resident server behind ws_reg_iterate (reg_server_kernel, registration.hip): requests travel through host-mapped memory
+  void *srv_mail = nullptr;           // ServerMail, pinned + mapped
+  void *srv_mail_dev = nullptr;       // device view
+  uint32_t *srv_ctl = nullptr;        // device words of the server (bell, pose, arrival counters), zero at creation
+  std::atomic<uint32_t> srv_launch{0};   // id of the last server launched (0: none yet); it lives until ServerMail::exited says so
+  std::atomic<bool> srv_stopping{false}; // somebody has asked that server to leave: the next request waits for it and starts a new one
+  uint32_t srv_ids = 0;               // launch ids handed out
+  uint32_t srv_seq = 0;               // request numbers handed out (1 .. 2^31 - 1)
+  uint32_t srv_served = 0;            // the last request that was answered
+  int srv_enabled = 1;                // 0: one launch per ws_reg_iterate (reg_host_iter_kernel), WS_REG_SERVER=0
+  uint32_t srv_idle_us = 50;          // the server leaves after this long without a request
+  uint32_t srv_launches = 0;          // statistics (ws_debug_reg_server)
+  struct
+  {
+    const ws_map *map = nullptr;
+    const void *points = nullptr, *map_data = nullptr;
+    size_t n = 0;
+    int32_t res = 0;
+    uint32_t flags = 0;
+    ws::MapParams par;
+  } srv_sig;                          // what the living server was launched for
   uint32_t loop_launches = 0;
   bool loop_sets_clear = false;
   int loop_mode = 0;                 // WS_REG_LOOP_*
@@ -371,6 +393,14 @@ int launch_reg_iteration(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags
 int launch_reg_shard(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, size_t first, size_t count, int64_t *sums_dev, int apply);
 int launch_reg_solve(ws_reg *r, const int64_t *sums_dev);
 int launch_reg_host_iter(ws_reg *r, const ws_map *m, const float T[16], int32_t res, uint32_t flags, uint32_t seq);
+int launch_reg_server(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, uint32_t launch_id, uint32_t served, uint32_t idle_us);
+size_t reg_server_mail_bytes();
+size_t reg_server_ctl_bytes();
+void reg_server_mail_write(void *mail, const float T[16], uint32_t seq);
+void reg_server_mail_stop(void *mail, uint32_t launch_id);
+uint32_t reg_server_mail_done(const void *mail);
+uint32_t reg_server_mail_exited(const void *mail);
+void reg_server_mail_sums(const void *mail, int64_t sums[44]);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init, bool peers = false, size_t first = 0, size_t count = 0);

@@ -13,8 +13,9 @@ struct RaySetup // 56 bytes
   int32_t distance;      // (int)|direction_vector|
   int32_t ivx, ivy, ivz; // interpolation_vector (unit length == MATRIX_RESOLUTION)
   int32_t steps;         // iterations of the ray-march loop; 0 = ray contributes nothing
-  uint64_t div_m;        // multiply-shift constants for the division by `distance`
-  int32_t div_k;
+  uint32_t div_m;        // multiply-shift constants for the division by `distance`: M = ceil(2^k / distance), k = 31 + ceil(log2 distance),
+  uint32_t spare;        // always below 2^32 -- a 32-BIT field: read out of a 64-bit one, `(uint32_t)div_m` reached the kernels as a
+  int32_t div_k;         // 64-bit operand with a zero high half, and every v_mul_hi_u32 with it dragged a wasted v_mad_u64_u32 along
   int32_t pad;    // bit 0: the division-free walk (march_steps_fast) is exact for this ray; bits 1..: direction bin
   int32_t kfirst; // first step of the ray TAIL: steps [kfirst, steps) go through the order keys, [0, kfirst) are free space
   uint32_t ub;    // upper bound of the tail's scatter targets: sum over its steps of iter_steps (update_tsdf.cu:102)
@@ -31,6 +32,13 @@ struct MarchFrame
   uint32_t rM32; // the same constant as 32 bits (it is below 2^32 for every res >= 2) for v_mul_hi_u32
   int32_t rS;    // rK - 32
   int32_t ringK[3]; // offset - pos + size: storage coordinate = ring(v + ringK, size) (device_map.h:93-101)
+  // the same two steps for the rays that stay inside the window (RAY_SIMPLE), with fewer instructions (div_res_b / ring_b below):
+  // the division on a numerator made non-negative by adding divB = res * divBq (a bound on |coordinate| inside the window)
+  uint32_t divB;
+  int32_t divBq;
+  int32_t resm1;    // res - 1
+  int32_t ringB[3]; // offset - pos - divBq
+  bool biased_ok;   // divB < 2^30 and divBq < 2^22: otherwise no ray of the scan is RAY_SIMPLE
   MapParams map;
 };
 __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos[3], int32_t res, int32_t tau, const MapParams &map)
@@ -49,6 +57,20 @@ __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos
   f.rM32 = (uint32_t)fd.M; // M = ceil(2^(31+l) / res) with 2^(l-1) < res <= 2^l: M < 2^32
   f.rS = fd.k - 32;
   for (int k = 0; k < 3; ++k) f.ringK[k] = (int32_t)((uint32_t)map.offset[k] - (uint32_t)map.pos[k] + (uint32_t)map.size[k]);
+  {
+    // |coordinate| of any voxel inside the window, in millimetres, is below (|pos| + size / 2 + 1) * res on every axis
+    int64_t reach = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+      const int64_t r = (map.pos[k] < 0 ? -(int64_t)map.pos[k] : (int64_t)map.pos[k]) + map.size[k] / 2 + 4;
+      reach = r > reach ? r : reach;
+    }
+    f.biased_ok = reach < (1ll << 22) && reach * res < (1ll << 30);
+    f.divBq = f.biased_ok ? (int32_t)reach : 0;
+    f.divB = (uint32_t)f.divBq * (uint32_t)res;
+    f.resm1 = res - 1;
+    for (int k = 0; k < 3; ++k) f.ringB[k] = (int32_t)((uint32_t)map.offset[k] - (uint32_t)map.pos[k] - (uint32_t)f.divBq);
+  }
   f.map = map;
   return f;
 }
@@ -316,6 +338,35 @@ __device__ __forceinline__ int32_t ring_fast(int32_t v, int32_t ringK, int32_t s
   x = min(x, x - (uint32_t)size);
   return (int32_t)x;
 }
+
+// The same two for a coordinate INSIDE THE WINDOW (every target of a RAY_SIMPLE ray), fewer instructions -- the marches are bound
+// by vector-instruction issue:
+//   div_res_b   trunc(y / res) + divBq as ONE unsigned multiply-shift: trunc = floor for y >= 0 and floor((y + res - 1) / res) for
+//               y < 0, and y + divB >= 0 -- five instructions (shift, and, add3, mul_hi, shift) instead of the seven of
+//               |y| -> multiply-shift -> sign back;
+//   ring_b      the biased quotient + ringB = v - pos + offset lies in [-size/2, size/2 + size): it is itself, or itself -+ size,
+//               whichever is in [0, size) -- the smallest of the three as unsigned numbers: add, sub, add, min3.
+__device__ __forceinline__ uint32_t div_res_b(int32_t y, const MarchFrame &f)
+{
+  const int32_t fix = (y >> 31) & f.resm1;
+  return __umulhi((uint32_t)(y + fix) + f.divB, f.rM32) >> f.rS;
+}
+__device__ __forceinline__ int32_t ring_b(uint32_t qb, int32_t ringB, int32_t size)
+{
+  const uint32_t x = qb + (uint32_t)ringB;
+  return (int32_t)min(min(x, x - (uint32_t)size), x + (uint32_t)size);
+}
+// ring_b for a quotient of the MIRRORED coordinate (s y, s = -1 where sm = ~0): the sign comes back inside the addition
+__device__ __forceinline__ int32_t ring_m(uint32_t qm, uint32_t sm, uint32_t kc, int32_t size)
+{
+  const uint32_t x = (qm ^ sm) + kc;
+  return (int32_t)min(min(x, x - (uint32_t)size), x + (uint32_t)size);
+}
+// trunc(m * iv / 32768) for m >= 0 (a fan offset, update_tsdf.cu:108-112): the sign of the product is iv's, so the rounding
+// toward zero is a per-ray bias -- 32767 for a negative iv -- in front of an arithmetic shift (mad, shift instead of
+// multiply, sign, mask, add, shift)
+__device__ __forceinline__ int32_t iv_bias(int32_t iv) { return (iv >> 31) & (MATRIX_RESOLUTION - 1); }
+__device__ __forceinline__ int32_t trunc15_biased(int32_t m, int32_t iv, int32_t bias) { return (__mul24(m, iv) + bias) >> 15; }
 
 // ---- compacting walk -----------------------------------------------------------------------------------------
 // The walks above do the per-sample arithmetic for all lanes and the per-candidate work for the lanes whose sample
