@@ -74,7 +74,8 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
         return O.cpu_update_tsdf(m, points, [0, 0, 0], [0, 0, 32768], tau, mw, res, threads=threads)
 
     # Every reported variant gets a probe (also its warm-up: page faults of the 513^3 map, OpenMP thread start) and 5 warmed
-    # samples.  The port's per-thread hash maps are merged serially, so beyond a few dozen threads it only gets
+    # samples.  The port merges its per-thread hash maps the way the reference does (in parallel, every entry probing
+    # the maps of the threads before it: O(threads) probes per entry, src/cpu/update_tsdf.cpp:676-722), so beyond a few dozen threads it only gets
     # slower: the widest TIMED variant is 32 threads, and "all host CPUs"  runs ONCE as a probe whose time is in the
     # JSON (`update_all_cpus_probe`), so that "32 of N" is a measured choice and not a comment.
     many = min(ncpu, 32)
@@ -93,7 +94,7 @@ def cpu_baseline(points, perturbed, size, tau, mw, res, reg_params):
     best_name, best_th = min(variants, key=lambda v: samples[v[0]]["median_s"])
     if ncpu > many:
         samples["update_all_cpus_probe"] = {"threads": ncpu, "probe_s": round(once(lambda: upd(ncpu)), 3), "warmed_samples": 0,
-                                            "note": "one run with every host CPU: not faster than the timed variants (serial merge of the per-thread maps)"}
+                                            "note": "one run with every host CPU: not faster than the timed variants (the reference's merge of the per-thread maps costs O(threads) probes per entry, src/cpu/update_tsdf.cpp:676-722)"}
     best_upd = samples[best_name]["median_s"]
     upd(best_th)  # the map the registration runs against
     it_box = []
@@ -518,7 +519,18 @@ def main():
             grp_bytes, grp_us, grp = b_scatter, t_scatter, [k for k in scatter_classes if k in kernels]
             timing = "sum of the per-class hipEvent pairs (separate pass)"
         achieved = grp_bytes / (grp_us * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "kernel_group": grp, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # vector instructions of the group per scatter target (the update is bound by instruction issue, not bytes):
+        # 64 lanes x SQ_INSTS_VALU of the group's kernels / V, from the counter passes of tools/ab_sq.sh (profiles/pmc_valu.json)
+        lane_insts = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_valu.json")) as fh:
+                vj = json.load(fh)
+                lane_insts = {"per_scatter_target": 64.0 * sum(vj["valu_per_launch"].values()) / V, "valu_per_launch": vj["valu_per_launch"],
+                              "source": "profiles/pmc_valu.json@" + str(vj.get("git_sha", "unknown")) + " (SQ_INSTS_VALU, tools/ab_sq.sh; not measured in this run)"}
+        except Exception:
+            pass
+        group_name = dom if len(grp) == 1 else "tsdf_update: " + " + ".join(grp)
+        roofline = {"bound": "hbm", "kernel": group_name, "dominant_kernel": dom, "kernel_group": grp, "lane_instructions": lane_insts, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": grp_bytes,
                     "avg_launch_us": grp_us, "timing": timing, "dominant_kernel_us": kernels[dom]["avg_us"],
                     "per_class_sum_us": t_scatter,

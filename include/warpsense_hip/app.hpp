@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cmath>
 #include <list>
 #include <map>
 #include <mutex>
@@ -349,6 +351,14 @@ public:
   // entering slabs with the default entry; nothing waits), chunks the global map already holds for the entering slabs are
   // uploaded (revisits only), and a worker thread files the leaving slabs into the global map once their copy to pinned
   // memory has landed.  Same maps as shift_map().
+  // staging for asynchronous shifts of up to `shift_voxels` per axis (plus slack), allocated now instead of inside the first
+  // shift: a pinned allocation of that size takes tens of milliseconds (56 ms of the first shifting scan of the 1025^3 stream)
+  void reserve_shift(int shift_voxels)
+  {
+    const rm::Pointi &size = local_map_.get_size();
+    const uint64_t d = (uint64_t)(shift_voxels > 0 ? shift_voxels : 0) + 8u;
+    WS_CHECK(ws_shift_reserve(gpu_.tsdf().handle(), d * ((uint64_t)size.x * size.y + (uint64_t)size.y * size.z + (uint64_t)size.x * size.z)));
+  }
   void shift_map_async(const rm::Pointi &new_pos)
   {
     wait_shift();
@@ -524,6 +534,13 @@ struct AppParams
   bool async_shift = false; // MappingNode::shift_map_async: the map shift off the scan path
 };
 
+// wall-clock microseconds of the stages of one cloud_callback -- the reference's RuntimeEvaluator forms "preprocess", "tsdf",
+// "registration", "total" (app.cpp:68-111), plus the map shift's turn
+struct StageTimes
+{
+  double preprocess_us = 0, tsdf_us = 0, registration_us = 0, shift_us = 0, total_us = 0;
+};
+
 class App
 {
 public:
@@ -534,6 +551,7 @@ public:
     pose_.setIdentity();
     last_tsdf_pose_.setIdentity();
     last_shift_pose_.setIdentity();
+    if (p.async_shift) node_.reserve_shift((int)std::ceil(p.shift * 1000.f / (float)p.hot.map_resolution));
     if (global_map_.has_file()) global_map_.write_meta(p.hot.tau, local_map_.get_size(), p.max_distance, p.hot.map_resolution, p.hot.max_weight);
   }
 
@@ -541,7 +559,11 @@ public:
   // The map-shift thread's turn (tsdf_mapping.cpp:104-127) runs synchronously at the end.
   const rm::Matrix4x4f &cloud_callback(const float *cloud_xyz, size_t n, size_t stride_floats, const rm::Matrix4x4f *pretransform = nullptr)
   {
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
     const size_t n_pts = pre_.preprocess(cloud_xyz, n, stride_floats, pose_, params_.hot.map_resolution); // App::preprocess :119-148
+    const clk::time_point t1 = clk::now();
     if (!initialized_ || distance_m(last_tsdf_pose_, pose_) > 0.3f || shifted_)
     {
       initialized_ = true;
@@ -552,6 +574,7 @@ public:
       shifted_ = false;
       ++n_updates_;
     }
+    const clk::time_point t2 = clk::now();
     rm::Matrix4x4f pre;
     if (pretransform)
       pre = *pretransform;
@@ -563,8 +586,15 @@ public:
                                                   params_.hot.epsilon, params_.hot.map_resolution, &last_iterations_);
     update_pose_estimate(transform);
     if (global_map_.has_file()) global_map_.write_pose(pose_, 1000.f);
+    const clk::time_point t3 = clk::now();
     map_shift();
+    const clk::time_point t4 = clk::now();
     last_points_ = n_pts;
+    times_.preprocess_us = us(t0, t1);
+    times_.tsdf_us = us(t1, t2);
+    times_.registration_us = us(t2, t3);
+    times_.shift_us = us(t3, t4);
+    times_.total_us = us(t0, t4);
     return pose_;
   }
   void update_pose_estimate(const rm::Matrix4x4f &t) // app.cpp:172-176
@@ -606,6 +636,7 @@ public:
 
   const rm::Matrix4x4f &pose() const { return pose_; }
   int last_iterations() const { return last_iterations_; }
+  const StageTimes &last_times() const { return times_; }
   size_t last_points() const { return last_points_; }
   int n_updates() const { return n_updates_; }
   int n_shifts() const { return n_shifts_; }
@@ -634,6 +665,7 @@ private:
   bool initialized_ = false, shifted_ = false;
   int last_iterations_ = 0, n_updates_ = 0, n_shifts_ = 0;
   size_t last_points_ = 0;
+  StageTimes times_;
 };
 
 } // namespace warpsense

@@ -10,7 +10,7 @@ for so in warpsense_amd/variants/*.so; do
     rm -rf gpurun_out/prof_sq_$name
     WS_HIP_LIB=$PWD/$so rocprofv3 --kernel-trace --pmc ${grp} -d gpurun_out/prof_sq_$name -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-registration > gpurun_out/prof_sq_$name.log 2>&1
     echo "== $name"
-    python tools/pmc_summary.py $(ls gpurun_out/prof_sq_$name/*.db gpurun_out/prof_sq_$name/*/*.db 2>/dev/null | head -1) | grep -E "^kernel|march|resolve<false, true|ray_s" | cut -c1-220 | tee gpurun_out/sq_$name.txt
+    python tools/pmc_summary.py $(ls gpurun_out/prof_sq_$name/*.db gpurun_out/prof_sq_$name/*/*.db 2>/dev/null | head -1) | grep -E "^kernel|march|resolve_kernel<false, true|ray_s" | cut -c1-260 | tee gpurun_out/sq_$name.txt
     rm -rf gpurun_out/prof_sq_$name
   done
 done

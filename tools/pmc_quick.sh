@@ -6,7 +6,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   tag=$(echo $grp | cut -d' ' -f1)
   rm -rf gpurun_out/prof_q_$tag
   rocprofv3 --kernel-trace --pmc ${grp} -d gpurun_out/prof_q_$tag -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-registration > gpurun_out/prof_q_$tag.log 2>&1
-  python tools/pmc_summary.py $(ls gpurun_out/prof_q_$tag/*.db gpurun_out/prof_q_$tag/*/*.db 2>/dev/null | head -1) | grep -E "^kernel|march|resolve<false, true|ray_s" > gpurun_out/q_$tag.txt
+  python tools/pmc_summary.py $(ls gpurun_out/prof_q_$tag/*.db gpurun_out/prof_q_$tag/*/*.db 2>/dev/null | head -1) | grep -E "^kernel|march|resolve_kernel<false, true|ray_s" > gpurun_out/q_$tag.txt
   rm -rf gpurun_out/prof_q_$tag
 done
 cat gpurun_out/q_*.txt | cut -c1-200

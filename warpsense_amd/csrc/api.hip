@@ -361,9 +361,9 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
   TRY(hipMalloc((void **)&m->az_off, AZ_ALLOC * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->ray_bin, MAX_SCAN_POINTS * 2 * sizeof(uint32_t)));
   TRY(hipMalloc((void **)&m->ray_order, MAX_SCAN_POINTS * sizeof(uint32_t)));
-  TRY(hipMalloc((void **)&m->fan_steps, 256 * sizeof(int32_t)));
-  ws::fill_fan_steps(m->fan_steps_host, m->res);
-  TRY(hipMemcpyAsync(m->fan_steps, m->fan_steps_host, 256 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  TRY(hipMalloc((void **)&m->fan_steps, WS_FAN_TABLE * sizeof(int32_t)));
+  ws::fill_fan_steps(m->fan_steps_host, m->res, m->ntz, m->nty);
+  TRY(hipMemcpyAsync(m->fan_steps, m->fan_steps_host, WS_FAN_TABLE * sizeof(int32_t), hipMemcpyHostToDevice, s));
   TRY(hipMemsetAsync(m->az_hist, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMemsetAsync(m->az_off, 0, AZ_ALLOC * sizeof(uint32_t), s));
   TRY(hipMalloc((void **)&m->scan_dev, MAX_SCAN_POINTS * 3 * sizeof(int32_t)));

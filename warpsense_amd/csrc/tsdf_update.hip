@@ -89,7 +89,10 @@ constexpr uint8_t VOX_NEGFREE = 8; // the resolve's merged view of the second by
 constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 
 #ifndef WS_TAIL_SPLIT
-#define WS_TAIL_SPLIT 2 // workgroups that share the tails of one group of 64 rays (four parts of 4 * WS_TAIL_SPLIT each)
+#define WS_TAIL_SPLIT (8 / WS_TAIL_WAVES) // workgroups that share the tails of one group of 64 rays: eight parts in all
+#endif
+#ifndef WS_FREE_THREADS
+#define WS_FREE_THREADS 256 // threads per workgroup of the free pass
 #endif
 #ifndef WS_FREE_FIRST
 #define WS_FREE_FIRST 32 // sub-chunks every wave of the free pass owns from the start (see pool_grab; 16: 136 us, 32: 121, 64: 120)
@@ -592,12 +595,16 @@ __device__ __forceinline__ void entry_publish(const ScatterArgs &a, uint32_t til
 // tiles WITHOUT records away from it
 __device__ __forceinline__ void list_tile(const ScatterArgs &a, uint32_t at, uint32_t tile)
 {
+  // tile -> (tx, ty, tz) by multiply-shift (constants behind the fan table, ws_map_create): exact for tile ids below 2^31
+  const uint32_t Mz = (uint32_t)a.fan_steps[256], My = (uint32_t)a.fan_steps[258];
+  const int32_t sz = a.fan_steps[257], sy = a.fan_steps[259];
+  const uint32_t col = sz >= 0 ? __umulhi(tile, Mz) >> sz : tile;
+  const uint32_t tx = sy >= 0 ? __umulhi(col, My) >> sy : col;
   TileEntry e;
   e.tile = tile;
-  e.tz = (int32_t)(tile % (uint32_t)a.ntz);
-  const uint32_t col = tile / (uint32_t)a.ntz;
-  e.ty = (int32_t)(col % (uint32_t)a.nty);
-  e.tx = (int32_t)(col / (uint32_t)a.nty);
+  e.tz = (int32_t)(tile - col * (uint32_t)a.ntz);
+  e.ty = (int32_t)(col - tx * (uint32_t)a.nty);
+  e.tx = (int32_t)tx;
   a.tile_list[at] = e;
   a.tile_dirty[tile_flag_plane_bytes((int64_t)a.ntx * a.nty * a.ntz) + tile] = 1;
 }
@@ -622,7 +629,7 @@ __device__ __forceinline__ void append_single(const ScatterArgs &a, uint32_t til
 #ifndef WS_TAIL_WGS
 #define WS_TAIL_WGS 5 // workgroups per CU the register budget is set for (six: 80 VGPRs, 16 of them spilled, 234 instead of 187 us)
 #endif
-constexpr int TAIL_SPLIT = WS_TAIL_SPLIT; // workgroups that share the tails of one group of 64 rays (4 parts each)
+constexpr int TAIL_SPLIT = WS_TAIL_SPLIT, TAIL_WAVES = WS_TAIL_WAVES; // workgroups that share the tails of one group of 64 rays (TAIL_WAVES parts each)
 constexpr int TAIL_QCAP = 128; // queue entries per wave of the compacting walk (one sample phase adds at most 64)
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 
@@ -848,8 +855,8 @@ __device__ __forceinline__ uint32_t wave_put(const ScatterArgs &a, WaveTab &wt, 
 template <bool SMALL>
 __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t item)
 {
-  __shared__ WaveTab s_tab[4];
-  __shared__ u32x4 s_queue[4 * TAIL_QCAP];
+  __shared__ WaveTab s_tab[TAIL_WAVES];
+  __shared__ u32x4 s_queue[TAIL_WAVES * TAIL_QCAP];
   __shared__ uint32_t s_stat[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   WaveTab &wt = s_tab[wave];
@@ -858,7 +865,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
 #endif
   const uint32_t n_sorted = a.az_off[AZ_BINS];
   const uint32_t slot = (item / (uint32_t)TAIL_SPLIT) * 64u + (uint32_t)lane;
-  const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * 4; // this workgroup's four parts of the tails
+  const int part0 = (int)(item % (uint32_t)TAIL_SPLIT) * TAIL_WAVES; // this workgroup's parts of the tails
   const bool has_ray = slot < n_sorted;
   uint32_t ix = 0;
   RaySetup r;
@@ -898,7 +905,7 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
   if (has_ray && r.steps > 0 && r.kfirst < r.steps)
   {
     const int32_t kbeg = r.kfirst, kend = r.steps;
-    const int32_t ch = (kend - kbeg + 4 * TAIL_SPLIT - 1) / (4 * TAIL_SPLIT);
+    const int32_t ch = (kend - kbeg + TAIL_WAVES * TAIL_SPLIT - 1) / (TAIL_WAVES * TAIL_SPLIT);
     k0 = min(kbeg + (part0 + wave) * ch, kend);
     k1 = min(k0 + ch, kend);
   }
@@ -1166,10 +1173,10 @@ __device__ __forceinline__ void tail_item(const ScatterArgs &a, const uint32_t i
 }
 
 template <bool SMALL> // SMALL: 32-bit offsets into the voxel bytes and the record pool (vox_ptr)
-__global__ __launch_bounds__(256, WS_TAIL_WGS) void march_tail_kernel(ScatterArgs a)
+__global__ __launch_bounds__(64 * WS_TAIL_WAVES, WS_TAIL_WGS * 4 / WS_TAIL_WAVES) void march_tail_kernel(ScatterArgs a)
 {
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * 256u) a.az_hist[i] = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * blockDim.x) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
   if (blockIdx.x < n_items) tail_item<SMALL>(a, blockIdx.x);
 }
@@ -1292,14 +1299,14 @@ constexpr int FREE_LANES = WS_FREE_LANES; // lanes that share the free-space par
                       // six: 80 VGPRs, one spilled outside the loops; seven: 72 with 15 spilled; round 4's stepped walk: 121 / 120 / 117 / 147)
 #endif
 template <bool SMALL> // SMALL: 32-bit offsets into the voxel bytes (vox_ptr)
-__global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArgs a)
+__global__ __launch_bounds__(WS_FREE_THREADS, WS_FREE_WGS * 256 / WS_FREE_THREADS) void march_free_kernel(ScatterArgs a)
 {
 #ifdef WS_FREE_TIMING
   const long long t_free_begin = wall_clock64();
 #endif
   if (a.counters->abort != 0) return; // (the tail march ran out of sub-chunks: the host repeats the scan)
-  __shared__ uint32_t s_keyed[4];
-  const uint32_t ix = blockIdx.x * (uint32_t)(256 / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
+  __shared__ uint32_t s_keyed[WS_FREE_THREADS / 64];
+  const uint32_t ix = blockIdx.x * (uint32_t)(WS_FREE_THREADS / FREE_LANES) + threadIdx.x / (uint32_t)FREE_LANES;
   const int32_t c = (int32_t)(threadIdx.x % (uint32_t)FREE_LANES);
   const int lane = threadIdx.x & 63;
   uint32_t n_keyed = 0;
@@ -1339,7 +1346,7 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
     // ~85; this loop runs 370 k times (tools/lane_model.py: 89 % of its lane slots carry a candidate).  The voxel byte of a
     // candidate is requested in one iteration and used in the next, as before.
     FreePending pend;
-    FreeBlock fblock = {a.sub_cap - (blockIdx.x * 4u + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
+    FreeBlock fblock = {a.sub_cap - (blockIdx.x * (uint32_t)(WS_FREE_THREADS / 64) + (threadIdx.x >> 6) + 1u) * FREE_WAVE_FIRST, pool_holds_static(a) ? FREE_WAVE_FIRST : 0u};
     pend.valid = false;
     pend.tile = pend.vox = pend.ix = pend.b = 0;
     pend.k = 0;
@@ -1425,7 +1432,8 @@ __global__ __launch_bounds__(256, WS_FREE_WGS) void march_free_kernel(ScatterArg
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    const uint32_t all = s_keyed[0] + s_keyed[1] + s_keyed[2] + s_keyed[3];
+    uint32_t all = 0;
+    for (int w = 0; w < WS_FREE_THREADS / 64; ++w) all += s_keyed[w];
     if (all) atomicAdd(&a.counters->last_free_keyed, all);
 #ifdef WS_FREE_TIMING
     // (instead of the tail march's statistics: 10 ns ticks this workgroup took, and when it started -- tools/free_timing.py)
@@ -2429,8 +2437,17 @@ int launch_scatter_prep(ws_map *m)
 }
 
 // fan_steps[j] of tail_bound for one resolution (host side, once per map).  j = 0 is unused.
-void fill_fan_steps(int32_t *fan_steps, int32_t res)
+void fill_fan_steps(int32_t *fan_steps, int32_t res, int32_t ntz, int32_t nty)
 {
+  {
+    // behind the fan table: the multiply-shift constants of the divisions by ntz and nty (tile id -> tile coordinates when a tile
+    // goes on the scan's list, list_tile: two general 32-bit divisions per listed tile otherwise)
+    const FastDiv dz = make_fastdiv(ntz), dy = make_fastdiv(nty);
+    fan_steps[256] = (int32_t)(uint32_t)dz.M;
+    fan_steps[257] = dz.k - 32; // (-1 for a divisor of 1: the quotient is the dividend)
+    fan_steps[258] = (int32_t)(uint32_t)dy.M;
+    fan_steps[259] = dy.k - 32;
+  }
   const int64_t half = res / 2 > 0 ? res / 2 : 1;
   fan_steps[0] = 0;
   for (int64_t j = 1; j < 256; ++j)
@@ -2502,7 +2519,7 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   const dim3 block(256);
   const dim3 grid_setup((unsigned)((n + 255) / 256));
   const dim3 grid_tail((unsigned)((n + 63) / 64) * TAIL_SPLIT);
-  const dim3 grid_free((unsigned)((n + 256 / FREE_LANES - 1) / (256 / FREE_LANES)));
+  const dim3 grid_free((unsigned)((n + WS_FREE_THREADS / FREE_LANES - 1) / (WS_FREE_THREADS / FREE_LANES)));
   m->tail_blocks = grid_tail.x;
   const bool fuse = fused && !s0;
   prof_begin(ctx, WS_K_SETUP);
@@ -2520,17 +2537,17 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   const bool small = 2ull * vstate_plane_bytes(m->n_tiles) < (1ull << 32) && (uint64_t)m->sub_cap * (SUB_RECS * 8ull) < (1ull << 32);
   prof_begin(ctx, WS_K_MARCH_TAILS);
   if (small)
-    hipLaunchKernelGGL(march_tail_kernel<true>, grid_tail, block, 0, s, sa);
+    hipLaunchKernelGGL(march_tail_kernel<true>, grid_tail, dim3(64 * TAIL_WAVES), 0, s, sa);
   else
-    hipLaunchKernelGGL(march_tail_kernel<false>, grid_tail, block, 0, s, sa);
+    hipLaunchKernelGGL(march_tail_kernel<false>, grid_tail, dim3(64 * TAIL_WAVES), 0, s, sa);
   prof_end(ctx, WS_K_MARCH_TAILS);
   if (!s0)
   {
     prof_begin(ctx, WS_K_MARCH_FREE);
     if (small)
-      hipLaunchKernelGGL(march_free_kernel<true>, grid_free, block, 0, s, sa);
+      hipLaunchKernelGGL(march_free_kernel<true>, grid_free, dim3(WS_FREE_THREADS), 0, s, sa);
     else
-      hipLaunchKernelGGL(march_free_kernel<false>, grid_free, block, 0, s, sa);
+      hipLaunchKernelGGL(march_free_kernel<false>, grid_free, dim3(WS_FREE_THREADS), 0, s, sa);
     prof_end(ctx, WS_K_MARCH_FREE);
   }
 

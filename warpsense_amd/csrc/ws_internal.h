@@ -18,6 +18,7 @@ constexpr int MATRIX_RESOLUTION = 32768; // include/warpsense/consts.h:12-13
 constexpr int WEIGHT_RESOLUTION = 64;    // include/warpsense/consts.h:9-10
 constexpr int DZ_PER_DISTANCE = 100;     // (int)(tan(45/128 deg)/2 * 32768), update_tsdf.cu:49-50 (checked on the host at load)
 constexpr size_t MAX_SCAN_POINTS = 1000000; // update_tsdf.h:33
+constexpr int WS_FAN_TABLE = 264;           // ws_map::fan_steps: 256 fan steps + the tile grid's division constants
 
 // ---- tiles: 4 x 4 x 64 voxels of the ring buffer's STORAGE index space (sx >> 2, sy >> 2, sz >> 6) ----
 // (tall: a wave's accesses are four 256-byte z-runs, and the vertical fan of a LiDAR azimuth falls into few tiles;
@@ -118,7 +119,10 @@ __host__ __device__ inline bool rec_negative(uint64_t rec, uint32_t fan_mask, ui
 constexpr int SUB_BITS = 5, SUB_RECS = 1 << SUB_BITS, TILE_DIRECT = 128;
 constexpr uint32_t SUB_WAVE_FIRST = 128; // sub-chunks a wave of the tail march starts with
 constexpr uint32_t SUB_REFILL = 32;      // and what it asks the pool for when it runs low
-constexpr uint32_t SUB_WG_BLOCK = 4 * SUB_WAVE_FIRST; // ... taken from the pool by its workgroup in one request
+#ifndef WS_TAIL_WAVES
+#define WS_TAIL_WAVES 4 // waves per workgroup of the tail march (tsdf_update.hip)
+#endif
+constexpr uint32_t SUB_WG_BLOCK = WS_TAIL_WAVES * SUB_WAVE_FIRST; // ... the fixed block of ids of a work item (its waves' shares side by side)
 constexpr uint32_t SUB_ID_LIMIT = (1u << 27) - 2u;  // an entry is id << 5 | fill - 1, + 1 in the hash
 // per-tile bytes, two planes in one allocation (tile_flag_plane_bytes apart): [0] "the free pass / an off-ray mark touched the
 // tile" (plain idempotent byte stores), [1] "the tile is on the scan's list" (it has records).  The resolve visits the listed
@@ -209,7 +213,7 @@ struct ws_map
   uint32_t *az_hist = nullptr, *az_off = nullptr, *ray_order = nullptr; // rays grouped by direction bin
   void *ray_bin = nullptr;   // [1 000 000] uint2: (direction bin, rank inside the bin) per ray
   int32_t *fan_steps = nullptr;       // [256] first ray step whose fan has j + 1 targets (depends on res only), see tail_bound
-  int32_t fan_steps_host[256] = {};   // staging of the same (lives as long as the map: async upload)
+  int32_t fan_steps_host[ws::WS_FAN_TABLE] = {}; // staging of the same (lives as long as the map: async upload); [256..259]: division constants of ntz, nty
   bool prepped = false; // the scatter's scratch (histograms, tile counters, free-space hash) is zero / empty
   int32_t tau = 0, max_weight = 0, res = 0;
   bool new_is_default = false; // new_map known to be (tau,0) everywhere
@@ -373,7 +377,7 @@ void prof_begin(ws_context *ctx, int cls);
 void prof_end(ws_context *ctx, int cls);
 
 // launchers implemented in the .hip files
-void fill_fan_steps(int32_t *fan_steps, int32_t res);
+void fill_fan_steps(int32_t *fan_steps, int32_t res, int32_t ntz, int32_t nty);
 int launch_tsdf_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const int32_t scanner_pos[3], const int32_t up[3], bool fused);
 int settle_tsdf(ws_map *m); // the verdict of the scan in flight (repeats an aborted scan); every entry point that takes a map calls it first
 size_t ray_setup_bytes();
