@@ -317,9 +317,17 @@ def test_perform_registration_through_the_resident_server():
     rc.prepare_registration(q)
     poses = [np.eye(4, dtype=np.float32)] + [S.perturbation(3.0 * k - 20, 28 - k, -9 + 0.5 * k, 0.15 * k - 1.7) for k in range(24)]
     want = [O.reg_iterate(oa, T, q, res, rc.flags) for T in poses]
-    base = _server(rc, enable=1, idle_us=200000)  # (a Python caller is slow: keep the server through the gaps)
-    got = [rc.perform_registration(reg.tsdf().device_map(), T, res) for T in poses]
-    assert _server(rc) - base == 1, "one server for the whole sequence"
+    # (objects of earlier tests that die in the middle of the sequence would enqueue work on the shared context -- freeing a
+    # map synchronises its stream -- and that asks the server to leave, as it must: keep the collector out of the sequence)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        base = _server(rc, enable=1, idle_us=200000)  # (a Python caller is slow: keep the server through the gaps)
+        got = [rc.perform_registration(reg.tsdf().device_map(), T, res) for T in poses]
+        assert _server(rc) - base == 1, "one server for the whole sequence"
+    finally:
+        gc.enable()
     for (h, g, e, c), (ho, go, eo, co) in zip(got, want):
         assert c == co and e == eo and c > 1000 and np.array_equal(g, go) and np.array_equal(h, ho)
     # the same calls with one launch each

@@ -39,7 +39,7 @@ __global__ void rcal_run8_256(const uint2 *p, uint32_t *out)
   SINK(v.x + v.y);
 }
 __global__ void rcal_scatter8(const uint2 *p, uint32_t *out) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; const uint2 v = p[mix(i) & (uint32_t)(BUF / 8 - 1)]; SINK(v.x + v.y); }
-__global__ void rcal_scatter1(const uint8_t *p, uint32_t *out) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t v = p[mix(i) & (uint32_t)(BUF - 1)]; SINK(v + 0x100u); }
+__global__ void rcal_scatter1(const uint8_t *p, uint32_t *out) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; const uint32_t v = p[mix(i) & (uint32_t)(BUF - 1)]; if (v == 0x57u) out[0] = v; }
 
 int main()
 {

@@ -1473,6 +1473,9 @@ struct ResolveArgs
 };
 static_assert(sizeof(ResolveArgs) <= 256, "ResolveArgs: more than 256 bytes of kernel arguments");
 
+#ifndef WS_RESOLVE_KO
+#define WS_RESOLVE_KO 0 // knock-out builds for timing (results wrong): 1 no scan A, 2 no LDS atomics in pass 1, 4 no records at all (fill = 0)
+#endif
 #ifndef WS_RESOLVE_GRID
 #define WS_RESOLVE_GRID 1280 // 256 compute units x five resident workgroups: every workgroup is on the chip from the start (1280 / 2560 / 4096: 124 / 129 / 130 us)
 #endif
@@ -1611,7 +1614,6 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   __shared__ uint32_t mstate[TILE_VOXELS];          // M_IDLE: decided; else min |value| of the blocking negatives (M_NONE: none)
   __shared__ uint16_t bound0[HAS_S0 ? TILE_VOXELS : 1]; // |stored value| + 1 (0: frozen)
   __shared__ uint32_t s_unres[2];
-  __shared__ uint32_t s_negs; // the tile in work has negative-weight (off-ray) records
 #ifdef WS_RESOLVE_TIMING
   const long long t_begin = wall_clock64();
 #endif
@@ -1805,7 +1807,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
   post.idx0 = 0;
   post.tile = 0;
   post.vs = post.touched = 0;
-  if (threadIdx.x == 0) s_unres[0] = s_unres[1] = s_negs = 0;
+  if (threadIdx.x == 0) s_unres[0] = s_unres[1] = 0;
   init_lds();
   __syncthreads();
 
@@ -1827,7 +1829,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     }
     n_mine += 1;
     const TilePre p = p_cur;
-    const uint32_t tile = tile_cur, nsub_real = p.fill, fill = aborted ? 0u : p.fill; // (an aborted scan: the entries may be anything)
+    const uint32_t tile = tile_cur, nsub_real = p.fill, fill = (aborted || (WS_RESOLVE_KO & 4)) ? 0u : p.fill; // (an aborted scan: the entries may be anything)
     const int nz = p.nz;
     const int64_t idx0 = p.idx0;
 
@@ -1892,11 +1894,15 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
         }
       };
       // scan A: the negatives that come before the current positive candidate and can block it
-      auto scan_a = [&]() {
+      // (first: right behind pass 1 every voxel's mstate is still M_NONE -- nothing to look up there)
+      auto scan_a = [&](auto first) {
         scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
           if (!rec_negative(rec, a.fan_mask, a.fan_mid)) return;
-          const uint32_t m = mstate[l];
-          if (m == M_IDLE || (uint32_t)av >= m) return;
+          if (!decltype(first)::value)
+          {
+            const uint32_t m = mstate[l];
+            if (m == M_IDLE || (uint32_t)av >= m) return;
+          }
           const unsigned long long P = kpos[l];
           if (P == KEY_INF || rec > P) return;
           const int32_t vp = rec_value(P);
@@ -1911,21 +1917,24 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
       };
 
       // ---- pass 1: earliest positive, smallest negative per voxel
-      bool has_neg = false;
       scan_records([&](uint64_t rec, int32_t value, int32_t av, int l) {
         // (one LDS atomic with a selected address and key instead of two exec-mask regions per record)
         const bool neg = rec_negative(rec, a.fan_mask, a.fan_mid);
-        has_neg = has_neg || neg;
         const unsigned long long key = neg ? (unsigned long long)neg_key(rec, av, value) : (unsigned long long)rec;
+#if WS_RESOLVE_KO & 2
+        if (key == 0x12345ull) atomicMin(neg ? &kneg[l] : &kpos[l], key); // (never)
+#else
         atomicMin(neg ? &kneg[l] : &kpos[l], key);
+#endif
       });
-      // Off-ray candidates exist only where the fan is more than one step wide (update_tsdf.cu:101-102: beyond 8.2 m at 50 mm): a
-      // tile without them has nothing that could block a positive candidate, and scan A -- a pass over all records -- is skipped
-      if (__any(has_neg) && lane == 0) s_negs = 1;
       __syncthreads();
-      if (s_negs != 0) scan_a();
+      // (round 6, measured and not kept: scan A only for tiles that hold off-ray records at all -- 105.9 us against 106.0:
+      // nearly every tile of the benchmark scan does.  Knock-out builds, WS_RESOLVE_KO: scan A 14 us, the atomics of pass 1 16,
+      // the rest of the fold 33, the kernel without any fold 50.)
+#if !(WS_RESOLVE_KO & 1)
+      scan_a(std::true_type{});
+#endif
       __syncthreads();
-      if (threadIdx.x == 0) s_negs = 0; // (read by everybody before the barrier above; written again after the decide's barrier)
       // this tile's records are not needed again (unless it needs ordered rounds, which stream): everything the next
       // iterations need is requested NOW and arrives under the decide phase, the barrier and the write-back
       from_regs = false;
@@ -2020,7 +2029,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
           if (threadIdx.x == 0) s_unres[phase] = 0;
           phase ^= 1;
           if (s_unres[phase] == 0) break;
-          scan_a();
+          scan_a(std::false_type{});
           __syncthreads();
 #pragma unroll
           for (int j = 0; j < 4; ++j)
