@@ -567,9 +567,47 @@ def test_long_rays_with_wide_fans_take_the_scans_own_key_split():
     assert t.stats()["error_flags"] == 0
 
 
+def test_rays_beyond_the_scans_key_split_take_the_piecewise_route():
+    """VERDICT r5 weak #9 / task 8d: a scan of more than 65 536 points leaves its records 15 bits for the ray step and 6 for the fan
+    (32 768 steps, 63 fan steps), and until round 6 a longer ray was dropped with WS_ERR_RANGE -- the reference marches it
+    (update_tsdf.cu:67,107-125).  Such a scan is now aborted by its set-up pass and repeated in pieces of 16 384 points, each with
+    the widest split (65 536 / 255), one after the other into new_map (the non-default route folds a piece on top of what the
+    earlier pieces left: the serial order is the order of the points).  70 000 points at 2 mm: nearly all a few hundred steps
+    from the sensor, ten of them 35-40 m away (35 000 - 40 000 steps of 1 mm, fans over 100 wide) at the far end of a 40 m long
+    window -- bit-exact against the oracle, no error, and an ordinary scan afterwards is exact as well."""
+    torch = _torch()
+    tau, res, mw = 40, 2, 640
+    view, t, oa, on = _pair_at((20001, 9, 9), tau, res, mw, (0, 0, 0), (3, 2, 5))
+    rng = np.random.default_rng(5)
+    n = 70000
+    sensor_vox = (-9990, 0, 0)
+    sx = sensor_vox[0] * res
+    pts = np.empty((n, 3), dtype=np.int32)
+    pts[:, 0] = sx + rng.integers(20, 300, n)
+    pts[:, 1] = rng.integers(-7, 8, n)
+    pts[:, 2] = rng.integers(-7, 8, n)
+    far = rng.choice(n, 10, replace=False)
+    pts[far, 0] = rng.integers(15000, 19900, 10)
+    O.update_tsdf(oa, on, pts, sensor_vox, (0, 0, 32768), tau, mw, res)
+    t.update_tsdf(torch.from_numpy(pts).cuda(), sensor_vox, (0, 0, 32768))
+    t.ctx.sync()  # (would raise the sticky WS_ERR_RANGE of the old behaviour)
+    st = t.stats()
+    assert st["status"] == 0 and st["error_flags"] == 0
+    got = _download_view(t, view, 0)
+    assert np.array_equal(got, oa.data), f"{np.count_nonzero(got != oa.data)} voxels differ"
+    assert np.all(_download_view(t, view, 1) == O.pack(tau, 0))
+    # and the map goes on as usual
+    small = np.ascontiguousarray(pts[:5000] + np.array([3, 1, -1], dtype=np.int32))
+    O.update_tsdf(oa, on, small, sensor_vox, (0, 0, 32768), tau, mw, res)
+    t.update_tsdf(torch.from_numpy(small).cuda(), sensor_vox, (0, 0, 32768))
+    t.ctx.sync()
+    assert np.array_equal(_download_view(t, view, 0), oa.data)
+
+
 def test_ray_beyond_the_key_range_is_reported():
-    """a ray of more than 65 536 steps cannot be ordered by the step field of the record even in a scan of two points: it is
-    dropped and the map's next synchronising call says so (WS_ERR_RANGE), instead of returning a map that silently lacks it"""
+    """a ray of more than 65 536 steps cannot be ordered by the step field of the record even with the widest split (scans, or
+    pieces of a scan, of up to 16 384 points): it is dropped and the map's next synchronising call says so (WS_ERR_RANGE),
+    instead of returning a map that silently lacks it"""
     torch = _torch()
     import warpsense_amd as W
     tau, res, mw = 32000, 2, 640  # 1 mm steps; distance 40 m + tau = 72 000 steps

@@ -317,7 +317,15 @@ __device__ __forceinline__ void ray_setup_block(const ScatterArgs &a)
         const bool small_iv = ivx >= INT32_MIN && ivx <= INT32_MAX && ivy >= INT32_MIN && ivy <= INT32_MAX && ivz >= INT32_MIN && ivz <= INT32_MAX;
         if (steps > (int64_t)(1 << (a.rec_fmt & 0xffu)) || (max_delta_z * 2) / res + 1 > (int64_t)((1 << (a.rec_fmt >> 8)) - 1) || !small_iv)
         {
-          raise_error(a.counters, a.status, ERR_RANGE); // outside the range of the record's step / fan fields for a scan of this many points
+          // Outside the range of the record's step / fan fields for a scan of this many points.  With the widest split (scans of
+          // up to 16 384 points: 65 536 steps, 255 fan steps) that is the end: the ray is dropped and the error is sticky.  A
+          // larger scan is ABORTED instead (bit 1 of the abort word; nothing of it reaches the maps) and the host repeats it in
+          // pieces of 16 384 points, each with the widest split, one after the other into new_map (settle_tsdf: the serial order
+          // is the order of the points, so consecutive pieces folded on top of each other are the same schedule).
+          if ((a.rec_fmt & 0xffu) == 16u && (a.rec_fmt >> 8) == 8u)
+            raise_error(a.counters, a.status, ERR_RANGE);
+          else
+            __hip_atomic_fetch_or(&a.counters->abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         else
         {
@@ -530,7 +538,7 @@ __device__ __forceinline__ uint32_t big_slot(unsigned long long key, uint32_t ma
 // back and the host repeats the scan with a larger pool (launch_tsdf_scatter)
 __device__ __forceinline__ void raise_abort(const ScatterArgs &a)
 {
-  __hip_atomic_store(&a.counters->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_or(&a.counters->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (bit 1: a ray beyond the key range, ray_setup_block)
 }
 
 // The pool, bottom to top: [one block of SUB_WG_BLOCK ids per work item of the tail march | what its waves ask for on top of
@@ -1178,6 +1186,7 @@ __global__ __launch_bounds__(64 * WS_TAIL_WAVES, WS_TAIL_WGS * 4 / WS_TAIL_WAVES
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * blockDim.x) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
+  if (a.counters->abort != 0) return; // (the set-up pass found a ray beyond the key range: the scan is repeated in pieces)
   if (blockIdx.x < n_items) tail_item<SMALL>(a, blockIdx.x);
 }
 
@@ -1773,7 +1782,7 @@ __global__ __launch_bounds__(256, WS_RESOLVE_WGS) void tile_resolve_kernel(Resol
     c->last_need = c->ub_total & ((1ull << 48) - 1ull);
     c->ub_total = 0;
     __hip_atomic_store(a.status + 10, c->big_inserted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(a.status + 9, aborted ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.status + 9, a.counters->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (bit 0: pool exhausted, bit 1: key range)
     __hip_atomic_store(a.status + 8, a.scan_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // The tiles with records: the scan's tile list (the marches appended every tile at its first reservation), dealt out
@@ -2479,7 +2488,8 @@ static int enqueue_scatter(ws_map *m, const int32_t *xyz_dev, size_t n, const in
   if (m->status_host[10] > m->big_slots / 4) m->prepped = false;
   ScatterArgs sa;
   sa.xyz = xyz_dev;
-  sa.xyz_keep = xyz_dev == m->scan_dev ? nullptr : m->scan_dev;
+  // (a scan, or a piece of one, that already lies in the map's own buffer is not copied there)
+  sa.xyz_keep = (xyz_dev >= m->scan_dev && xyz_dev < m->scan_dev + 3 * MAX_SCAN_POINTS) ? nullptr : m->scan_dev;
   sa.n = (uint32_t)n;
   for (int k = 0; k < 3; ++k)
   {
@@ -2627,9 +2637,8 @@ int settle_tsdf(ws_map *m)
     m->pending.active.store(false, std::memory_order_release);
     return rc;
   };
-  for (;;)
-  {
-    const uint32_t seq = m->pending.seq;
+  // the verdict of the scatter numbered `seq`: 0 fine, bit 0 pool exhausted, bit 1 a ray beyond the key range; < 0: error
+  auto verdict = [&](uint32_t seq) -> int {
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
     while (st[8] != seq)
@@ -2640,29 +2649,80 @@ int settle_tsdf(ws_map *m)
         if (st[8] != seq)
         {
           set_error("TSDF update: the resolve did not report the end of the marches");
-          return done(WS_ERR_INTERNAL);
+          return WS_ERR_INTERNAL;
         }
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (st[9] == 0) return done(WS_OK); // the normal case
+    return (int)st[9];
+  };
+  // a larger pool for a scan of n points that has just been aborted for lack of one
+  auto grow_pool = [&](size_t n) -> int {
+    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4) & ((1ull << 48) - 1ull);
+    uint64_t grow_to = subs_for_scan(m, need, n);
+    if (grow_to < (uint64_t)m->sub_cap * 2) grow_to = (uint64_t)m->sub_cap * 2;
+    if (grow_to > SUB_ID_LIMIT)
+    {
+      set_error("TSDF update: the scan needs more than 2^27 record sub-chunks");
+      return WS_ERR_CAPACITY;
+    }
+    // (waits for the stream: the aborted update has drained and put its scratch back; leaves prepped == false: the new hash is
+    // filled by the preparation pass, the tile tables are zero already)
+    return resize_records(m, grow_to);
+  };
+  for (;;)
+  {
+    const int v = verdict(m->pending.seq);
+    if (v < 0) return done(v);
+    if (v == 0) return done(WS_OK); // the normal case
+    if (v & 2)
+    {
+      // A ray with more steps / a wider fan than the record's key holds for a scan of this many points (until
+      // round 6 such a ray was dropped with WS_ERR_RANGE; the reference marches it, update_tsdf.cu:67,107).  The scan is repeated
+      // in pieces of 16 384 points -- their records carry the widest split, 65 536 steps and 255 fan steps -- one after the
+      // other into new_map: the first piece as the scan itself would have gone, every further one on top of what new_map holds
+      // (the non-default route: the fold starts from the stored entry), which is the serial schedule of the whole scan.  Then
+      // the integrate over the whole map.  Slow (every candidate of the later pieces is a record, the integrate is dense) and
+      // exact; beyond 65 536 steps / 255 fan steps WS_ERR_RANGE remains.
+      constexpr size_t PIECE = 16384;
+      bool s0 = m->pending.s0;
+      for (size_t off = 0; off < m->pending.n; off += PIECE)
+      {
+        const size_t cnt = std::min(PIECE, m->pending.n - off);
+        for (int attempt = 0;; ++attempt)
+        {
+          uint32_t seq = 0;
+          int rc = enqueue_scatter(m, m->scan_dev + 3 * off, cnt, m->pending.pos, m->pending.up, false, s0, &seq);
+          if (rc != WS_OK) return done(rc);
+          const int pv = verdict(seq);
+          if (pv < 0) return done(pv);
+          if (pv == 0) break;
+          if ((pv & 2) || attempt >= 8)
+          {
+            set_error("TSDF update: a piece of the scan could not be placed");
+            return done(WS_ERR_INTERNAL);
+          }
+          rc = grow_pool(cnt);
+          if (rc != WS_OK) return done(rc);
+        }
+        m->new_is_default = false; // new_map carries the pieces so far
+        s0 = true;
+      }
+      if (m->pending.integrate_after)
+      {
+        const int rc = launch_tsdf_integrate(m);
+        if (rc != WS_OK) return done(rc);
+      }
+      return done(WS_OK);
+    }
     if (++m->pending.attempts > 8)
     {
       set_error("TSDF update: the scan did not fit the record pool it had just been given");
       return done(WS_ERR_INTERNAL);
     }
-    const unsigned long long need = *reinterpret_cast<volatile unsigned long long *>(m->status_host + 4) & ((1ull << 48) - 1ull);
-    uint64_t grow_to = subs_for_scan(m, need, m->pending.n);
-    if (grow_to < (uint64_t)m->sub_cap * 2) grow_to = (uint64_t)m->sub_cap * 2;
-    if (grow_to > SUB_ID_LIMIT)
-    {
-      set_error("TSDF update: the scan needs more than 2^27 record sub-chunks");
-      return done(WS_ERR_CAPACITY);
-    }
-    // (waits for the stream: the aborted update has drained and put its scratch back; leaves prepped == false: the new hash is
-    // filled by the preparation pass, the tile tables are zero already).  The repeat reads the copy of the scan the set-up pass
-    // of the aborted attempt has left in scan_dev, and takes the route (default / non-default new_map) of the first attempt.
-    int rc = resize_records(m, grow_to);
+    // The repeat reads the copy of the scan the set-up pass of the aborted attempt has left in scan_dev, and takes the route
+    // (default / non-default new_map) of the first attempt.
+    int rc = grow_pool(m->pending.n);
     if (rc == WS_OK) rc = enqueue_scatter(m, m->scan_dev, m->pending.n, m->pending.pos, m->pending.up, m->pending.fused, m->pending.s0, &m->pending.seq);
     if (rc == WS_OK && m->pending.integrate_after) rc = launch_tsdf_integrate(m);
     if (rc != WS_OK) return done(rc);
