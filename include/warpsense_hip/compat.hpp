@@ -302,7 +302,7 @@ public:
     new_map_.to_host(latest_map);
   }
   // addition: scan already resident on the device (e.g. ScanPreprocessor::points_dev()).  Asynchronous like a stream copy: the buffer must
-  // stay unchanged until the next call that takes this map (register_cloud, perform_registration, pause, to_host, the next update) has returned
+  // stay unchanged until the kernels of this call have read it (anything enqueued later on the context's stream is safe)
   void update_tsdf_dev(const int32_t *xyz_dev, size_t n, const rmagine::Pointi &scanner_pos, const rmagine::Pointi &up)
   {
     int rc = ws_tsdf_update_dev(map_, xyz_dev, n, &scanner_pos.x, &up.x);
