@@ -65,7 +65,7 @@ def main(prefix):
         except Exception:
             sha = "unknown"
     h = hashlib.sha256()
-    for f_ in ("tsdf_update.hip", "ws_march.h", "ws_device.h", "registration.hip", "api.hip"):
+    for f_ in ("tsdf_update.hip", "tsdf_integrate.hip", "ws_march.h", "ws_dda.h", "ws_device.h", "registration.hip", "api.hip"):
         with open(os.path.join(root, "warpsense_amd", "csrc", f_), "rb") as fh:
             h.update(fh.read())
     out["git_sha"] = sha

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_hip.so")
 H5_LIB_PATH = os.path.join(PKG_DIR, "libwarpsense_h5.so")  # optional: global-map file (needs the HDF5 C library)
-SOURCES = ["api.hip", "tsdf_update.hip", "registration.hip", "scan_preprocess.hip"]
+SOURCES = ["api.hip", "tsdf_update.hip", "tsdf_integrate.hip", "registration.hip", "scan_preprocess.hip"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_device.h"), os.path.join(CSRC, "ws_march.h"), os.path.join(CSRC, "ws_dda.h"),
            os.path.join(ROOT, "include", "warpsense_hip.h")]
 ARCH = "gfx950"

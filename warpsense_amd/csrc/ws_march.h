@@ -75,6 +75,22 @@ __host__ __device__ inline MarchFrame make_march_frame(const int32_t scanner_pos
   return f;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4; // four consecutive voxels of a column: dword aligned only
+
+// ring-buffer storage coordinates of a world voxel (device_map.h:93-101)
+__device__ __forceinline__ void storage_coords(const MapParams &m, int32_t vx, int32_t vy, int32_t vz, int32_t &sx, int32_t &sy, int32_t &sz)
+{
+  sx = ring(vx - m.pos[0] + m.offset[0] + m.size[0], m.size[0]);
+  sy = ring(vy - m.pos[1] + m.offset[1] + m.size[1], m.size[1]);
+  sz = ring(vz - m.pos[2] + m.offset[2] + m.size[2], m.size[2]);
+}
+__device__ __forceinline__ int64_t storage_index(const MapParams &m, int32_t sx, int32_t sy, int32_t sz)
+{
+  // sizes are below 2^24 and size[0] * size[1] below 2^31 (checked by ws_map_create): one full-rate 24-bit multiply-add
+  const int32_t row = (int32_t)(__umul24((uint32_t)sx, (uint32_t)m.size[1]) + (uint32_t)sy);
+  return (int64_t)row * (int64_t)m.size[2] + sz;
+}
 // Walk the steps [k0, k1) of one ray and call emit(k, fan_step, vx, vy, vz, value, positive) for every
 // write_tsdf_min the reference would issue (update_tsdf.cu:67-125): voxel in bounds, weight != 0.
 // `positive` = on-ray entry (step == mid, positive weight), else the weight is negated.
