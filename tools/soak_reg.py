@@ -3,7 +3,11 @@ must stop after the same number of Gauss-Newton iterations as the oracle and end
 (and equal the pose bit for bit in most cases -- counted).  The fixed cases live in tests/test_gpu_registration.py; this
 is for changes to the first wave's arithmetic (solve, exponential map) and to the reduction.
 
-    python tools/soak_reg.py [--cases 30] [--seed 1]
+    python tools/soak_reg.py [--cases 30] [--seed 1] [--server]
+
+--server: the reference's OWN loop shape instead (tsdf_registration.cpp:55-92): one perform_registration per iteration -- answered
+by the resident server behind ws_reg_iterate (round 6) -- and the oracle's host update (wso_gn_update) in between; every
+iteration's h, g, e, c and the final pose must be the oracle's bit for bit.
 """
 import argparse
 import os
@@ -29,6 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--server", action="store_true")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -57,8 +62,30 @@ def main():
         max_it = int(rng.choice([200, 200, 60]))
         rp = reg.params_.registration
         rp.max_iterations = max_it
-        T_gpu = reg.register_cloud(q, np.eye(4, dtype=np.float32))
         T_cpu, it_cpu, _ = O.register_cloud(oa, q, np.eye(4), max_it, rp.it_weight_gradient, rp.epsilon, res)
+        if args.server:
+            import ctypes as C
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_abi_and_host import OracleGnBackend
+            st = OracleGnBackend.State()
+            O.lib().wso_gn_begin(C.byref(st), O._p(O.colmajor(np.eye(4, dtype=np.float32))), int(max_it), C.c_float(rp.it_weight_gradient), C.c_float(rp.epsilon))
+            reg.reg_.prepare_registration(q)
+            its = 0
+            while not (st.finished or st.iterations >= st.max_iterations):
+                T = np.ctypeslib.as_array(st.T).reshape(4, 4).T.copy()
+                h, g, e, c = reg.reg_.perform_registration(reg.tsdf().device_map(), T, res)
+                ho, go, eo, co = O.reg_iterate(oa, T, q, res, reg.reg_.flags)
+                if not (c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)):
+                    print(f"case {case}: sums differ at iteration {its}")
+                    bad += 1
+                    break
+                sums = np.concatenate([h.T.reshape(-1), g, [e, c]]).astype(np.int64)
+                O.lib().wso_gn_update(C.byref(st), O._p(np.ascontiguousarray(sums)))
+                its += 1
+            T_gpu = np.ctypeslib.as_array(st.T).reshape(4, 4).T.copy()
+            reg.last_iterations = int(st.iterations)
+        else:
+            T_gpu = reg.register_cloud(q, np.eye(4, dtype=np.float32))
         dt, ang = pose_error(T_gpu, T_cpu)
         same = np.array_equal(np.asarray(T_gpu, dtype=np.float32), np.asarray(T_cpu, dtype=np.float32))
         exact += int(same)
