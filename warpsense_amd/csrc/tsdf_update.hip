@@ -1171,7 +1171,9 @@ __global__ __launch_bounds__(64 * WS_TAIL_WAVES, WS_TAIL_WGS * 4 / WS_TAIL_WAVES
   // the direction histogram has been consumed by the sort blocks of this scan: zero for the next one (no clean-up launch)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)(AZ_BINS + 1); i += gridDim.x * blockDim.x) a.az_hist[i] = 0;
   const uint32_t n_items = ((a.n + 63u) / 64u) * (uint32_t)TAIL_SPLIT;
-  if (a.counters->abort != 0) return; // (the set-up pass found a ray beyond the key range: the scan is repeated in pieces)
+  // (No look at counters->abort here, although a scan that the set-up pass has aborted for a ray beyond the key range could leave at
+  // once: the word shares its cache line with the pool's cursor, which other workgroups of THIS launch hit with atomics -- every
+  // workgroup starting with a load of it took the kernel from 135 to 210 us.  Such a scan marches in vain and is repeated in pieces.)
   if (blockIdx.x < n_items) tail_item<SMALL>(a, blockIdx.x);
 }
 
