@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void scatter_prep_kernel(PrepArgs p)
 {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   if (tid < (int64_t)(offsetof(TsdfCounters, last_records) / 4)) reinterpret_cast<uint32_t *>(p.counters)[tid] = 0;
+  if (tid == 0) p.counters->abort = p.counters->error = 0;
   for (int64_t i = tid; i < p.n_hist; i += stride) p.az_hist[i] = 0;
   for (int64_t i = tid; i < p.n_tiles; i += stride) p.tile_nsub[i] = 0;
   for (int64_t i = tid; i < (int64_t)(2 * tile_flag_plane_bytes(p.n_tiles)); i += stride) p.tile_dirty[i] = 0;

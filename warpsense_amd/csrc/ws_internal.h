@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
@@ -138,10 +139,10 @@ struct TileEntry // 16 bytes: one touched tile of the scan in flight
 
 struct TsdfCounters // device-resident
 {
+  // ---- the first line: what the marches hit with atomics while they run
   uint32_t chunk_cursor;  // sub-chunks handed out from the bottom of the pool by the tail march (reset by the set-up pass of the next scan)
   uint32_t n_listed;      // tiles with records (what the marches put on the tile list; final when the resolve starts; survives until the next scatter)
-  uint32_t error;         // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
-  uint32_t abort;         // != 0: the scan in flight ran out of chunks -- the later kernels only put the scratch back, the map stays as it was
+  uint32_t pad2[2];
   unsigned long long ub_total; // bits 0..47: sum of the per-ray record upper bounds of the scan; bits 48..63: set-up blocks that have added theirs
   uint32_t big_inserted;  // keys ever put into the (tile, chunk) hash since it was last emptied (the host empties it when it fills up)
   uint32_t free_cursor;   // sub-chunks handed out from the TOP of the pool by the free pass (one record each: a free-space candidate on a keyed voxel)
@@ -158,7 +159,13 @@ struct TsdfCounters // device-resident
   unsigned long long last_need; // record bound of the last scan
   uint32_t last_unlisted; // tiles without records (marks of the byte planes only) the resolve found by its scan
   uint32_t pad1;
+  // ---- a line of their own (round 6): the two words that EVERY workgroup of the free pass and of the resolve reads when it starts.
+  // Next to the cursors above they shared a cache line with the launch's own atomics -- a look at `abort` at the start of the tail
+  // march's workgroups took that kernel from 135 to 210 us.
+  alignas(128) uint32_t abort; // != 0: the scan in flight leaves no trace and is repeated -- bit 0: it ran out of sub-chunks, bit 1: a ray beyond the key range
+  uint32_t error;              // bits of this scatter (also OR-ed into the map's sticky host-visible error word)
 };
+static_assert(offsetof(TsdfCounters, abort) % 128 == 0 && offsetof(TsdfCounters, abort) >= 128, "TsdfCounters: abort / error in a line of their own");
 
 // device-resident Gauss-Newton state (tsdf_registration.cpp:28-96)
 struct GnCore
