@@ -50,9 +50,10 @@ typedef enum
   WS_ERR_CAPACITY = -4,    /* a scan that needs more than 2^27 record sub-chunks: returned by the NEXT call that takes the map (the one
                               that looks at the scan's verdict; the record pool itself cannot overflow: a scan that exhausts it is
                               repeated with a larger one) */
-  WS_ERR_RANGE = -5,       /* a ray with more ray steps / fan steps than the record's key holds for a scan of that many points: 65 536
-                              steps and 255 fan steps up to 2^14 points, 32 768 / 63 for the reference's 131 072-point scans, 8192 / 31
-                              for the 1 000 000-point maximum; the ray was dropped (sticky)                 */
+  WS_ERR_RANGE = -5,       /* a ray of more than 65 536 ray steps or 255 fan steps: beyond what the record's key holds even with the
+                              widest split; the ray was dropped (sticky).  (A scan whose OWN split is narrower -- 32 768 / 63 for the
+                              reference's 131 072-point scans, 8192 / 31 at a million points -- is repeated in pieces of 16 384
+                              points with the widest split instead: exact) */
   WS_ERR_TIMEOUT = -6,     /* ws_register_cloud_peers: a peer rank did not deliver (ws_register_cloud itself retries with one
                               launch per iteration instead of returning this) */
   WS_ERR_INTERNAL = -7     /* a device-side consistency check failed (sticky)            */
