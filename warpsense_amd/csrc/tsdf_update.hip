@@ -98,7 +98,7 @@ constexpr uint32_t ERR_RANGE = 2, ERR_FREE_BOUND = 4, ERR_INTERNAL = 8;
 #define WS_FREE_FIRST 32 // sub-chunks every wave of the free pass owns from the start (see pool_grab; 16: 136 us, 32: 121, 64: 120)
 #endif
 #ifndef WS_SORT_BLOCKS
-#define WS_SORT_BLOCKS 64
+#define WS_SORT_BLOCKS 128 // (64 / 128 / 256 / 512 blocks: set-up + sort 29.0 / 28.0 / 29.1 / 34 us)
 #endif
 #ifndef WS_SORT_RINGS
 #define WS_SORT_RINGS 16 // (tail march at 4 / 8 / 16 / 32 / 64 rings: 146 / 146 / 146 / 154 / 152 us, set-up pass 36 / 31 / 28 / 30 / 28)
@@ -508,10 +508,22 @@ __global__ __launch_bounds__(256) void ray_sort_kernel(ScatterArgs a)
   __syncthreads();
   const uint32_t b = blockIdx.x, nb = gridDim.x;
   if (b == 0 && threadIdx.x == 0) a.az_off[AZ_BINS] = s_off[AZ_BINS]; // rays that contribute: the tail march's grid
-  for (uint32_t ix = b * 256u + threadIdx.x; ix < a.n; ix += nb * 256u)
+  // (four rays per trip, their loads in flight together: one after the other the trips were a chain of memory round trips)
+  for (uint32_t ix0 = b * 256u + threadIdx.x; ix0 < a.n; ix0 += nb * 256u * 4u)
   {
-    const unsigned long long br = *reinterpret_cast<const unsigned long long *>(&a.ray_bin[ix]);
-    a.ray_order[s_off[(uint32_t)br] + (uint32_t)(br >> 32)] = ix;
+    unsigned long long br[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u)
+    {
+      const uint32_t ix = ix0 + u * nb * 256u;
+      br[u] = *reinterpret_cast<const unsigned long long *>(&a.ray_bin[ix < a.n ? ix : ix0]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u)
+    {
+      const uint32_t ix = ix0 + u * nb * 256u;
+      if (ix < a.n) a.ray_order[s_off[(uint32_t)br[u]] + (uint32_t)(br[u] >> 32)] = ix;
+    }
   }
 }
 __global__ __launch_bounds__(256) void ray_setup_kernel(ScatterArgs a) { ray_setup_block(a); }
