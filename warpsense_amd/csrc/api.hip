@@ -994,12 +994,12 @@ static int reg_iterate_served(ws_reg *r, const ws_map *m, const float T[16], int
   }
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
-  while (reg_server_mail_done(r->srv_mail) != seq)
+  while (!reg_server_mail_answer(r->srv_mail, seq, sums))
   {
     if (exited() == id)
     {
       // the server left (idle for too long, or asked to by another thread's call) without having seen this request
-      if (reg_server_mail_done(r->srv_mail) == seq) break;
+      if (reg_server_mail_answer(r->srv_mail, seq, sums)) break;
       const int rc = launch();
       if (rc != WS_OK) return rc;
     }
@@ -1011,7 +1011,6 @@ static int reg_iterate_served(ws_reg *r, const ws_map *m, const float T[16], int
       return WS_ERR_INTERNAL;
     }
   }
-  reg_server_mail_sums(r->srv_mail, sums);
   r->srv_served = seq;
   return WS_OK;
 }

@@ -1830,11 +1830,21 @@ struct ServerMail // host-mapped, 64-byte aligned
   uint32_t line[16];  // host -> device: pose words 0-2, 4-6, 8-10, 12-14 (column-major, rows 0-2); [3] request number (written
                       // last), [7] id of the launch the host wants gone, [11] checksum of the pose words and the number
   uint32_t pad[16];
-  int64_t sums[44];   // device -> host
-  int64_t done;       // device -> host: number of the request the sums belong to (written last)
+  // device -> host: the 44 sums in seven 64-byte lines of 7 words + a TAG: request number << 32 | a hash of the line's seven words.
+  // Every line validates itself, so nothing orders the lines against each other and the kernel does not wait for the writes'
+  // acknowledgement before it says "done" (one fabric round trip less per request): the host takes an answer when all seven tags
+  // carry its request number and match their lines.
+  uint64_t answer[7][8];
   int64_t exited;     // device -> host: id of the last launch that has left the GPU
 };
-static_assert(offsetof(ServerMail, sums) == 128, "ServerMail");
+static_assert(offsetof(ServerMail, answer) == 128, "ServerMail");
+__host__ __device__ inline uint64_t server_line_tag(uint32_t seq, const uint64_t *w /* 7 words */)
+{
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) x = (x << 7 | x >> 57) ^ w[k];
+  return ((uint64_t)seq << 32) | (uint32_t)(x ^ (x >> 32));
+}
 size_t reg_server_mail_bytes() { return sizeof(ServerMail); }
 __host__ __device__ inline uint32_t server_checksum(const uint32_t *line)
 {
@@ -1864,15 +1874,25 @@ void reg_server_mail_stop(void *mail, uint32_t launch_id)
   volatile uint32_t *dst = static_cast<ServerMail *>(mail)->line;
   dst[7] = launch_id;
 }
-uint32_t reg_server_mail_done(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->done); }
-uint32_t reg_server_mail_exited(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->exited); }
-void reg_server_mail_sums(const void *mail, int64_t sums[44])
+// the answer to request `seq`, if it is there completely: 1 and the 44 sums, else 0
+int reg_server_mail_answer(const void *mail, uint32_t seq, int64_t sums[44])
 {
-  std::atomic_thread_fence(std::memory_order_acquire);
-  const volatile int64_t *src = static_cast<const ServerMail *>(mail)->sums;
-  for (int k = 0; k < 44; ++k) sums[k] = src[k];
+  const ServerMail *m = static_cast<const ServerMail *>(mail);
+  uint64_t w[7][8];
+  for (int j = 0; j < 7; ++j)
+  {
+    const volatile uint64_t *src = m->answer[j];
+    const uint64_t tag = src[7];
+    if ((uint32_t)(tag >> 32) != seq) return 0;
+    for (int k = 0; k < 7; ++k) w[j][k] = src[k];
+    w[j][7] = tag;
+  }
+  for (int j = 0; j < 7; ++j)
+    if (server_line_tag(seq, w[j]) != w[j][7] || const_cast<volatile uint64_t *>(m->answer[j])[7] != w[j][7]) return 0; // (torn, or being rewritten)
+  for (int k = 0; k < 44; ++k) sums[k] = (int64_t)w[k / 7][k % 7];
+  return 1;
 }
-
+uint32_t reg_server_mail_exited(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->exited); }
 // Device memory of the server (ws_reg::srv_ctl, zero at creation, never reset afterwards):
 //   lines[REG_GROUPS][16]   the host's line as workgroup 0 has copied it, once per group of 32 workgroups: what a workgroup
 //                           polls -- request number, stop word, checksum and pose in ONE 64-byte read, 32 pollers per line
@@ -1914,13 +1934,27 @@ __device__ __forceinline__ int server_line_state(uint32_t w /* lane l < 16: word
   return c == (uint32_t)__builtin_amdgcn_readlane((int)w, 11) ? 1 : 0;
 }
 
+template <bool MFMA>
 __global__ __launch_bounds__(REG_THREADS) void reg_server_kernel(ServerArgs a)
 {
-  __shared__ int64_t wave_part[REG_THREADS / 64][REG_SLOTS];
+  __shared__ int64_t wave_part[MFMA ? 1 : REG_THREADS / 64][REG_SLOTS];
   __shared__ int64_t red[REG_SLOTS];
-  __shared__ float T_sh[16];
+  __shared__ unsigned long long wg_sum[REG_SLOTS + MF_AUX]; // MFMA: the workgroup's totals of a request (LDS atomics of the eight waves)
+  __shared__ alignas(16) uint32_t mf_stage[MFMA ? (REG_THREADS / 64) * MF_STAGE_WORDS : 4];
+  __shared__ alignas(16) float T_sh[16];
+  __shared__ alignas(16) int32_t TI_sh[16];
   __shared__ uint32_t bell_sh; // 0: leave
-  const Prefetched f = prefetch_points(a.pts); // the cloud does not change while a server lives (ws_reg_prepare* stops it)
+  // the cloud does not change while a server lives (ws_reg_prepare* stops it): its points stay in registers from call to call,
+  // and -- MFMA, clouds of at most one point per lane -- so does the voxel each point fell into with its seven entries (the map does
+  // not change either: whoever enqueues an update asks the server to leave first)
+  const Prefetched f = prefetch_points(a.pts);
+  const bool wave_has_points = __ballot(f.valid[0]) != 0ull;
+  const MfLane mfl = make_mf_lane();
+  const LoopGather lg = make_loop_gather(a.pts);
+  VoxelCache cache;
+  cache.bx = cache.by = cache.bz = 0;
+  cache.cur = cache.xn = cache.xl = cache.yn = cache.yl = cache.zn = cache.zl = 0;
+  cache.filled = false;
   constexpr uint32_t per_group = REG_BLOCKS / REG_GROUPS;
   const int lane = threadIdx.x & 63;
   const int group = (int)(blockIdx.x / per_group);
@@ -1931,6 +1965,7 @@ __global__ __launch_bounds__(REG_THREADS) void reg_server_kernel(ServerArgs a)
 #pragma unroll
     for (int g = 0; g < REG_GROUPS; ++g) then[g] = a.ctl->then[g][lane];
   }
+  if (MFMA && threadIdx.x < REG_SLOTS + MF_AUX) wg_sum[threadIdx.x] = 0;
   for (;;)
   {
     // ---- wave 0 waits for a request
@@ -1972,24 +2007,50 @@ __global__ __launch_bounds__(REG_THREADS) void reg_server_kernel(ServerArgs a)
           __builtin_amdgcn_s_sleep(4);
         }
       }
-      if (lane < 16) T_sh[lane] = __uint_as_float(w);
+      if (lane < 16)
+      {
+        T_sh[lane] = __uint_as_float(w);
+        if (MFMA) store_int_pose(TI_sh, lane, __uint_as_float(w)); // (cu_to_int_mat of the twelve words that are the pose; the other four are never read)
+      }
       if (lane == 0) bell_sh = state == 1 ? seq : 0u;
     }
     __syncthreads();
     const uint32_t bell = bell_sh;
     if (bell == 0) break;
     // ---- perform_registration (registration.cu:347-368) for that pose
-    float T[16];
+    if (MFMA)
+    {
+      // the sums on the matrix cores, as in the resident loop (reg_loop_kernel)
+      if (wave_has_points)
+      {
+        const IntTransform t = load_int_pose(TI_sh);
+        const Gathered g0 = gather_point_loop(a.pts, lg, t, f.p[0][0], f.p[0][1], f.p[0][2], f.valid[0], cache);
+        mf_v16i C;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
-    int64_t acc[REG_SLOTS];
+        for (int i = 0; i < 16; ++i) C[i] = 0;
+        mfma_consume(g0, C, mf_stage + (threadIdx.x >> 6) * MF_STAGE_WORDS, mfl);
+        mfma_flush(C, wg_sum, mfl);
+      }
+      __syncthreads(); // (also keeps T_sh / TI_sh / bell_sh from being rewritten while anybody reads them)
+    }
+    else
+    {
+      float T[16];
 #pragma unroll
-    for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
-    accumulate_points(a.pts, T, f, acc);
-    block_reduce32(acc, wave_part, red); // (its barriers also keep T_sh / bell_sh from being rewritten while anybody reads them)
+      for (int i = 0; i < 16; ++i) T[i] = T_sh[i];
+      int64_t acc[REG_SLOTS];
+#pragma unroll
+      for (int t = 0; t < REG_SLOTS; ++t) acc[t] = 0;
+      accumulate_points(a.pts, T, f, acc);
+      block_reduce32(acc, wave_part, red); // (its barriers: see above)
+    }
     if (threadIdx.x < 64)
     {
-      const uint64_t s = (uint64_t)red[lane & (REG_SLOTS - 1)];
+      uint64_t s;
+      if (MFMA)
+        s = mfma_finalize(wg_sum, mfl); // lanes 0..31 and 32..63: the total of slot lane & 31 (and wg_sum is zero again)
+      else
+        s = (uint64_t)red[lane & (REG_SLOTS - 1)];
       const uint32_t half = lane < REG_SLOTS ? (uint32_t)(s & 0xffffffffull) : (uint32_t)(s >> 32);
       __hip_atomic_fetch_add(&a.ctl->accum[group][lane], REG_COUNT_ONE | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (blockIdx.x == 0)
@@ -2017,22 +2078,28 @@ __global__ __launch_bounds__(REG_THREADS) void reg_server_kernel(ServerArgs a)
         }
         const uint64_t high = (uint64_t)shfl_xor_i64((int64_t)sum, 32);
         const int64_t total = (int64_t)(sum + (high << 32)); // lanes 0 .. 31: the total of slot `lane`
-        // expand_sums, one lane per word: lane k < 44 fetches the term it needs from the lane that holds it
+        // expand_sums: word k of the reference's 44 comes from the lane that holds its term; lane 8 j + i (i < 7) of the answer holds
+        // word 7 j + i, lane 8 j + 7 the tag of line j
+        const int line = lane >> 3, wi = lane & 7, k = 7 * line + wi;
         int src = 0;
-        if (lane < 36)
+        if (k < 36)
         {
-          const int i = lane % 6, j = lane / 6;
+          const int i = k % 6, j = k / 6;
           src = i <= j ? tri_index(i, j) : tri_index(j, i);
         }
-        else if (lane < 42)
-          src = 21 + (lane - 36);
-        else if (lane < 44)
-          src = 27 + (lane - 42);
+        else if (k < 42)
+          src = 21 + (k - 36);
+        else if (k < 44)
+          src = 27 + (k - 42);
         int64_t v = shfl_i64(total, src);
-        if (lane >= 42) v = (int64_t)(int32_t)v; // e and c are `int` in the reference (registration.cu:16-21)
-        if (lane < 44) __hip_atomic_store(&a.mail->sums[lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&a.mail->done, (int64_t)bell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (k >= 42) v = (int64_t)(int32_t)v; // e and c are `int` in the reference (registration.cu:16-21)
+        if (k >= 44 || wi == 7) v = 0;
+        // the tag of a line: from its seven words, gathered into the line's last lane
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) x = (x << 7 | x >> 57) ^ (uint64_t)shfl_i64(v, (lane & ~7) + q);
+        const uint64_t tag = ((uint64_t)bell << 32) | (uint32_t)(x ^ (x >> 32));
+        if (lane < 56) __hip_atomic_store(&a.mail->answer[line][wi], wi == 7 ? tag : (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     served = bell;
@@ -2145,7 +2212,11 @@ int launch_reg_server(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, u
   a.served = served;
   a.idle_ticks = idle_us * 100u; // wall_clock64: 100 MHz
   prof_begin(ctx, WS_K_REG);
-  hipLaunchKernelGGL(reg_server_kernel, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  // at most one point per lane (every scan the reference's 131 072-point buffers can hold): the sums come from the matrix cores
+  if (WS_REG_MFMA && (size_t)(a.pts.end - a.pts.first) <= (size_t)REG_BLOCKS * REG_THREADS)
+    hipLaunchKernelGGL(reg_server_kernel<true>, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(reg_server_kernel<false>, dim3(REG_BLOCKS), dim3(REG_THREADS), 0, ctx->stream, a);
   prof_end(ctx, WS_K_REG);
   WS_HIP(hipGetLastError());
   return WS_OK;

@@ -409,9 +409,8 @@ size_t reg_server_mail_bytes();
 size_t reg_server_ctl_bytes();
 void reg_server_mail_write(void *mail, const float T[16], uint32_t seq);
 void reg_server_mail_stop(void *mail, uint32_t launch_id);
-uint32_t reg_server_mail_done(const void *mail);
+int reg_server_mail_answer(const void *mail, uint32_t seq, int64_t sums[44]);
 uint32_t reg_server_mail_exited(const void *mail);
-void reg_server_mail_sums(const void *mail, int64_t sums[44]);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
 int launch_reg_loop(ws_reg *r, const ws_map *m, int32_t res, uint32_t flags, const ws::GnCore &init, bool peers = false, size_t first = 0, size_t count = 0);
