@@ -293,6 +293,17 @@ def test_loop_sums_on_a_map_of_arbitrary_entries(n, res):
             assert np.array_equal(g, go), (mode, max_it)
             assert np.array_equal(h, ho), (mode, max_it)
             assert np.array_equal(T, T_o.astype(np.float32)), (mode, max_it, np.abs(T - T_o).max())
+    # the same inputs through the resident server behind perform_registration (matrix cores up to 131 072 points, v_mad_i64_i32 beyond),
+    # twice: the second request answers from the voxels the first one cached
+    _server(rc, enable=1, idle_us=200000)
+    ho, go, eo, co = O.reg_iterate(om, T_in, q, res, rc.flags)
+    for _ in range(2):
+        h, g, e, c = rc.perform_registration(tsdf.device_map(), T_in, res)
+        assert (e, c) == (eo, co) and np.array_equal(g, go) and np.array_equal(h, ho)
+    T2 = (S.perturbation(300, 200, -100, 0.7) @ np.asarray(T_in, dtype=np.float64)).astype(np.float32)
+    ho, go, eo, co = O.reg_iterate(om, T2, q, res, rc.flags)
+    h, g, e, c = rc.perform_registration(tsdf.device_map(), T2, res)
+    assert (e, c) == (eo, co) and np.array_equal(g, go) and np.array_equal(h, ho)
     rc.close()
 
 
