@@ -194,7 +194,10 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out);
 int ws_reg_destroy(ws_reg *reg);
 /* RegistrationCuda::prepare_registration — registration.cu:303-308 */
 int ws_reg_prepare(ws_reg *reg, const int32_t *xyz_host, size_t n);
-int ws_reg_prepare_dev(ws_reg *reg, const int32_t *xyz_dev, size_t n); /* device-to-device copy */
+/* the same for a cloud in HBM: an asynchronous device-to-device copy on the context's stream (xyz_dev must stay unchanged until that
+ * copy has run: anything enqueued later on the context's stream is safe; a caller with streams of its own -- torch's allocator --
+ * keeps the buffer until the next ws_reg_prepare* or a ws_sync, as warpsense_amd/api.py does) */
+int ws_reg_prepare_dev(ws_reg *reg, const int32_t *xyz_dev, size_t n);
 /* the registration's own copy of the prepared cloud (device memory, n x 3 int32) and its point count; the pointer
  * changes when a larger cloud makes the buffer grow (callers that capture kernels into HIP graphs key on it) */
 const int32_t *ws_reg_points_dev(const ws_reg *reg, size_t *n);

@@ -630,7 +630,12 @@ class RegistrationCuda:
         n = int(points.shape[0])
         self.curr_n_points = n
         if _is_device(points):
+            # (an asynchronous device-to-device copy on the context's stream: like TSDFCuda.update_tsdf, keep the tensor away from
+            # torch's allocator until the next cloud's copy has been enqueued behind it)
+            prev = getattr(self, "_cloud_in_flight", None)
             check(self._L.ws_reg_prepare_dev(self.handle, _ptr(points), n), "ws_reg_prepare_dev")
+            self._cloud_in_flight = points
+            del prev
         else:
             pts = np.ascontiguousarray(points, dtype=np.int32)
             check(self._L.ws_reg_prepare(self.handle, _ptr(pts), n), "ws_reg_prepare")
