@@ -428,3 +428,36 @@ def test_a_reader_thread_beside_the_resident_server():
         th.join()
     assert not errs, errs
     assert n_reads[0] > 0
+
+
+def test_registrations_come_and_go_beside_a_reader_thread():
+    """every entry point that takes a map walks the context's list of registrations (a resident server must leave before other work
+    is enqueued): the list is guarded -- another thread may create and destroy registrations of the same context meanwhile"""
+    import threading
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene(rings=32, az=256)
+    ctx = reg.tsdf().ctx
+    lm = W.LocalMap(*oa.size, 1000, 0)
+    host = W.DeviceMap(lm.size.copy(), lm.offset.copy(), np.empty_like(lm.data), lm.pos.copy())
+    stop = threading.Event()
+    errs = []
+
+    def churn():
+        try:
+            while not stop.is_set():
+                rcs = [W.RegistrationCuda(None, ctx) for _ in range(4)]
+                for r in rcs:
+                    r.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        for _ in range(60):
+            reg.tsdf().avg_map().to_host(host)
+            assert np.array_equal(host.data_, oa.data)
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs

@@ -105,6 +105,7 @@ static int ctx_take_errors(ws_context *ctx);
 static void servers_leave(ws_context *ctx)
 {
   if (!ctx) return;
+  std::lock_guard<std::mutex> lock(ctx->lists_mu);
   for (ws_reg *r : ctx->regs)
   {
     const uint32_t id = r->srv_launch.load(std::memory_order_acquire);
@@ -190,7 +191,12 @@ int ws_sync(ws_context *ctx)
 {
   if (!ctx) return invalid("ws_sync: ctx is NULL");
   servers_leave(ctx);
-  for (ws_map *m : ctx->maps)
+  std::vector<ws_map *> maps;
+  {
+    std::lock_guard<std::mutex> lock(ctx->lists_mu);
+    maps = ctx->maps;
+  }
+  for (ws_map *m : maps)
   {
     const int rc = settle_tsdf(m); // (an aborted scan is repeated before the stream is drained)
     if (rc != WS_OK) return rc;
@@ -238,12 +244,15 @@ static int map_free(ws_map *m)
   if (!m) return WS_OK;
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->shift_stream) (void)hipStreamSynchronize(m->shift_stream);
-  for (size_t i = 0; i < m->ctx->maps.size(); ++i)
-    if (m->ctx->maps[i] == m)
-    {
-      m->ctx->maps.erase(m->ctx->maps.begin() + (long)i);
-      break;
-    }
+  {
+    std::lock_guard<std::mutex> lock(m->ctx->lists_mu);
+    for (size_t i = 0; i < m->ctx->maps.size(); ++i)
+      if (m->ctx->maps[i] == m)
+      {
+        m->ctx->maps.erase(m->ctx->maps.begin() + (long)i);
+        break;
+      }
+  }
   map_free_records(m);
   void *ptrs[] = {m->data[0], m->data[1], m->vstate, m->az_hist, m->az_off, m->ray_bin, m->ray_order, m->fan_steps, m->rays, m->scan_dev, m->counters, m->tile_nsub,
                   m->tile_ent, m->tile_dirty, m->tile_list, m->block_stats, m->box_stage};
@@ -294,6 +303,7 @@ static int map_take_error(ws_map *m)
 static int ctx_take_errors(ws_context *ctx)
 {
   int rc = WS_OK;
+  std::lock_guard<std::mutex> lock(ctx->lists_mu);
   for (ws_map *m : ctx->maps)
   {
     const int r = map_take_error(m);
@@ -417,7 +427,10 @@ int ws_map_create(ws_context *ctx, const int32_t size[3], const int32_t pos[3], 
     m->new_is_default = true;
   }
 #undef TRY
-  ctx->maps.push_back(m);
+  {
+    std::lock_guard<std::mutex> lock(ctx->lists_mu);
+    ctx->maps.push_back(m);
+  }
   *out = m;
   return WS_OK;
 }
@@ -822,6 +835,7 @@ int ws_reg_destroy(ws_reg *r)
   if (r->ctx)
   {
     servers_leave(r->ctx);
+    std::lock_guard<std::mutex> lock(r->ctx->lists_mu);
     auto &v = r->ctx->regs;
     for (size_t i = 0; i < v.size(); ++i)
       if (v[i] == r)
@@ -903,7 +917,10 @@ int ws_reg_create(ws_context *ctx, size_t max_points, ws_reg **out)
     ws_reg_destroy(r);
     return rc;
   }
-  ctx->regs.push_back(r);
+  {
+    std::lock_guard<std::mutex> lock(ctx->lists_mu);
+    ctx->regs.push_back(r);
+  }
   *out = r;
   return WS_OK;
 }

@@ -203,6 +203,7 @@ struct ws_context
   };
   std::vector<Span> spans;       // recorded, not yet resolved
   std::vector<hipEvent_t> pool;  // free events
+  std::mutex lists_mu;           // guards the two lists below (objects are created and destroyed while another thread's call walks them)
   std::vector<struct ws_map *> maps; // maps of this context (sticky device-side errors are reported at ws_sync)
   std::vector<struct ws_reg *> regs; // registrations of this context (a resident server of ws_reg_iterate is asked to leave by whoever enqueues other work)
   double prof_ms[WS_K_COUNT] = {};
