@@ -269,6 +269,9 @@ int ws_debug_reg_stall(ws_reg *reg, int32_t stall_next, int32_t *fallbacks);
 /* test / tuning entry: the resident server behind ws_reg_iterate (enable: 1 / 0, -1 = leave as it is; idle_us > 0: how long it
  * stays without a request, default 50); *launches = servers started so far on this handle */
 int ws_debug_reg_server(ws_reg *reg, int32_t enable, int32_t idle_us, int32_t *launches);
+/* Test entry, no GPU needed: the host half of the server's mail protocol (request line with checksum, the answer's seven tagged lines:
+ * stale, incomplete and torn answers must not be taken).  0: as expected, else a bit per failed case. */
+int ws_debug_reg_mail_selftest(void);
 
 /* Test entry: the 44 sums (h[36] column-major, g[6], e, c -- the out-parameters of perform_registration, registration.cu:347-368)
  * the LAST Gauss-Newton update of the last ws_register_cloud / ws_register_cloud_peers on `reg` was made from.  Synchronises. */

@@ -312,3 +312,11 @@ def test_bench_gpus_flag_starts_the_ranks_or_checks_the_launcher(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit):
         bench.self_launch(argparse.Namespace(gpus=4))
+
+
+def test_the_servers_mail_protocol_on_the_host_side():
+    """the resident server behind ws_reg_iterate answers in seven 64-byte lines of seven words + a tag (request number, hash of the
+    words) that it writes without waiting: the host must not take a stale answer, one that has not arrived completely, or a torn
+    line -- exercised on ordinary memory, no GPU (ws_debug_reg_mail_selftest returns a bit per failed case)"""
+    from warpsense_amd import _lib
+    assert _lib.load().ws_debug_reg_mail_selftest() == 0

@@ -27,7 +27,7 @@ EXPORTS = [
     "ws_tsdf_integrate", "ws_tsdf_set_integrate", "ws_tsdf_set_capacity", "ws_debug_tsdf_chunk_policy", "ws_tsdf_stats", "ws_reg_create", "ws_reg_destroy", "ws_reg_prepare",
     "ws_reg_prepare_dev", "ws_reg_points_dev", "ws_reg_iterate", "ws_register_cloud", "ws_reg_begin", "ws_reg_accumulate_dev",
     "ws_reg_solve_dev", "ws_reg_iterate_shard_dev", "ws_reg_poll", "ws_reg_peer_mailbox", "ws_reg_peer_connect", "ws_reg_peer_connect_local",
-    "ws_reg_peer_disconnect", "ws_reg_peer_reset", "ws_register_cloud_peers", "ws_reg_set_loop", "ws_debug_solve6", "ws_debug_reg_stall", "ws_debug_reg_server", "ws_debug_reg_sums", "ws_debug_block_stats", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
+    "ws_reg_peer_disconnect", "ws_reg_peer_reset", "ws_register_cloud_peers", "ws_reg_set_loop", "ws_debug_solve6", "ws_debug_reg_stall", "ws_debug_reg_server", "ws_debug_reg_mail_selftest", "ws_debug_reg_sums", "ws_debug_block_stats", "ws_scan_create", "ws_scan_destroy", "ws_scan_preprocess",
     "ws_scan_preprocess_dev", "ws_scan_points_dev", "ws_scan_download", "ws_prof_enable", "ws_prof_read", "ws_prof_reset",
 ]
 
@@ -152,6 +152,7 @@ def load() -> C.CDLL:
     L.ws_debug_solve6.argtypes = [vp, vp, vp, sz, vp, vp]
     L.ws_debug_reg_stall.argtypes = [vp, C.c_int32, vp]
     L.ws_debug_reg_server.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    L.ws_debug_reg_mail_selftest.argtypes = []
     L.ws_debug_reg_sums.argtypes = [vp, vp]
     L.ws_debug_block_stats.argtypes = [vp, vp, sz]
     L.ws_debug_tsdf_chunk_policy.argtypes = [vp, C.c_uint64, u32]

@@ -1084,6 +1084,8 @@ int ws_reg_iterate(ws_reg *r, const ws_map *m, const float T[16], int32_t res, u
 }
 
 // test / tuning entry: the resident server of ws_reg_iterate on or off, its idle time; returns the servers launched so far
+int ws_debug_reg_mail_selftest(void) { return reg_server_mail_selftest(); }
+
 int ws_debug_reg_server(ws_reg *r, int32_t enable, int32_t idle_us, int32_t *launches)
 {
   if (!r) return invalid("ws_debug_reg_server: reg is NULL");

@@ -1892,6 +1892,58 @@ int reg_server_mail_answer(const void *mail, uint32_t seq, int64_t sums[44])
   for (int k = 0; k < 44; ++k) sums[k] = (int64_t)w[k / 7][k % 7];
   return 1;
 }
+// host half of the protocol without a GPU (tests): a mail block in ordinary memory, an answer written as the kernel writes it, then
+// everything that must make the host wait -- a stale request number, a line of the previous answer, a torn line.  0: all as expected
+int reg_server_mail_selftest()
+{
+  ServerMail *m = new ServerMail();
+  std::memset(m, 0, sizeof *m);
+  int64_t want[44], got[44];
+  auto fill = [&](uint32_t seq, int64_t salt) {
+    for (int k = 0; k < 44; ++k) want[k] = (int64_t)(0x9E3779B97F4A7C15ull * (uint64_t)(k + 1)) ^ (salt << 17);
+    for (int j = 0; j < 7; ++j)
+    {
+      uint64_t w[7];
+      for (int k = 0; k < 7; ++k) w[k] = 7 * j + k < 44 ? (uint64_t)want[7 * j + k] : 0ull;
+      for (int k = 0; k < 7; ++k) m->answer[j][k] = w[k];
+      m->answer[j][7] = server_line_tag(seq, w);
+    }
+  };
+  int bad = 0;
+  if (reg_server_mail_answer(m, 1, got)) bad |= 1; // nothing written yet
+  fill(5, 1);
+  if (!reg_server_mail_answer(m, 5, got) || std::memcmp(got, want, sizeof want) != 0) bad |= 2;
+  if (reg_server_mail_answer(m, 6, got) || reg_server_mail_answer(m, 4, got)) bad |= 4; // another request's answer
+  // the next answer arrives line by line: incomplete until the last line is there
+  int64_t old[44];
+  std::memcpy(old, want, sizeof old);
+  const ServerMail before = *m;
+  fill(6, 2);
+  const ServerMail after = *m;
+  for (int upto = 0; upto < 7; ++upto)
+  {
+    *m = before;
+    for (int j = 0; j <= upto; ++j) std::memcpy(m->answer[j], after.answer[j], sizeof m->answer[j]);
+    const int ok = reg_server_mail_answer(m, 6, got);
+    if (upto < 6 ? ok != 0 : (ok == 0 || std::memcmp(got, want, sizeof want) != 0)) bad |= 8;
+  }
+  // a torn line: words of the new answer under the old tag, and the other way round
+  *m = after;
+  m->answer[3][2] = before.answer[3][2];
+  if (reg_server_mail_answer(m, 6, got)) bad |= 16;
+  *m = after;
+  m->answer[3][7] = before.answer[3][7];
+  if (reg_server_mail_answer(m, 6, got)) bad |= 32;
+  // the request line: what the host writes is what the kernel's checksum accepts
+  float T[16];
+  for (int i = 0; i < 16; ++i) T[i] = 0.25f * (float)i - 1.f;
+  reg_server_mail_write(m, T, 77);
+  uint32_t line[16];
+  for (int i = 0; i < 16; ++i) line[i] = m->line[i];
+  if (line[3] != 77 || line[11] != server_checksum(line)) bad |= 64;
+  delete m;
+  return bad;
+}
 uint32_t reg_server_mail_exited(const void *mail) { return (uint32_t) * const_cast<volatile int64_t *>(&static_cast<const ServerMail *>(mail)->exited); }
 // Device memory of the server (ws_reg::srv_ctl, zero at creation, never reset afterwards):
 //   lines[REG_GROUPS][16]   the host's line as workgroup 0 has copied it, once per group of 32 workgroups: what a workgroup

@@ -411,6 +411,7 @@ size_t reg_server_ctl_bytes();
 void reg_server_mail_write(void *mail, const float T[16], uint32_t seq);
 void reg_server_mail_stop(void *mail, uint32_t launch_id);
 int reg_server_mail_answer(const void *mail, uint32_t seq, int64_t sums[44]);
+int reg_server_mail_selftest();
 uint32_t reg_server_mail_exited(const void *mail);
 int launch_scan_preprocess(ws_scan *sc, const float *xyz_dev, size_t n, size_t stride, const int32_t M[16], int32_t res);
 size_t pre_table_slots(size_t max_points);
