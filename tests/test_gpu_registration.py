@@ -461,3 +461,43 @@ def test_registrations_come_and_go_beside_a_reader_thread():
         stop.set()
         th.join()
     assert not errs, errs
+
+
+def test_the_resident_server_behind_a_long_upload_of_another_thread():
+    """another thread keeps uploading a 270 MB map (tens of milliseconds each, far beyond the time a caller spins for the server's
+    answer): the server is asked to leave, a new one waits in the stream behind the copy -- the call drains the stream and takes the
+    answer then; every answer is exact, none is an error.  (The uploads write the map's own content back: the answers do not change.)"""
+    import threading
+    import warpsense_amd as W
+    reg, oa, pts, res = build_scene(size=(512, 512, 256), rings=32, az=256)
+    rc = reg.reg_
+    _server(rc, enable=1, idle_us=300)
+    q = S.transform_points_mm(pts, S.perturbation(40, -30, 10, 2.0))
+    rc.prepare_registration(q)
+    poses = [S.perturbation(2.0 * k - 20, 18 - k, -9 + 0.5 * k, 0.1 * k - 1.2) for k in range(12)]
+    want = [O.reg_iterate(oa, T, q, res, rc.flags) for T in poses]
+    host = W.DeviceMap(oa.size.copy(), oa.offset.copy(), oa.data.copy(), oa.pos.copy())
+    stop = threading.Event()
+    errs = []
+    n_up = [0]
+
+    def uploader():
+        try:
+            while not stop.is_set():
+                reg.tsdf().avg_map().to_device(host)
+                n_up[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=uploader)
+    th.start()
+    try:
+        for rep in range(3):
+            for T, (ho, go, eo, co) in zip(poses, want):
+                h, g, e, c = rc.perform_registration(reg.tsdf().device_map(), T, res)
+                assert c == co and e == eo and np.array_equal(g, go) and np.array_equal(h, ho)
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+    assert n_up[0] > 0

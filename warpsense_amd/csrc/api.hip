@@ -1020,10 +1020,21 @@ static int reg_iterate_served(ws_reg *r, const ws_map *m, const float T[16], int
       const int rc = launch();
       if (rc != WS_OK) return rc;
     }
-    if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+    if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
     {
-      reg_server_mail_stop(r->srv_mail, id);
+      // Not an error yet: the server may be waiting in the stream behind somebody else's work (another thread's upload of a large
+      // map takes longer than this).  Drain the stream the ordinary way -- a server that starts finds the request, answers it and
+      // leaves when nothing else comes -- and only then look again; a kernel that never ends is the runtime's to report.
       WS_HIP(hipStreamSynchronize(r->ctx->stream));
+      if (reg_server_mail_answer(r->srv_mail, seq, sums)) break;
+      if (exited() == id)
+      {
+        // (it left on another thread's request without having seen this one: the next turn of the loop starts a new one)
+        const int rc = launch();
+        if (rc != WS_OK) return rc;
+        WS_HIP(hipStreamSynchronize(r->ctx->stream));
+        if (reg_server_mail_answer(r->srv_mail, seq, sums)) break;
+      }
       set_error("ws_reg_iterate: the resident server did not answer");
       return WS_ERR_INTERNAL;
     }

@@ -1974,8 +1974,11 @@ struct ServerArgs
 __device__ __forceinline__ int server_line_state(uint32_t w /* lane l < 16: word l */, uint32_t served, uint32_t launch_id, uint32_t &seq)
 {
   seq = (uint32_t)__builtin_amdgcn_readlane((int)w, 3);
-  if ((uint32_t)__builtin_amdgcn_readlane((int)w, 7) == launch_id) return 2;
-  if (seq == served || seq == 0) return 0;
+  // A request that is waiting is answered BEFORE the server obeys a word to leave: the word comes from another thread's call, whose
+  // work is ordered behind this kernel either way, and a caller whose every new server found that word already there (a thread that
+  // uploads maps in a loop asks each of them to leave before it has started) would never be answered.
+  const bool leave = (uint32_t)__builtin_amdgcn_readlane((int)w, 7) == launch_id;
+  if (seq == served || seq == 0) return leave ? 2 : 0;
   // a consistent snapshot?  (the writer stores the number last; a read that saw it and not all of the pose -- torn in two on the
   // way -- fails the checksum and is simply repeated)
   uint32_t c = 0x5bd1e995u ^ seq;
