@@ -22,6 +22,13 @@ def _gpu_available() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
+    # a test that hangs (a spin on a word the GPU never writes) must fail, not hold the box until somebody's limit ends the run:
+    # ten minutes per test where pytest-timeout is installed (the slowest test takes 25 s), by a watchdog thread -- the spins sit in
+    # C code that a signal handler cannot interrupt
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600, method="thread"))
     if _gpu_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
