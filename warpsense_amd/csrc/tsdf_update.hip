@@ -1531,15 +1531,18 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
   const int lane = threadIdx.x & 63;
   const uint32_t half = threadIdx.x >> 5, pos = threadIdx.x & 31u;
   constexpr int U = WS_STREAM_U;
-  for (uint32_t b0 = first; b0 < nsub; b0 += 64) // (first: 0 or 64 -- the first 64 entries may be in the caller's registers)
+  // (first: a multiple of 8 below or at 64 -- the entries in front of it are in the caller's registers; a batch stays inside one block of
+  // 64 entries: lane l of every wave holds entry 64 (b0 / 64) + l)
+  for (uint32_t b0 = first; b0 < nsub; b0 = (b0 & ~63u) + 64u)
   {
+    const uint32_t blk0 = b0 & ~63u, in0 = b0 & 63u;
     uint32_t ents = cid;
-    if (b0 == 64)
+    if (blk0 == 64)
       ents = a.tile_ent[(size_t)tile * TILE_DIRECT + 64u + (uint32_t)lane];
-    else if (b0 > 64)
-      ents = b0 + (uint32_t)lane < nsub ? resolve_entry(a, tile, b0 + (uint32_t)lane) : ENT_NONE;
-    const uint32_t nb = min(64u, nsub - b0);
-    for (uint32_t j0 = 0; j0 < nb; j0 += 8u * U)
+    else if (blk0 > 64)
+      ents = blk0 + (uint32_t)lane < nsub ? resolve_entry(a, tile, blk0 + (uint32_t)lane) : ENT_NONE;
+    const uint32_t nb = min(64u, nsub - blk0); // entries of this block
+    for (uint32_t j0 = in0; j0 < nb; j0 += 8u * U)
     {
       unsigned long long rec[U];
       bool ok[U];
@@ -1569,7 +1572,9 @@ __device__ __forceinline__ void for_each_record(const ResolveArgs &a, uint32_t t
 #define WS_RESOLVE_WGS 5 // (107 -> 102 VGPRs without spills, 29 KB of LDS: 4 -> 5 workgroups per CU, 139 -> 130 us)
 #endif
 constexpr int RES_MAXR = WS_RES_MAXR;   // records a thread keeps in registers (2048 record places = 64 sub-chunks per tile); larger tiles re-read them per pass
-static_assert(RES_MAXR * 8 <= 64 && TILE_DIRECT == 128, "the register route reads the first 64 entries of the tile's direct table, the streaming route the other 64");
+static_assert(RES_MAXR >= 1 && RES_MAXR * 8 <= 64 && TILE_DIRECT == 128, "the register route reads the first 8 RES_MAXR <= 64 entries of the tile's direct table, the streaming route the rest");
+// (RES_MAXR 4 / 5 / 6 / 7 / 8, same box: the resolve 108-110 / 108 / 105-106 / 104-105 / 102-103 us -- fewer registers buy no sixth
+// workgroup per CU, 28 KB of LDS and the other ~80 registers cap it at five, and the sub-chunks beyond the registers are streamed per pass)
 
 // what a thread needs of a tile before it can start, requested two tiles ahead
 struct TilePre
